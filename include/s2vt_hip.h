@@ -1,0 +1,154 @@
+/*
+ * s2vt_hip.h — C ABI of libs2vt_hip.so: the MI355X (gfx950) implementation of the S2VT hot path.
+ *
+ * The reference (Kamino666/S2VT-video-caption) has no native boundary: the path sits behind the
+ * Python class `S2VT(nn.Module)` (S2VTModel.py:10-110) and `MaskCriterion` (utils.py:6-26) and all
+ * arithmetic is delegated to torch ops.  Each entry point below therefore names the reference call
+ * site(s) whose torch op(s) it replaces; `S2VTModel.py` / `utils.py` at the root of this repository
+ * are the reference-side bindings (ctypes) a maintainer would drop in — see INTEGRATION.md.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a positive hipError_t or -1 (bad argument) on failure;
+ *    `s2vt_last_error()` gives the message (thread-local).  No C++ exception crosses the ABI.
+ *  - all pointers are DEVICE pointers into memory owned by the caller (torch); fp32 unless noted;
+ *    parameter tensors use the reference's state_dict layout.
+ *  - every call is asynchronous and ordered on `stream` (a hipStream_t passed as void*); nothing is
+ *    allocated: scratch comes from the caller-provided workspace (size from *_workspace_bytes).
+ *  - dims: B batch, L = `length` frames (= padded caption length), F feat_dim, H dim_hid,
+ *    E dim_embed, V vocab_size; T = 2L-1 LSTM steps.  Internal activations are time-major
+ *    [t][b][:]; the external tensors keep the reference's batch-major layout.
+ */
+#ifndef S2VT_HIP_H
+#define S2VT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2VT_ABI_VERSION 1
+
+typedef struct s2vt_dims {
+    int32_t B, L, F, H, E, V;
+} s2vt_dims;
+
+/* The 13 parameter tensors of S2VT.__init__ (S2VTModel.py:19-28), reference names in comments. */
+typedef struct s2vt_params {
+    const float* vid_w_ih;  /* vid_rnn.weight_ih_l0  [4H, H]   */
+    const float* vid_w_hh;  /* vid_rnn.weight_hh_l0  [4H, H]   */
+    const float* vid_b_ih;  /* vid_rnn.bias_ih_l0    [4H]      */
+    const float* vid_b_hh;  /* vid_rnn.bias_hh_l0    [4H]      */
+    const float* word_w_ih; /* word_rnn.weight_ih_l0 [4H, E+H] columns = [embed | vid_out] (S2VTModel.py:75) */
+    const float* word_w_hh; /* word_rnn.weight_hh_l0 [4H, H]   */
+    const float* word_b_ih; /* word_rnn.bias_ih_l0   [4H]      */
+    const float* word_b_hh; /* word_rnn.bias_hh_l0   [4H]      */
+    const float* feat_w;    /* feat_linear.weight    [H, F]    */
+    const float* feat_b;    /* feat_linear.bias      [H]       */
+    const float* out_w;     /* out_linear.weight     [V, H]    */
+    const float* out_b;     /* out_linear.bias       [V]       */
+    const float* emb_w;     /* embedding.weight      [V, E]    */
+} s2vt_params;
+
+/* Gradient outputs, same order and shapes; every tensor is OVERWRITTEN (not accumulated). */
+typedef struct s2vt_grads {
+    float* vid_w_ih; float* vid_w_hh; float* vid_b_ih; float* vid_b_hh;
+    float* word_w_ih; float* word_w_hh; float* word_b_ih; float* word_b_hh;
+    float* feat_w; float* feat_b; float* out_w; float* out_b; float* emb_w;
+} s2vt_grads;
+
+int s2vt_abi_version(void);
+const char* s2vt_last_error(void);
+
+/* ---------------------------------------------------------------- whole-path entry points */
+
+/* Bytes of workspace s2vt_train_forward/backward need (saved activations + scratch). */
+size_t s2vt_train_workspace_bytes(const s2vt_dims* d);
+
+/* S2VT.forward(feats, targets, mode='train')  (S2VTModel.py:48-54, 63-81; called at train.py:120,142).
+ *   feats   [B, L, F]; targets int64 [B, L-1] with row stride targets_ld (= caption[:, :-1]);
+ *   logits  [B, L-1, V] out.  The workspace then holds what s2vt_train_backward needs. */
+int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
+                       int64_t targets_ld, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Autograd of the above (loss.backward(), train.py:124) given dlogits [B, L-1, V] (contiguous).
+ * dfeats [B, L, F] may be NULL (nothing reads it in the reference: SURVEY.md §3.1 note). */
+int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
+                        const s2vt_grads* g, float* dfeats, void* workspace, size_t workspace_bytes, void* stream);
+
+size_t s2vt_decode_workspace_bytes(const s2vt_dims* d);
+
+/* S2VT.forward(feats, mode='test')  (S2VTModel.py:82-110; called at eval.py:52): greedy decode,
+ * ids int64 [B, L-1] out, never stops at <eos>, lowest index wins argmax ties. */
+int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* MaskCriterion's inner nn.CrossEntropyLoss() (utils.py:11,22): mean CE of logits [B, L-1, V] against
+ * target[:, 1:] (target int64 [B, L], row stride target_ld).  lse [B*(L-1)] and rowloss [B*(L-1)] are
+ * caller-provided scratch (lse is consumed by the backward); loss_out is one device float. */
+int s2vt_mean_ce_forward(int32_t B, int32_t Lm1, int32_t V, const float* logits, const int64_t* target,
+                         int64_t target_ld, float* lse, float* rowloss, float* loss_out, void* stream);
+/* dlogits = (softmax(logits) - onehot(target)) * gout[0] / (B*(L-1)); gout is a device scalar. */
+int s2vt_mean_ce_backward(int32_t B, int32_t Lm1, int32_t V, const float* logits, const int64_t* target,
+                          int64_t target_ld, const float* lse, const float* gout, float* dlogits, void* stream);
+
+/* ---------------------------------------------------------------- per-op entry points
+ * (the pieces the whole-path drivers are built from; exported for tests, profiling and reuse) */
+
+/* C[M,N] (+)= op(A)·op(B) (+ bias[N]) in fp32 on the matrix cores.
+ *   a_kmajor: A stored [M][K] (else [K][M]);  b_kmajor: B stored [N][K] (else [K][N]).
+ * Stands for torch's addmm/mm under nn.Linear / nn.LSTM input projections (S2VTModel.py:54,67,77,80). */
+int s2vt_gemm_f32(int32_t a_kmajor, int32_t b_kmajor, int32_t M, int32_t N, int32_t K, const float* A, int64_t lda,
+                  const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t accumulate,
+                  void* stream);
+
+/* feat_linear (S2VTModel.py:54): x1[l*B+b, :] = feats[b, l, :]·W^T + bias  (time-major output [L*B, H]). */
+int s2vt_feat_proj_fwd(const s2vt_dims* d, const float* feats, const float* w, const float* bias, float* x1,
+                       void* stream);
+/* its weight/bias gradients from dx1 [L*B, H] (time-major); dfeats optional. colsum_ws: >= s2vt_colsum_ws_floats(L*B, H) floats. */
+int s2vt_feat_proj_bwd(const s2vt_dims* d, const float* feats, const float* w, const float* dx1, float* dw,
+                       float* dbias, float* dfeats, float* colsum_ws, void* stream);
+size_t s2vt_colsum_ws_floats(int64_t rows, int32_t cols);
+
+/* One LSTM timestep, gates i,f,g,o (what nn.LSTM runs per step: S2VTModel.py:67,77,86,93,103):
+ *   G = gx (or bias if gx == NULL) + h_prev·W_hh^T ; cell update; writes h_out, c_out and, if stash != NULL,
+ *   the activated gates [B,4H] for the backward.  h_prev/c_prev NULL = zero state.  Row stride of every
+ *   [B, *] operand = its natural width. */
+int s2vt_lstm_step_fwd(int32_t B, int32_t H, const float* gx, const float* bias, const float* w_hh,
+                       const float* h_prev, const float* c_prev, float* h_out, float* c_out, float* stash,
+                       void* stream);
+/* BPTT of one step: dh = dh_out + dg_next·W_hh (w_hh_t = W_hh^T [H,4H]); dc (in/out, [B,H]) carries dL/dc;
+ * dg [B,4H] out (may alias stash). dg_next NULL at the last step; dc_is_zero = 1 there. */
+int s2vt_lstm_step_bwd(int32_t B, int32_t H, const float* dg_next, const float* w_hh_t, const float* dh_out,
+                       const float* stash, const float* c, const float* c_prev, float* dc, int32_t dc_is_zero,
+                       float* dg, void* stream);
+
+/* A whole layer: T steps from zero state. gx [n_gx*B, 4H] time-major covers steps 0..n_gx-1 (x-part + both
+ * biases); later steps see `bias` only (the zero-padded input of S2VTModel.py:64-65).
+ * Outputs time-major h_all/c_all [T*B, H], stash [T*B, 4H] (may alias gx). */
+int s2vt_lstm_seq_fwd(int32_t T, int32_t B, int32_t H, const float* gx, int32_t n_gx, const float* bias,
+                      const float* w_hh, float* h_all, float* c_all, float* stash, void* stream);
+/* BPTT over the layer: dh_out [T*B, H] time-major with dh_out rows for steps < dh_first absent (treated as 0);
+ * stash is overwritten by dG [T*B,4H]; w_hh_t and dc [B,H] are scratch provided by the caller. */
+int s2vt_lstm_seq_bwd(int32_t T, int32_t B, int32_t H, const float* w_hh, const float* dh_out, int32_t dh_first,
+                      const float* c_all, float* stash_dg, float* w_hh_t, float* dc, void* stream);
+
+/* One greedy decode step's out_linear + argmax (S2VTModel.py:95-96,105-106): packed[b] (zeroed by the caller)
+ * receives max over v of (ordered(logit) << 32 | (0xFFFFFFFF - v)); token = 0xFFFFFFFF - low 32 bits. */
+int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, const float* w_out, const float* b_out,
+                            unsigned long long* packed, void* stream);
+
+/* ---------------------------------------------------------------- live kernel timing (bench.py)
+ * When enabled, launch sites bracket kernels of one kind with hipEvents on the launch stream.
+ * kinds: 0 gemm, 1 lstm_step_fwd (whole sequence loop), 2 lstm_step_bwd (whole sequence loop),
+ *        3 ce, 4 logits_argmax. */
+int s2vt_prof_enable(int32_t on);
+/* Synchronises the recorded events; returns summed milliseconds and launch count for `kind`. */
+int s2vt_prof_read(int32_t kind, double* total_ms, int64_t* launches);
+int s2vt_prof_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* S2VT_HIP_H */

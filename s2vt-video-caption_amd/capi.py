@@ -1,0 +1,103 @@
+"""ctypes binding of include/s2vt_hip.h (libs2vt_hip.so).
+
+This is plumbing only: torch owns every tensor, this module passes raw device pointers, sizes and the
+current HIP stream.  There is no CPU fallback: if the library cannot be loaded the import of the
+compute path fails loudly.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_double, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libs2vt_hip.so")
+
+
+class Dims(ctypes.Structure):
+    _fields_ = [(n, c_int32) for n in ("B", "L", "F", "H", "E", "V")]
+
+
+PARAM_FIELDS = ("vid_w_ih", "vid_w_hh", "vid_b_ih", "vid_b_hh", "word_w_ih", "word_w_hh", "word_b_ih", "word_b_hh",
+                "feat_w", "feat_b", "out_w", "out_b", "emb_w")
+# state_dict keys in the same order
+PARAM_KEYS = ("vid_rnn.weight_ih_l0", "vid_rnn.weight_hh_l0", "vid_rnn.bias_ih_l0", "vid_rnn.bias_hh_l0",
+              "word_rnn.weight_ih_l0", "word_rnn.weight_hh_l0", "word_rnn.bias_ih_l0", "word_rnn.bias_hh_l0",
+              "feat_linear.weight", "feat_linear.bias", "out_linear.weight", "out_linear.bias", "embedding.weight")
+
+
+class Params(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in PARAM_FIELDS]
+
+
+class Grads(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in PARAM_FIELDS]
+
+
+# name -> (restype, argtypes): every symbol include/s2vt_hip.h declares
+SIGNATURES = {
+    "s2vt_abi_version": (c_int32, []),
+    "s2vt_last_error": (c_char_p, []),
+    "s2vt_train_workspace_bytes": (c_size_t, [POINTER(Dims)]),
+    "s2vt_train_forward": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
+    "s2vt_train_backward": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_void_p, POINTER(Grads), c_void_p,
+                                      c_void_p, c_size_t, c_void_p]),
+    "s2vt_decode_workspace_bytes": (c_size_t, [POINTER(Dims)]),
+    "s2vt_greedy_decode": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_int32, c_void_p, c_void_p, c_size_t,
+                                     c_void_p]),
+    "s2vt_mean_ce_forward": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
+    "s2vt_mean_ce_backward": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
+    "s2vt_gemm_f32": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64,
+                                c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
+    "s2vt_feat_proj_fwd": (c_int32, [POINTER(Dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "s2vt_feat_proj_bwd": (c_int32, [POINTER(Dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
+    "s2vt_colsum_ws_floats": (c_size_t, [c_int64, c_int32]),
+    "s2vt_lstm_step_fwd": (c_int32, [c_int32, c_int32] + [c_void_p] * 9),
+    "s2vt_lstm_step_bwd": (c_int32, [c_int32, c_int32] + [c_void_p] * 7 + [c_int32, c_void_p, c_void_p]),
+    "s2vt_lstm_seq_fwd": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_int32] + [c_void_p] * 6),
+    "s2vt_lstm_seq_bwd": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 5),
+    "s2vt_decode_step_argmax": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5),
+    "s2vt_prof_enable": (c_int32, [c_int32]),
+    "s2vt_prof_read": (c_int32, [c_int32, POINTER(c_double), POINTER(c_int64)]),
+    "s2vt_prof_reset": (c_int32, []),
+}
+
+_lib = None
+
+
+class S2VTHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libs2vt_hip.so and type every entry point.  Raises if the library is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise S2VTHipError(
+            "libs2vt_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `python s2vt-video-caption_amd/build.py`. There is no CPU fallback for the S2VT hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the library lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.s2vt_abi_version() != 1:
+        raise S2VTHipError("libs2vt_hip.so ABI %d != 1" % lib.s2vt_abi_version())
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().s2vt_last_error()
+        raise S2VTHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode(errors="replace") if msg else "?"))
+
+
+def prof_read(kind):
+    ms, n = c_double(0.0), c_int64(0)
+    check(load().s2vt_prof_read(kind, ctypes.byref(ms), ctypes.byref(n)), "s2vt_prof_read")
+    return ms.value, n.value

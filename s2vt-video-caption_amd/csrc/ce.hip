@@ -1,0 +1,132 @@
+// Mean cross-entropy over vocabulary logits (utils.py:11,22: nn.CrossEntropyLoss() with the default
+// 'mean' reduction over all B*(L-1) rows against target[:, 1:]) and its gradient.
+// One 256-thread workgroup per logits row: 16-B vector loads, wave shuffles + LDS for the row max and
+// the exp-sum; per-row losses are then summed in a fixed order by a single workgroup (deterministic).
+#include "common.h"
+#include "kernels.h"
+
+namespace s2vt {
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// target row r = b*Lm1 + j  ->  target[b*ldt + j + 1]
+__device__ __forceinline__ int64_t row_target(const int64_t* target, int64_t r, int Lm1, int64_t ldt) {
+    const int64_t b = r / Lm1, j = r % Lm1;
+    return target[b * ldt + j + 1];
+}
+
+__global__ __launch_bounds__(256) void ce_row_kernel(const float* logits, int V, const int64_t* target, int Lm1,
+                                                     int64_t ldt, float* lse, float* rowloss, int* err) {
+    __shared__ float sred[4];
+    const int64_t r = blockIdx.x;
+    const float* row = logits + r * V;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool vec = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
+    float m = -INFINITY;
+    if (vec) {
+        for (int c = tid * 4; c < V; c += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+            m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+        }
+    } else {
+        for (int c = tid; c < V; c += 256) m = fmaxf(m, row[c]);
+    }
+    m = wave_max(m);
+    if (lane == 0) sred[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
+    __syncthreads();
+    float s = 0.f;
+    if (vec) {
+        for (int c = tid * 4; c < V; c += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+            s += expf(v[0] - m) + expf(v[1] - m) + expf(v[2] - m) + expf(v[3] - m);
+        }
+    } else {
+        for (int c = tid; c < V; c += 256) s += expf(row[c] - m);
+    }
+    s = wave_sum(s);
+    if (lane == 0) sred[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        const float tot = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+        const float l = logf(tot) + m;
+        int64_t t = row_target(target, r, Lm1, ldt);
+        if (t < 0 || t >= V) {
+            if (err) atomicExch(err, 2);
+            t = t < 0 ? 0 : V - 1;
+        }
+        lse[r] = l;
+        rowloss[r] = l - row[t];
+    }
+}
+
+// loss = (sum_r rowloss[r]) / rows, fixed summation order (one workgroup, fp32 pairwise per thread strip).
+__global__ __launch_bounds__(256) void ce_mean_kernel(const float* rowloss, int64_t rows, float* loss_out) {
+    __shared__ float sred[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s = 0.f;
+    for (int64_t r = tid; r < rows; r += 256) s += rowloss[r];
+    s = wave_sum(s);
+    if (lane == 0) sred[wave] = s;
+    __syncthreads();
+    if (tid == 0) loss_out[0] = ((sred[0] + sred[1]) + (sred[2] + sred[3])) / (float)rows;
+}
+
+int mean_ce_fwd(hipStream_t s, const float* logits, int64_t rows, int V, const int64_t* target, int Lm1, int64_t ldt,
+                float* lse, float* rowloss, float* loss_out, int* err_flag) {
+    S2VT_REQUIRE(rows > 0 && V > 0 && logits && target && lse && rowloss && loss_out, "mean_ce_fwd: bad arguments");
+    hipLaunchKernelGGL(ce_row_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, V, target, Lm1, ldt, lse, rowloss,
+                       err_flag);
+    S2VT_LAUNCH_CHECK("ce_row_kernel");
+    hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, s, rowloss, rows, loss_out);
+    S2VT_LAUNCH_CHECK("ce_mean_kernel");
+    return 0;
+}
+
+// dlogits[r][v] = (exp(logit - lse_r) - [v == target_r]) * gout / rows
+__global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, int64_t rows, int V, const int64_t* target,
+                                                     int Lm1, int64_t ldt, const float* lse, const float* gout,
+                                                     float* dlogits) {
+    const int64_t r = blockIdx.x;
+    const float* row = logits + r * V;
+    float* drow = dlogits + r * V;
+    const float l = lse[r];
+    const float scale = gout[0] / (float)rows;
+    int64_t t = row_target(target, r, Lm1, ldt);
+    t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+    const int tid = threadIdx.x;
+    const bool vec = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(row) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(drow) & 15) == 0);
+    if (vec) {
+        for (int c = tid * 4; c < V; c += 1024) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+            f32x4 d;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = (expf(v[j] - l) - ((c + j) == t ? 1.f : 0.f)) * scale;
+            *reinterpret_cast<f32x4*>(drow + c) = d;
+        }
+    } else {
+        for (int c = tid; c < V; c += 256) drow[c] = (expf(row[c] - l) - (c == t ? 1.f : 0.f)) * scale;
+    }
+}
+
+int mean_ce_bwd(hipStream_t s, const float* logits, int64_t rows, int V, const int64_t* target, int Lm1, int64_t ldt,
+                const float* lse, const float* gout, float* dlogits) {
+    S2VT_REQUIRE(rows > 0 && V > 0 && logits && target && lse && gout && dlogits, "mean_ce_bwd: bad arguments");
+    hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, rows, V, target, Lm1, ldt, lse,
+                       gout, dlogits);
+    S2VT_LAUNCH_CHECK("ce_bwd_kernel");
+    return 0;
+}
+
+}  // namespace s2vt

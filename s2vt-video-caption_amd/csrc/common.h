@@ -1,0 +1,54 @@
+// Shared device/host helpers for the gfx950 (CDNA4, wave64) S2VT kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace s2vt {
+
+// ---- error plumbing (no C++ exceptions cross the C ABI) -------------------------------
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+#define S2VT_HIP(call)                                        \
+    do {                                                      \
+        int _rc = ::s2vt::check_hip((call), #call);           \
+        if (_rc) return _rc;                                  \
+    } while (0)
+
+#define S2VT_LAUNCH_CHECK(name)                               \
+    do {                                                      \
+        int _rc = ::s2vt::check_hip(hipGetLastError(), name); \
+        if (_rc) return _rc;                                  \
+    } while (0)
+
+#define S2VT_REQUIRE(cond, ...)                               \
+    do {                                                      \
+        if (!(cond)) {                                        \
+            ::s2vt::set_error(__VA_ARGS__);                   \
+            return -1;                                        \
+        }                                                     \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// Row map of a stored matrix: stored_row = idx ? idx[r] : (inner ? (r % inner) * outer + r / inner : r).
+// `inner/outer` converts between batch-major (b*L + l) and time-major (l*B + b) row orders.
+struct RowMap {
+    const int32_t* idx;  // optional gather index
+    int inner, outer;    // optional permutation (inner == 0: identity)
+};
+
+__device__ __forceinline__ int map_row(const RowMap& m, int r) {
+    if (m.idx) return m.idx[r];
+    if (m.inner) return (r % m.inner) * m.outer + r / m.inner;
+    return r;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+}  // namespace s2vt

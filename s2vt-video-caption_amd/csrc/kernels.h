@@ -1,0 +1,77 @@
+// Internal launch interface between the HIP kernels and the C-ABI drivers (api.cpp).
+#pragma once
+#include "common.h"
+
+namespace s2vt {
+
+// ---- gemm.hip
+int gemm_f32(hipStream_t stream, bool a_kmajor, bool b_kmajor, int M, int N, int K,
+             const float* A, int64_t lda, RowMap amap, const float* B, int64_t ldb, RowMap bmap,
+             float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate);
+
+// ---- lstm.hip
+struct StepFwdArgs {
+    int B, H;
+    // segment 1: recurrent contraction h_prev[B,H] · W_hh[4H,H]^T  (h_prev == nullptr: h = 0)
+    const float* h_prev; int64_t ldh;
+    const float* w_hh; int64_t ldw;
+    // segment 2 (optional): x2[row(b), 0:K2] · W2[4H, 0:K2]^T, row(b) = token id (embedding gather)
+    const float* x2; int64_t ldx2; int K2;
+    const float* w2; int64_t ldw2;
+    const int32_t* tok_idx;                  // int32 token per batch row, or
+    const unsigned long long* tok_packed;    // packed argmax word of the previous decode step, or
+    int tok_const;                           // one token for every row (<sos>); used when both null
+    // pre-computed gate input (x-part + both biases) per batch row, or bias only
+    const float* gx; int64_t ldgx;
+    const float* bias;                       // [4H], used when gx == nullptr
+    const float* c_prev; int64_t ldc;        // nullptr: c = 0
+    float* h_out; int64_t ldho;
+    float* h_out2; int64_t ldho2;            // optional second copy (batch-major view)
+    float* c_out; int64_t ldco;
+    float* stash; int64_t ldst;              // [B,4H] activated gates i,f,g,o (train only)
+};
+int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a);
+
+struct StepBwdArgs {
+    int B, H;
+    // dh_rec = dG_next[B,4H] · W_hh[4H,H]  (computed against the transposed copy W_hh^T [H,4H])
+    const float* dg_next; int64_t lddg;      // nullptr at the last timestep
+    const float* w_hh_t; int64_t ldwt;
+    const float* dh_out; int64_t lddho;      // gradient arriving from above at this step (nullable)
+    const float* stash; int64_t ldst;        // activated gates of this step
+    const float* c; int64_t ldc;             // c_t
+    const float* c_prev; int64_t ldcp;       // c_{t-1} (nullptr: 0)
+    float* dc; int64_t lddc;                 // in: dL/dc_t carried from t+1 (ignored if first), out: dL/dc_{t-1}
+    int dc_is_zero;                          // 1 at the last timestep (no incoming dc)
+    float* dg; int64_t lddg_out;             // out: pre-activation gate grads [B,4H]
+};
+int lstm_step_bwd(hipStream_t stream, const StepBwdArgs& a);
+
+struct LogitsArgmaxArgs {
+    int B, H, V;
+    const float* h; int64_t ldh;
+    const float* w_out; int64_t ldw;         // [V,H]
+    const float* b_out;
+    unsigned long long* packed;              // [B] zero-initialised; atomicMax of (ordered logit << 32 | ~index)
+};
+int logits_argmax(hipStream_t stream, const LogitsArgmaxArgs& a);
+
+// ---- misc.hip
+int add_vectors(hipStream_t s, const float* a, const float* b, float* out, int n);
+int transpose_f32(hipStream_t s, const float* in, int rows, int cols, float* out);   // out[cols][rows]
+int colsum_f32(hipStream_t s, const float* x, int64_t rows, int cols, int64_t ld, float* partial, float* out,
+               bool accumulate);
+size_t colsum_partial_floats(int64_t rows, int cols);
+int targets_to_time_major(hipStream_t s, const int64_t* targets, int B, int Lm1, int64_t ld, int V, int32_t* out,
+                          int* err_flag);
+int embedding_scatter_add(hipStream_t s, const float* d_rows, int64_t rows, int E, const int32_t* tok, float* d_emb);
+int unpack_tokens(hipStream_t s, const unsigned long long* packed, int steps, int B, int64_t* out_ids);
+int fill_zero(hipStream_t s, void* p, size_t bytes);
+
+// ---- ce.hip
+int mean_ce_fwd(hipStream_t s, const float* logits, int64_t rows, int V, const int64_t* target, int Lm1, int64_t ldt,
+                float* lse, float* rowloss, float* loss_out, int* err_flag);
+int mean_ce_bwd(hipStream_t s, const float* logits, int64_t rows, int V, const int64_t* target, int Lm1, int64_t ldt,
+                const float* lse, const float* gout, float* dlogits);
+
+}  // namespace s2vt

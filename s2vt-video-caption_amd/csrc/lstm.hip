@@ -1,0 +1,385 @@
+// Fused LSTM timestep kernels (forward cell, BPTT cell, decode logits+argmax) for gfx950.
+//
+// One launch per timestep computes, for a [16*MT batch rows] x [16*NT columns] tile per workgroup,
+// the recurrent contraction on the matrix cores (v_mfma_f32_16x16x4_f32, exact fp32) and the
+// whole pointwise cell in the epilogue, so gate pre-activations never touch HBM:
+//   forward  (S2VTModel.py:67,77,86,93,103 -> nn.LSTM step):   G = gx_t + h_{t-1} W_hh^T (+ Emb[tok] W_e^T)
+//            columns of a tile = {i,f,g,o} x UN hidden units, so one workgroup owns complete cells;
+//   backward (autograd of the same, train.py:124):  dh = dh_out_t + dG_{t+1} W_hh, then the gate
+//            derivatives -> dG_t, dc_{t-1};
+//   decode   (S2VTModel.py:95-96,105-106): logits tile + first-max argmax folded into one 64-bit
+//            atomicMax per (row, tile).
+// The 4 waves of a workgroup split K in 64-wide chunks (wave w takes chunks w, w+4, ...), each
+// staging its operands through a wave-private LDS image with full-line coalesced 16-B loads and a
+// register prefetch of its next chunk, and the 4 partial tiles are summed through LDS.
+// Both operands are k-contiguous (h/dG rows, W_hh rows / W_hh^T rows), LDS row stride 68 floats:
+// 16-B aligned staging writes and conflict-free ds_read_b128 operand reads.  Within each 16-wide
+// k block lane quarter q owns k = 4q..4q+3 for both operands (fixed summation order).
+#include "common.h"
+#include "kernels.h"
+
+namespace s2vt {
+
+constexpr int KC = 64;       // k chunk per wave iteration
+constexpr int SLD = 68;      // LDS row stride in floats
+constexpr int NWAVE = 4;
+
+__device__ __forceinline__ f32x4 ld4(const float* row, int c, int limit, bool vec) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row == nullptr || c >= limit) return v;
+    if (vec && c + 3 < limit) {
+        v = *reinterpret_cast<const f32x4*>(row + c);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c + j < limit) v[j] = row[c + j];
+    }
+    return v;
+}
+
+// acc[mi][ni][a] += A[16*MT rows, 0:K] · B[16*NT rows, 0:K]^T over this wave's chunks.
+// arow/brow: per-lane row pointers for rows (lane/16 + 4 i); sA/sB: wave-private LDS images.
+template <int MT, int NT, int NA>
+__device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const float* const (&arow)[MT * 4],
+                                             const float* const (&brow)[NT * 4], int K, bool vecA, bool vecB,
+                                             float* sA, float* sB, int wave, int lane) {
+    const int nch = (K + KC - 1) / KC;
+    const int lrow = lane >> 4, kq = (lane & 15) * 4;
+    const int fi = lane & 15, fq = lane >> 4;
+    f32x4 ra[MT * 4], rb[NT * 4];
+    int c = wave;
+    if (c < nch) {
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) ra[i] = ld4(arow[i], c * KC + kq, K, vecA);
+#pragma unroll
+        for (int i = 0; i < NT * 4; ++i) rb[i] = ld4(brow[i], c * KC + kq, K, vecB);
+    }
+    while (c < nch) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) *reinterpret_cast<f32x4*>(&sA[(lrow + 4 * i) * SLD + kq]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NT * 4; ++i) *reinterpret_cast<f32x4*>(&sB[(lrow + 4 * i) * SLD + kq]) = rb[i];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const int cn = c + NWAVE;
+        if (cn < nch) {
+#pragma unroll
+            for (int i = 0; i < MT * 4; ++i) ra[i] = ld4(arow[i], cn * KC + kq, K, vecA);
+#pragma unroll
+            for (int i = 0; i < NT * 4; ++i) rb[i] = ld4(brow[i], cn * KC + kq, K, vecB);
+        }
+#pragma unroll
+        for (int s = 0; s < KC / 16; ++s) {
+            f32x4 a[MT], b[NT];
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                a[mi] = *reinterpret_cast<const f32x4*>(&sA[(mi * 16 + fi) * SLD + 16 * s + 4 * fq]);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+                b[ni] = *reinterpret_cast<const f32x4*>(&sB[(ni * 16 + fi) * SLD + 16 * s + 4 * fq]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni)
+                        acc[mi][ni][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            a[mi][j], b[ni][j], acc[mi][ni][j & (NA - 1)], 0, 0, 0);
+        }
+        c = cn;
+    }
+}
+
+// Sum the 4 waves' partial tiles: every wave writes its accumulators to red[wave][row][col],
+// after which red holds 4 partials per output.  16x16 C/D layout: col = lane&15, row = 4*(lane>>4)+reg.
+template <int MT, int NT, int NA>
+__device__ __forceinline__ void write_partials(const f32x4 (&acc)[MT][NT][NA], float* red, int wave, int lane) {
+    constexpr int TM = 16 * MT, RLD = 16 * NT + 1;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[mi][ni][0][r];
+                if (NA == 2) v += acc[mi][ni][NA - 1][r];
+                red[(wave * TM + mi * 16 + 4 * (lane >> 4) + r) * RLD + ni * 16 + (lane & 15)] = v;
+            }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ float read_sum(const float* red, int row, int col) {
+    constexpr int TM = 16 * MT, RLD = 16 * NT + 1;
+    float s = red[row * RLD + col];
+#pragma unroll
+    for (int w = 1; w < NWAVE; ++w) s += red[(w * TM + row) * RLD + col];
+    return s;
+}
+
+static inline bool vec_ok(const void* ptr, int64_t ld) {
+    return ptr != nullptr && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0);
+}
+
+// ------------------------------------------------------------------------------ forward step
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepFwdArgs p, int vec1, int vec2) {
+    constexpr int TM = 16 * MT, TN = 16 * NT, UN = TN / 4;
+    constexpr int NA = (MT * NT == 1) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* sA = smem + wave * (TM + TN) * SLD;
+    float* sB = sA + TM * SLD;
+    const int b0 = blockIdx.y * TM, u0 = blockIdx.x * UN;
+    const int lrow = lane >> 4;
+
+    f32x4 acc[MT][NT][NA];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int a = 0; a < NA; ++a) acc[mi][ni][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (p.h_prev) {
+        const float* arow[MT * 4];
+        const float* brow[NT * 4];
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) {
+            const int b = b0 + lrow + 4 * i;
+            arow[i] = (b < p.B) ? p.h_prev + (int64_t)b * p.ldh : nullptr;
+        }
+#pragma unroll
+        for (int i = 0; i < NT * 4; ++i) {
+            const int r = lrow + 4 * i, g = r / UN, u = u0 + r % UN;
+            brow[i] = (u < p.H) ? p.w_hh + ((int64_t)g * p.H + u) * p.ldw : nullptr;
+        }
+        wave_gemm_nt<MT, NT, NA>(acc, arow, brow, p.H, vec1 & 1, vec1 & 2, sA, sB, wave, lane);
+    }
+    if (p.x2) {
+        const float* arow[MT * 4];
+        const float* brow[NT * 4];
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) {
+            const int b = b0 + lrow + 4 * i;
+            if (b < p.B) {
+                int64_t tok;
+                if (p.tok_idx) tok = p.tok_idx[b];
+                else if (p.tok_packed) tok = (int64_t)(0xFFFFFFFFu - (uint32_t)(p.tok_packed[b] & 0xFFFFFFFFull));
+                else tok = p.tok_const;
+                arow[i] = p.x2 + tok * p.ldx2;
+            } else {
+                arow[i] = nullptr;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NT * 4; ++i) {
+            const int r = lrow + 4 * i, g = r / UN, u = u0 + r % UN;
+            brow[i] = (u < p.H) ? p.w2 + ((int64_t)g * p.H + u) * p.ldw2 : nullptr;
+        }
+        wave_gemm_nt<MT, NT, NA>(acc, arow, brow, p.K2, vec2 & 1, vec2 & 2, sA, sB, wave, lane);
+    }
+
+    __syncthreads();
+    float* red = smem;
+    write_partials<MT, NT, NA>(acc, red, wave, lane);
+    __syncthreads();
+
+    for (int e = tid; e < TM * UN; e += 256) {
+        const int bl = e / UN, u = e % UN;
+        const int b = b0 + bl, unit = u0 + u;
+        if (b >= p.B || unit >= p.H) continue;
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v = read_sum<MT, NT>(red, bl, g * UN + u);
+            const int col = g * p.H + unit;
+            v += p.gx ? p.gx[(int64_t)b * p.ldgx + col] : (p.bias ? p.bias[col] : 0.f);
+            pre[g] = v;
+        }
+        const float ig = 1.0f / (1.0f + expf(-pre[0]));
+        const float fg = 1.0f / (1.0f + expf(-pre[1]));
+        const float gg = tanhf(pre[2]);
+        const float og = 1.0f / (1.0f + expf(-pre[3]));
+        const float cp = p.c_prev ? p.c_prev[(int64_t)b * p.ldc + unit] : 0.f;
+        const float c = fg * cp + ig * gg;
+        const float h = og * tanhf(c);
+        p.h_out[(int64_t)b * p.ldho + unit] = h;
+        if (p.h_out2) p.h_out2[(int64_t)b * p.ldho2 + unit] = h;
+        p.c_out[(int64_t)b * p.ldco + unit] = c;
+        if (p.stash) {
+            float* st = p.stash + (int64_t)b * p.ldst + unit;
+            st[0] = ig;
+            st[(int64_t)p.H] = fg;
+            st[(int64_t)2 * p.H] = gg;
+            st[(int64_t)3 * p.H] = og;
+        }
+    }
+}
+
+int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a) {
+    S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.h_out && a.c_out, "lstm_step_fwd: bad arguments");
+    S2VT_REQUIRE(a.gx || a.bias, "lstm_step_fwd: need gx or bias");
+    const int vec1 = (vec_ok(a.h_prev, a.ldh) ? 1 : 0) | (vec_ok(a.w_hh, a.ldw) ? 2 : 0);
+    const int vec2 = (vec_ok(a.x2, a.ldx2) ? 1 : 0) | (vec_ok(a.w2, a.ldw2) ? 2 : 0);
+    if (a.B <= 16) {
+        dim3 grid(cdiv(a.H, 8), cdiv(a.B, 16));
+        hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2>), grid, dim3(256), 0, stream, a, vec1, vec2);
+    } else {
+        dim3 grid(cdiv(a.H, 8), cdiv(a.B, 32));
+        hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2>), grid, dim3(256), 0, stream, a, vec1, vec2);
+    }
+    S2VT_LAUNCH_CHECK("lstm_step_fwd_kernel");
+    return 0;
+}
+
+// ----------------------------------------------------------------------------- backward step
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepBwdArgs p, int vec) {
+    constexpr int TM = 16 * MT, TN = 16 * NT;
+    constexpr int NA = (MT * NT == 1) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* sA = smem + wave * (TM + TN) * SLD;
+    float* sB = sA + TM * SLD;
+    const int b0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int lrow = lane >> 4;
+
+    f32x4 acc[MT][NT][NA];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int a = 0; a < NA; ++a) acc[mi][ni][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (p.dg_next) {
+        const float* arow[MT * 4];
+        const float* brow[NT * 4];
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) {
+            const int b = b0 + lrow + 4 * i;
+            arow[i] = (b < p.B) ? p.dg_next + (int64_t)b * p.lddg : nullptr;
+        }
+#pragma unroll
+        for (int i = 0; i < NT * 4; ++i) {
+            const int n = n0 + lrow + 4 * i;
+            brow[i] = (n < p.H) ? p.w_hh_t + (int64_t)n * p.ldwt : nullptr;
+        }
+        wave_gemm_nt<MT, NT, NA>(acc, arow, brow, 4 * p.H, vec & 1, vec & 2, sA, sB, wave, lane);
+    }
+    __syncthreads();
+    float* red = smem;
+    write_partials<MT, NT, NA>(acc, red, wave, lane);
+    __syncthreads();
+
+    for (int e = tid; e < TM * TN; e += 256) {
+        const int bl = e / TN, ul = e % TN;
+        const int b = b0 + bl, unit = n0 + ul;
+        if (b >= p.B || unit >= p.H) continue;
+        float dh = read_sum<MT, NT>(red, bl, ul);
+        if (p.dh_out) dh += p.dh_out[(int64_t)b * p.lddho + unit];
+        const float* st = p.stash + (int64_t)b * p.ldst + unit;
+        const float ig = st[0], fg = st[(int64_t)p.H], gg = st[(int64_t)2 * p.H], og = st[(int64_t)3 * p.H];
+        const float c = p.c[(int64_t)b * p.ldc + unit];
+        const float cp = p.c_prev ? p.c_prev[(int64_t)b * p.ldcp + unit] : 0.f;
+        const float tc = tanhf(c);
+        float dc = dh * og * (1.0f - tc * tc);
+        if (!p.dc_is_zero) dc += p.dc[(int64_t)b * p.lddc + unit];
+        const float d_o = dh * tc;
+        float* dg = p.dg + (int64_t)b * p.lddg_out + unit;
+        dg[0] = dc * gg * ig * (1.0f - ig);
+        dg[(int64_t)p.H] = dc * cp * fg * (1.0f - fg);
+        dg[(int64_t)2 * p.H] = dc * ig * (1.0f - gg * gg);
+        dg[(int64_t)3 * p.H] = d_o * og * (1.0f - og);
+        p.dc[(int64_t)b * p.lddc + unit] = dc * fg;
+    }
+}
+
+int lstm_step_bwd(hipStream_t stream, const StepBwdArgs& a) {
+    S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.stash && a.c && a.dc && a.dg, "lstm_step_bwd: bad arguments");
+    const int vec = (vec_ok(a.dg_next, a.lddg) ? 1 : 0) | (vec_ok(a.w_hh_t, a.ldwt) ? 2 : 0);
+    dim3 grid(cdiv(a.H, 16), cdiv(a.B, 16));
+    hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1>), grid, dim3(256), 0, stream, a, vec);
+    S2VT_LAUNCH_CHECK("lstm_step_bwd_kernel");
+    return 0;
+}
+
+// -------------------------------------------------------------------- decode: logits + argmax
+__device__ __forceinline__ uint32_t ordered_bits(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(256) void logits_argmax_kernel(LogitsArgmaxArgs p, int vec) {
+    constexpr int TM = 16 * MT, TN = 16 * NT;
+    constexpr int NA = (MT * NT == 1) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* sA = smem + wave * (TM + TN) * SLD;
+    float* sB = sA + TM * SLD;
+    const int b0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int lrow = lane >> 4;
+
+    f32x4 acc[MT][NT][NA];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int a = 0; a < NA; ++a) acc[mi][ni][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+        const float* arow[MT * 4];
+        const float* brow[NT * 4];
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) {
+            const int b = b0 + lrow + 4 * i;
+            arow[i] = (b < p.B) ? p.h + (int64_t)b * p.ldh : nullptr;
+        }
+#pragma unroll
+        for (int i = 0; i < NT * 4; ++i) {
+            const int n = n0 + lrow + 4 * i;
+            brow[i] = (n < p.V) ? p.w_out + (int64_t)n * p.ldw : nullptr;
+        }
+        wave_gemm_nt<MT, NT, NA>(acc, arow, brow, p.H, vec & 1, vec & 2, sA, sB, wave, lane);
+    }
+    __syncthreads();
+    float* red = smem;
+    write_partials<MT, NT, NA>(acc, red, wave, lane);
+    __syncthreads();
+
+    // 8 threads per batch row, TN/8 columns each; first-max (lowest index) wins ties.
+    constexpr int CPT = TN / 8;
+    static_assert(TM * 8 == 256, "one pass over the tile");
+    const int bl = tid >> 3, sub = tid & 7;
+    const int b = b0 + bl;
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int nl = sub * CPT + j, n = n0 + nl;
+        if (b < p.B && n < p.V) {
+            const float v = read_sum<MT, NT>(red, bl, nl) + (p.b_out ? p.b_out[n] : 0.f);
+            const unsigned long long key =
+                ((unsigned long long)ordered_bits(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)n);
+            best = key > best ? key : best;
+        }
+    }
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    if (sub == 0 && b < p.B && best) atomicMax(&p.packed[b], best);
+}
+
+int logits_argmax(hipStream_t stream, const LogitsArgmaxArgs& a) {
+    S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.V > 0 && a.h && a.w_out && a.packed, "logits_argmax: bad arguments");
+    const int vec = (vec_ok(a.h, a.ldh) ? 1 : 0) | (vec_ok(a.w_out, a.ldw) ? 2 : 0);
+    dim3 grid(cdiv(a.V, 32), cdiv(a.B, 32));
+    hipLaunchKernelGGL((logits_argmax_kernel<2, 2>), grid, dim3(256), 0, stream, a, vec);
+    S2VT_LAUNCH_CHECK("logits_argmax_kernel");
+    return 0;
+}
+
+}  // namespace s2vt

@@ -1,0 +1,137 @@
+// Small memory-bound helpers around the S2VT contractions: bias sums, the W_hh transpose used by
+// BPTT, deterministic column sums (bias gradients), caption index conversion, the embedding
+// scatter-add (autograd of S2VTModel.py:71) and unpacking of the decode argmax words.
+#include "common.h"
+#include "kernels.h"
+
+namespace s2vt {
+
+__global__ void add_vectors_kernel(const float* a, const float* b, float* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+int add_vectors(hipStream_t s, const float* a, const float* b, float* out, int n) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(add_vectors_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, b, out, n);
+    S2VT_LAUNCH_CHECK("add_vectors_kernel");
+    return 0;
+}
+
+// out[c][r] = in[r][c]; 64x64 tiles through LDS (padded), coalesced on both sides.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* in, int rows, int cols, float* out) {
+    __shared__ float tile[64][65];
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? in[(int64_t)r * cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) out[(int64_t)c * rows + r] = tile[tx][i];
+    }
+}
+int transpose_f32(hipStream_t s, const float* in, int rows, int cols, float* out) {
+    dim3 grid(cdiv(cols, 64), cdiv(rows, 64));
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, s, in, rows, cols, out);
+    S2VT_LAUNCH_CHECK("transpose_kernel");
+    return 0;
+}
+
+// Deterministic column sum in two passes: partial[chunk][col] over CS_ROWS-row chunks, then a fixed-
+// order sum over chunks (bias gradients must not depend on atomics' arrival order).
+constexpr int CS_ROWS = 128;
+size_t colsum_partial_floats(int64_t rows, int cols) { return (size_t)((rows + CS_ROWS - 1) / CS_ROWS) * cols; }
+
+__global__ void colsum_partial_kernel(const float* x, int64_t rows, int cols, int64_t ld, float* partial) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+    const int64_t r1 = (r0 + CS_ROWS < rows) ? r0 + CS_ROWS : rows;
+    float s = 0.f;
+    for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
+    partial[(int64_t)blockIdx.y * cols + c] = s;
+}
+__global__ void colsum_final_kernel(const float* partial, int nchunks, int cols, float* out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = accumulate ? out[c] : 0.f;
+    for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * cols + c];
+    out[c] = s;
+}
+int colsum_f32(hipStream_t s, const float* x, int64_t rows, int cols, int64_t ld, float* partial, float* out,
+               bool accumulate) {
+    if (cols <= 0) return 0;
+    const int nchunks = (int)((rows + CS_ROWS - 1) / CS_ROWS);
+    if (nchunks > 0) {
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(cdiv(cols, 256), nchunks), dim3(256), 0, s, x, rows, cols, ld,
+                           partial);
+        S2VT_LAUNCH_CHECK("colsum_partial_kernel");
+    }
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, partial, nchunks, cols, out,
+                       accumulate ? 1 : 0);
+    S2VT_LAUNCH_CHECK("colsum_final_kernel");
+    return 0;
+}
+
+// targets[b*ld + t] (int64, batch-major) -> out[t*B + b] (int32, time-major); out-of-range ids are
+// clamped and flagged (torch's embedding would raise).
+__global__ void targets_tm_kernel(const int64_t* targets, int B, int Lm1, int64_t ld, int V, int32_t* out, int* err) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * Lm1) return;
+    const int t = i / B, b = i % B;
+    int64_t tok = targets[(int64_t)b * ld + t];
+    if (tok < 0 || tok >= V) {
+        if (err) atomicExch(err, 1);
+        tok = tok < 0 ? 0 : V - 1;
+    }
+    out[i] = (int32_t)tok;
+}
+int targets_to_time_major(hipStream_t s, const int64_t* targets, int B, int Lm1, int64_t ld, int V, int32_t* out,
+                          int* err_flag) {
+    const int n = B * Lm1;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(targets_tm_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, targets, B, Lm1, ld, V, out, err_flag);
+    S2VT_LAUNCH_CHECK("targets_tm_kernel");
+    return 0;
+}
+
+// d_emb[tok[r], :] += d_rows[r, :]  (one wave-wide run of fp32 atomics per 256 B of a row; rows with
+// the same token collide, which is what makes this an atomic scatter).
+__global__ void emb_scatter_kernel(const float* d_rows, int64_t rows, int E, const int32_t* tok, float* d_emb) {
+    const int64_t r = blockIdx.y;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows || c >= E) return;
+    atomicAdd(&d_emb[(int64_t)tok[r] * E + c], d_rows[r * E + c]);
+}
+int embedding_scatter_add(hipStream_t s, const float* d_rows, int64_t rows, int E, const int32_t* tok, float* d_emb) {
+    if (rows <= 0 || E <= 0) return 0;
+    hipLaunchKernelGGL(emb_scatter_kernel, dim3(cdiv(E, 256), (unsigned)rows), dim3(256), 0, s, d_rows, rows, E, tok,
+                       d_emb);
+    S2VT_LAUNCH_CHECK("emb_scatter_kernel");
+    return 0;
+}
+
+// packed[step][b] -> ids[b][step] (int64, the reference's output layout S2VTModel.py:108-110)
+__global__ void unpack_tokens_kernel(const unsigned long long* packed, int steps, int B, int64_t* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= steps * B) return;
+    const int st = i / B, b = i % B;
+    out[(int64_t)b * steps + st] = (int64_t)(0xFFFFFFFFu - (uint32_t)(packed[i] & 0xFFFFFFFFull));
+}
+int unpack_tokens(hipStream_t s, const unsigned long long* packed, int steps, int B, int64_t* out_ids) {
+    const int n = steps * B;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(unpack_tokens_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, packed, steps, B, out_ids);
+    S2VT_LAUNCH_CHECK("unpack_tokens_kernel");
+    return 0;
+}
+
+int fill_zero(hipStream_t s, void* p, size_t bytes) {
+    if (bytes == 0) return 0;
+    S2VT_HIP(hipMemsetAsync(p, 0, bytes, s));
+    return 0;
+}
+
+}  // namespace s2vt

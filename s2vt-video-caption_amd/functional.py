@@ -1,0 +1,164 @@
+"""Autograd glue between torch tensors and the C-ABI library (host side of the hot path).
+
+Mirrors the reference's operator surface for this path: `train_forward` is what
+`S2VT.forward(mode='train')` computes (S2VTModel.py:48-81), `greedy_decode` is `mode='test'`
+(S2VTModel.py:82-110), `mean_cross_entropy` is the `nn.CrossEntropyLoss()` inside `MaskCriterion`
+(utils.py:11,22).  Everything here requires HIP tensors; CPU tensors raise.
+"""
+import ctypes
+
+import torch
+
+from . import capi
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_hip(t, name):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise capi.S2VTHipError(
+            "%s must be a HIP (cuda) tensor: this build runs the S2VT hot path on MI355X only and has no "
+            "CPU fallback (got %s)" % (name, getattr(t, "device", type(t))))
+
+
+def _f32c(t, name):
+    require_hip(t, name)
+    if t.dtype != torch.float32:
+        raise capi.S2VTHipError("%s must be float32, got %s" % (name, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _params_struct(cls, tensors):
+    s = cls()
+    for f, t in zip(capi.PARAM_FIELDS, tensors):
+        setattr(s, f, t.data_ptr())
+    return s
+
+
+def _dims(feats, params):
+    B, L, F = feats.shape
+    H = params[8].shape[0]           # feat_linear.weight [H, F]
+    V, E = params[12].shape          # embedding.weight   [V, E]
+    if params[8].shape[1] != F:
+        raise ValueError("feats last dim %d != feat_dim %d" % (F, params[8].shape[1]))
+    return capi.Dims(B, L, F, H, E, V)
+
+
+class _TrainForward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, targets, *params):
+        lib = capi.load()
+        feats = _f32c(feats, "feats")
+        params = tuple(_f32c(p, "parameter") for p in params)
+        require_hip(targets, "targets")
+        if targets.dtype != torch.int64:
+            targets = targets.long()
+        if targets.dim() != 2 or targets.stride(1) != 1:
+            targets = targets.reshape(targets.shape[0], -1).contiguous()
+        d = _dims(feats, params)
+        if targets.shape[0] != d.B or targets.shape[1] != d.L - 1:
+            raise ValueError("targets must be [B, L-1] = [%d, %d], got %s" % (d.B, d.L - 1, tuple(targets.shape)))
+        dev = feats.device
+        with torch.cuda.device(dev):
+            nbytes = lib.s2vt_train_workspace_bytes(ctypes.byref(d))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            logits = torch.empty(d.B, d.L - 1, d.V, dtype=torch.float32, device=dev)
+            ps = _params_struct(capi.Params, params)
+            capi.check(lib.s2vt_train_forward(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), _ptr(targets),
+                                              targets.stride(0), _ptr(logits), _ptr(ws), nbytes, _stream(dev)),
+                       "s2vt_train_forward")
+        ctx.save_for_backward(feats, *params)
+        ctx.ws, ctx.d, ctx.used = ws, d, False
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        if ctx.used:
+            raise capi.S2VTHipError("S2VT backward ran twice on one forward: the saved activations are consumed "
+                                    "in place (retain_graph is not supported)")
+        ctx.used = True
+        lib = capi.load()
+        feats, *params = ctx.saved_tensors
+        d, ws = ctx.d, ctx.ws
+        dev = feats.device
+        dlogits = _f32c(dlogits, "dlogits")
+        with torch.cuda.device(dev):
+            grads = [torch.empty_like(p) for p in params]
+            dfeats = torch.empty_like(feats) if ctx.needs_input_grad[0] else None
+            ps = _params_struct(capi.Params, params)
+            gs = _params_struct(capi.Grads, grads)
+            capi.check(lib.s2vt_train_backward(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), _ptr(dlogits),
+                                               ctypes.byref(gs), _ptr(dfeats), _ptr(ws), ws.numel(), _stream(dev)),
+                       "s2vt_train_backward")
+        ctx.ws = None
+        return (dfeats, None) + tuple(grads)
+
+
+def train_forward(feats, targets, params):
+    """logits [B, L-1, V] of S2VT.forward(mode='train'); `params` in capi.PARAM_KEYS order."""
+    return _TrainForward.apply(feats, targets, *params)
+
+
+@torch.no_grad()
+def greedy_decode(feats, params, sos_ix):
+    """ids int64 [B, L-1] of S2VT.forward(mode='test')."""
+    lib = capi.load()
+    feats = _f32c(feats, "feats")
+    params = tuple(_f32c(p.detach(), "parameter") for p in params)
+    d = _dims(feats, params)
+    dev = feats.device
+    with torch.cuda.device(dev):
+        nbytes = lib.s2vt_decode_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ids = torch.empty(d.B, d.L - 1, dtype=torch.int64, device=dev)
+        ps = _params_struct(capi.Params, params)
+        capi.check(lib.s2vt_greedy_decode(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), int(sos_ix), _ptr(ids),
+                                          _ptr(ws), nbytes, _stream(dev)), "s2vt_greedy_decode")
+    return ids
+
+
+class _MeanCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        lib = capi.load()
+        logits = _f32c(logits, "logits")
+        require_hip(target, "target")
+        if target.dtype != torch.int64:
+            target = target.long()
+        if target.stride(1) != 1:
+            target = target.contiguous()
+        B, Lm1, V = logits.shape
+        if target.shape[0] != B or target.shape[1] != Lm1 + 1:
+            raise ValueError("target must be [B, L] = [%d, %d], got %s" % (B, Lm1 + 1, tuple(target.shape)))
+        dev = logits.device
+        with torch.cuda.device(dev):
+            scratch = torch.empty(2 * B * Lm1 + 1, dtype=torch.float32, device=dev)
+            lse, rowloss, loss = scratch[:B * Lm1], scratch[B * Lm1:2 * B * Lm1], scratch[2 * B * Lm1:]
+            capi.check(lib.s2vt_mean_ce_forward(B, Lm1, V, _ptr(logits), _ptr(target), target.stride(0), _ptr(lse),
+                                                _ptr(rowloss), _ptr(loss), _stream(dev)), "s2vt_mean_ce_forward")
+        ctx.save_for_backward(logits, target, lse)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = capi.load()
+        logits, target, lse = ctx.saved_tensors
+        B, Lm1, V = logits.shape
+        dev = logits.device
+        gout = _f32c(gout.reshape(1), "grad_output")
+        with torch.cuda.device(dev):
+            dlogits = torch.empty_like(logits)
+            capi.check(lib.s2vt_mean_ce_backward(B, Lm1, V, _ptr(logits), _ptr(target), target.stride(0), _ptr(lse),
+                                                 _ptr(gout), _ptr(dlogits), _stream(dev)), "s2vt_mean_ce_backward")
+        return dlogits, None
+
+
+def mean_cross_entropy(logits, target):
+    """Mean CE of logits [B, L-1, V] against target[:, 1:] (target int64 [B, L]) — utils.py:11,22."""
+    return _MeanCE.apply(logits, target)

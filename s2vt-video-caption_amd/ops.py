@@ -1,0 +1,141 @@
+"""Thin tensor-level wrappers over the per-op C-ABI entry points (include/s2vt_hip.h).
+
+Used by the beam-search driver and by the GPU parity tests; no autograd here.  All tensors must be
+contiguous float32 HIP tensors unless noted; outputs are allocated by torch.
+"""
+import ctypes
+
+import torch
+
+from . import capi
+from .functional import _ptr, _stream, _f32c
+
+
+def gemm(a, b, bias=None, a_kmajor=True, b_kmajor=True, out=None, accumulate=False):
+    """out[M,N] (+)= op(a)·op(b) (+bias).  a: [M,K] if a_kmajor else [K,M]; b: [N,K] if b_kmajor else [K,N]."""
+    lib = capi.load()
+    a, b = _f32c(a, "a"), _f32c(b, "b")
+    M, K = (a.shape if a_kmajor else (a.shape[1], a.shape[0]))
+    N = b.shape[0] if b_kmajor else b.shape[1]
+    Kb = b.shape[1] if b_kmajor else b.shape[0]
+    if K != Kb:
+        raise ValueError("gemm: inner dims differ (%d vs %d)" % (K, Kb))
+    dev = a.device
+    with torch.cuda.device(dev):
+        if out is None:
+            out = torch.empty(M, N, dtype=torch.float32, device=dev)
+            if accumulate:
+                out.zero_()
+        capi.check(lib.s2vt_gemm_f32(int(a_kmajor), int(b_kmajor), M, N, K, _ptr(a), a.stride(0), _ptr(b),
+                                     b.stride(0), _ptr(out), out.stride(0), _ptr(bias), int(accumulate),
+                                     _stream(dev)), "s2vt_gemm_f32")
+    return out
+
+
+def feat_proj_fwd(feats, w, bias):
+    """x1 time-major [L*B, H] = feats[B,L,F]·w^T + bias."""
+    lib = capi.load()
+    feats, w = _f32c(feats, "feats"), _f32c(w, "w")
+    B, L, F = feats.shape
+    H = w.shape[0]
+    d = capi.Dims(B, L, F, H, 1, 1)
+    dev = feats.device
+    with torch.cuda.device(dev):
+        x1 = torch.empty(L * B, H, dtype=torch.float32, device=dev)
+        capi.check(lib.s2vt_feat_proj_fwd(ctypes.byref(d), _ptr(feats), _ptr(w), _ptr(bias), _ptr(x1), _stream(dev)),
+                   "s2vt_feat_proj_fwd")
+    return x1
+
+
+def feat_proj_bwd(feats, w, dx1, need_dfeats=False):
+    lib = capi.load()
+    feats, w, dx1 = _f32c(feats, "feats"), _f32c(w, "w"), _f32c(dx1, "dx1")
+    B, L, F = feats.shape
+    H = w.shape[0]
+    d = capi.Dims(B, L, F, H, 1, 1)
+    dev = feats.device
+    with torch.cuda.device(dev):
+        dw = torch.empty_like(w)
+        db = torch.empty(H, dtype=torch.float32, device=dev)
+        dfe = torch.empty_like(feats) if need_dfeats else None
+        ws = torch.empty(max(1, lib.s2vt_colsum_ws_floats(L * B, H)), dtype=torch.float32, device=dev)
+        capi.check(lib.s2vt_feat_proj_bwd(ctypes.byref(d), _ptr(feats), _ptr(w), _ptr(dx1), _ptr(dw), _ptr(db),
+                                          _ptr(dfe), _ptr(ws), _stream(dev)), "s2vt_feat_proj_bwd")
+    return dw, db, dfe
+
+
+def lstm_step_fwd(gx, bias, w_hh, h_prev, c_prev, want_stash=False):
+    """One LSTM step; gx [B,4H] or None (then bias [4H]); h_prev/c_prev [B,H] or None."""
+    lib = capi.load()
+    w_hh = _f32c(w_hh, "w_hh")
+    H = w_hh.shape[1]
+    B = gx.shape[0] if gx is not None else h_prev.shape[0]
+    dev = w_hh.device
+    with torch.cuda.device(dev):
+        h = torch.empty(B, H, dtype=torch.float32, device=dev)
+        c = torch.empty(B, H, dtype=torch.float32, device=dev)
+        stash = torch.empty(B, 4 * H, dtype=torch.float32, device=dev) if want_stash else None
+        capi.check(lib.s2vt_lstm_step_fwd(B, H, _ptr(gx), _ptr(bias), _ptr(w_hh), _ptr(h_prev), _ptr(c_prev), _ptr(h),
+                                          _ptr(c), _ptr(stash), _stream(dev)), "s2vt_lstm_step_fwd")
+    return (h, c, stash) if want_stash else (h, c)
+
+
+def lstm_step_bwd(dg_next, w_hh_t, dh_out, stash, c, c_prev, dc, dc_is_zero):
+    lib = capi.load()
+    B, H4 = stash.shape
+    H = H4 // 4
+    dev = stash.device
+    with torch.cuda.device(dev):
+        dg = torch.empty_like(stash)
+        capi.check(lib.s2vt_lstm_step_bwd(B, H, _ptr(dg_next), _ptr(w_hh_t), _ptr(dh_out), _ptr(stash), _ptr(c),
+                                          _ptr(c_prev), _ptr(dc), int(dc_is_zero), _ptr(dg), _stream(dev)),
+                   "s2vt_lstm_step_bwd")
+    return dg
+
+
+def lstm_seq_fwd(T, B, gx, n_gx, bias, w_hh, want_stash=False):
+    """Whole layer from zero state; gx [n_gx*B, 4H] time-major (overwritten by the stash if want_stash)."""
+    lib = capi.load()
+    w_hh = _f32c(w_hh, "w_hh")
+    H = w_hh.shape[1]
+    dev = w_hh.device
+    with torch.cuda.device(dev):
+        h_all = torch.empty(T * B, H, dtype=torch.float32, device=dev)
+        c_all = torch.empty(T * B, H, dtype=torch.float32, device=dev)
+        stash = None
+        if want_stash:
+            stash = torch.empty(T * B, 4 * H, dtype=torch.float32, device=dev)
+            if n_gx:
+                stash[:n_gx * B].copy_(gx)
+            gx = stash
+        capi.check(lib.s2vt_lstm_seq_fwd(T, B, H, _ptr(gx), n_gx, _ptr(bias), _ptr(w_hh), _ptr(h_all), _ptr(c_all),
+                                         _ptr(stash), _stream(dev)), "s2vt_lstm_seq_fwd")
+    return h_all, c_all, stash
+
+
+def lstm_seq_bwd(T, B, w_hh, dh_out, dh_first, c_all, stash):
+    """BPTT over a layer; returns dG [T*B,4H] (stash is consumed in place)."""
+    lib = capi.load()
+    w_hh = _f32c(w_hh, "w_hh")
+    H = w_hh.shape[1]
+    dev = w_hh.device
+    with torch.cuda.device(dev):
+        wt = torch.empty(H, 4 * H, dtype=torch.float32, device=dev)
+        dc = torch.empty(B, H, dtype=torch.float32, device=dev)
+        capi.check(lib.s2vt_lstm_seq_bwd(T, B, H, _ptr(w_hh), _ptr(dh_out), dh_first, _ptr(c_all), _ptr(stash),
+                                         _ptr(wt), _ptr(dc), _stream(dev)), "s2vt_lstm_seq_bwd")
+    return stash
+
+
+def decode_step_argmax(h, w_out, b_out):
+    """token ids int64 [B] = argmax_v (h·w_out^T + b_out), lowest index on ties."""
+    lib = capi.load()
+    h, w_out = _f32c(h, "h"), _f32c(w_out, "w_out")
+    B, H = h.shape
+    V = w_out.shape[0]
+    dev = h.device
+    with torch.cuda.device(dev):
+        packed = torch.zeros(B, dtype=torch.int64, device=dev)
+        capi.check(lib.s2vt_decode_step_argmax(B, H, V, _ptr(h), _ptr(w_out), _ptr(b_out), _ptr(packed), _stream(dev)),
+                   "s2vt_decode_step_argmax")
+        return 0xFFFFFFFF - (packed & 0xFFFFFFFF)

@@ -1,0 +1,104 @@
+"""CPU: the C-ABI library loads and exports every symbol include/s2vt_hip.h declares; host-side logic of
+the drop-in modules (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "s2vt_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(s2vt_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_all_exported_and_bound(lib):
+    from s2vt_video_caption_amd import capi
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    raw = ctypes.CDLL(capi.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), "libs2vt_hip.so does not export %s" % name
+        assert name in capi.SIGNATURES, "capi.py does not bind %s" % name
+    assert sorted(capi.SIGNATURES) == declared
+    assert lib.s2vt_abi_version() == 1
+
+
+def test_workspace_queries_and_argument_errors(lib):
+    from s2vt_video_caption_amd import capi
+    d = capi.Dims(64, 80, 4096, 1000, 1000, 12000)
+    tb = lib.s2vt_train_workspace_bytes(ctypes.byref(d))
+    db = lib.s2vt_decode_workspace_bytes(ctypes.byref(d))
+    assert 5e8 < tb < 2e9 and 1e8 < db < tb
+    bad = capi.Dims(0, 80, 4096, 1000, 1000, 12000)
+    assert lib.s2vt_train_workspace_bytes(ctypes.byref(bad)) == 0
+    # null pointers are rejected before any GPU call, with a message
+    rc = lib.s2vt_train_forward(ctypes.byref(d), None, None, None, 0, None, None, 0, None)
+    assert rc == -1 and b"s2vt_train_forward" in lib.s2vt_last_error()
+    with pytest.raises(capi.S2VTHipError):
+        capi.check(rc, "s2vt_train_forward")
+
+
+def test_dropin_module_layout_and_reference_pickle():
+    import S2VTModel
+    from s2vt_video_caption_amd import capi, synth
+    d = synth.CONFIGS["tiny"]
+    m = S2VTModel.S2VT(d["V"], d["F"], d["L"], dim_hid=d["H"], dim_embed=d["E"])
+    assert tuple(m.state_dict().keys()) == capi.PARAM_KEYS
+    shapes = synth.param_shapes(d["V"], d["F"], d["H"], d["E"])
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == shapes[k]
+    for attr in ("feat_dim", "length", "dim_hid", "dim_embed", "sos_ix", "eos_ix", "vocab_size", "rnn_type"):
+        assert hasattr(m, attr)
+    # a full-module pickle WRITTEN BY THE REFERENCE class loads into the drop-in class
+    ref = torch.load(os.path.join(ROOT, "tests", "golden", "tiny_reference_module.pth"), weights_only=False)
+    assert isinstance(ref, S2VTModel.S2VT)
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=7)
+    for k, v in ref.state_dict().items():
+        assert torch.equal(v, sd[k])
+    m.load_state_dict(ref.state_dict())
+    # same default-init RNG stream as the reference's construction order (S2VTModel.py:19-28)
+    torch.manual_seed(0)
+    a = S2VTModel.S2VT(30, 16, 4, dim_hid=8, dim_embed=8)
+    torch.manual_seed(0)
+    vid = torch.nn.LSTM(8, 8, batch_first=True)
+    assert torch.equal(a.vid_rnn.weight_ih_l0, vid.weight_ih_l0)
+
+
+def test_cpu_tensors_fail_loudly_no_fallback():
+    import S2VTModel
+    import utils
+    from s2vt_video_caption_amd import capi
+    m = S2VTModel.S2VT(50, 64, 8, dim_hid=32, dim_embed=24)
+    with pytest.raises(capi.S2VTHipError):
+        m(torch.randn(2, 8, 64), targets=torch.zeros(2, 7, dtype=torch.long), mode="train")
+    with pytest.raises(capi.S2VTHipError):
+        m(torch.randn(2, 8, 64), mode="test")
+    with pytest.raises(capi.S2VTHipError):
+        utils.MaskCriterion()(torch.randn(2, 7, 50), torch.zeros(2, 8, dtype=torch.long), torch.ones(2, 8))
+
+
+def test_unsupported_configs_raise():
+    import S2VTModel
+    m = S2VTModel.S2VT(50, 64, 8, dim_hid=32, dim_embed=24, rnn_type="gru")
+    with pytest.raises(NotImplementedError):
+        m._hip_params()
+    m = S2VTModel.S2VT(50, 64, 8, dim_hid=32, dim_embed=24, num_layers=2)
+    with pytest.raises(NotImplementedError):
+        m._hip_params()
+
+
+def test_synth_recipe_is_deterministic_and_order_independent():
+    from s2vt_video_caption_amd import synth
+    a = synth.make_state_dict(50, 64, 32, 24, seed=3)
+    b = synth.make_state_dict(50, 64, 32, 24, seed=3)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    f1, c1, m1 = synth.make_batch(4, 8, 64, 50, seed=1)
+    f2, c2, m2 = synth.make_batch(4, 8, 64, 50, seed=1)
+    assert torch.equal(f1, f2) and torch.equal(c1, c2) and torch.equal(m1, m2)
+    assert (c1[:, 0] == 3).all() and ((c1 == 4).sum(1) == 1).all() and c1.max() < 50
+    assert torch.equal(m1.sum(1), (c1 != 0).sum(1).float())

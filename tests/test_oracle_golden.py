@@ -1,0 +1,124 @@
+"""CPU: pin the oracle against the golden vectors produced by the reference itself
+(oracle/make_golden.py).  These run everywhere, including the GPU box where the reference is absent."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import s2vt_oracle as orc
+from s2vt_video_caption_amd import synth
+
+
+def _setup(g, name):
+    d = synth.CONFIGS[name]
+    assert list(g["dims"]) == [d[k] for k in "BLFHEV"]
+    seed = int(g["seed"])
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed, out_scale=float(g["out_scale"]))
+    feats, caps, mask = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
+    return d, sd, feats, caps, mask
+
+
+def test_tiny_forward_loss_grads_match_reference(golden):
+    g = golden("tiny")
+    d, sd, feats, caps, mask = _setup(g, "tiny")
+    logits = orc.forward_train(sd, feats, caps[:, :-1])
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=0, atol=2e-6)
+    losses, grads, final = orc.train_steps(sd, feats, caps, mask, int(g["n_steps"]))
+    np.testing.assert_allclose(losses, g["losses"], rtol=0, atol=2e-6)
+    for k in orc.KEYS:
+        ref = g["grad/" + k]
+        np.testing.assert_allclose(grads[k].numpy(), ref, rtol=0, atol=1e-6 + 2e-5 * np.abs(ref).max(), err_msg=k)
+        np.testing.assert_allclose(final[k].numpy(), g["final/" + k], rtol=0, atol=1e-5, err_msg=k)
+
+
+def test_tiny_greedy_and_beam_match_reference(golden):
+    g = golden("tiny")
+    d, sd, feats, caps, mask = _setup(g, "tiny")
+    ids = orc.greedy_decode(sd, feats)
+    assert ids.dtype == torch.int64 and tuple(ids.shape) == (d["B"], d["L"] - 1)
+    np.testing.assert_array_equal(ids.numpy(), g["greedy_ids"])
+    beams = orc.beam_search(sd, feats, beam_width=int(g["beam_width"]), max_depth=30)
+    for b, s in enumerate(beams):
+        ref = [int(x) for x in g["beam_ids"][b] if x >= 0]
+        assert s == ref
+
+
+def test_c1_matches_reference(golden):
+    g = golden("c1")
+    d, sd, feats, caps, mask = _setup(g, "c1")
+    ids, marg = orc.greedy_decode(sd, feats, return_margins=True)
+    np.testing.assert_array_equal(ids.numpy(), g["greedy_ids"])
+    np.testing.assert_allclose(marg.numpy(), g["greedy_margin"], rtol=0, atol=1e-5)
+    logits = orc.forward_train(sd, feats, caps[:, :-1])
+    np.testing.assert_allclose(logits[:, ::13, :64].numpy(), g["logits_rows"], rtol=0, atol=5e-6)
+    assert abs(float(logits.double().sum()) - float(g["logits_sum"])) < 1e-2
+    loss = orc.mask_criterion(logits, caps, mask)
+    assert abs(float(loss) - g["losses"][0]) < 5e-6
+    beams = orc.beam_search(sd, feats[:2], beam_width=int(g["beam_width"]), max_depth=30)
+    for b, s in enumerate(beams):
+        assert s == [int(x) for x in g["beam_ids"][b] if x >= 0]
+
+
+def test_c1_train_trajectory_matches_reference(golden):
+    g = golden("c1")
+    d, sd, feats, caps, mask = _setup(g, "c1")
+    losses, grads, final = orc.train_steps(sd, feats, caps, mask, int(g["n_steps"]))
+    np.testing.assert_allclose(losses, g["losses"], rtol=0, atol=1e-5)
+    for k in orc.KEYS:
+        assert abs(float(grads[k].double().norm()) - float(g["gradnorm/" + k])) <= 1e-4 * float(g["gradnorm/" + k]) + 1e-7, k
+        np.testing.assert_allclose(grads[k].reshape(-1)[:32].numpy(), g["gradhead/" + k], rtol=0,
+                                   atol=1e-6 + 1e-4 * np.abs(g["gradhead/" + k]).max(), err_msg=k)
+        assert abs(float(final[k].double().norm()) - float(g["finalnorm/" + k])) <= 1e-5 * float(g["finalnorm/" + k]), k
+
+
+def test_mask_criterion_is_plain_mean_ce_and_nan_on_empty_mask():
+    torch.manual_seed(0)
+    logits = torch.randn(3, 7, 11)
+    target = torch.randint(0, 11, (3, 8))
+    mask = (torch.rand(3, 8) > 0.5).float()
+    mask[0, 1] = 1
+    got = orc.mask_criterion(logits, target, mask)
+    ref = torch.nn.functional.cross_entropy(logits.reshape(21, 11), target[:, 1:].reshape(-1))
+    assert abs(float(got) - float(ref)) < 1e-6
+    assert torch.isnan(orc.mask_criterion(logits, target, torch.zeros(3, 8)))
+
+
+def test_reference_shaped_cpu_model_equals_oracle():
+    """The nn.LSTM-based model timed as cpu_baseline computes the same function as the explicit oracle."""
+    d = synth.CONFIGS["tiny"]
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=3)
+    feats, caps, mask = synth.make_batch(5, d["L"], d["F"], d["V"], seed=9)
+    m = orc.ReferenceShapedCPUModel(sd)
+    a = m(feats, caps[:, :-1])
+    b = orc.forward_train(sd, feats, caps[:, :-1])
+    assert (a - b).abs().max().item() < 2e-6
+    assert torch.equal(m.greedy(feats), orc.greedy_decode(sd, feats))
+
+
+def test_oracle_fp64_close_to_fp32():
+    d = synth.CONFIGS["tiny"]
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=5)
+    feats, caps, _ = synth.make_batch(2, d["L"], d["F"], d["V"], seed=5)
+    a = orc.forward_train(sd, feats, caps[:, :-1], dtype=torch.float64)
+    b = orc.forward_train(sd, feats, caps[:, :-1])
+    assert (a - b.double()).abs().max().item() < 1e-5
+
+
+@pytest.mark.skipif(not __import__("os").path.exists("/root/reference/S2VTModel.py"), reason="reference not present")
+def test_oracle_against_live_reference():
+    """Only in the build container: import the reference read-only and compare directly."""
+    import importlib.util
+    import sys
+    sys.dont_write_bytecode = True
+    spec = importlib.util.spec_from_file_location("_ref_S2VTModel", "/root/reference/S2VTModel.py")
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    d = synth.CONFIGS["tiny"]
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=17)
+    feats, caps, _ = synth.make_batch(4, d["L"], d["F"], d["V"], seed=17)
+    m = ref.S2VT(d["V"], d["F"], d["L"], dim_hid=d["H"], dim_embed=d["E"])
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        a = m(feats, targets=caps[:, :-1], mode="train")
+        ids = m(feats, mode="test")
+    assert (a - orc.forward_train(sd, feats, caps[:, :-1])).abs().max().item() < 2e-6
+    assert torch.equal(ids, orc.greedy_decode(sd, feats))
