@@ -1,0 +1,283 @@
+#!/usr/bin/env python
+"""Benchmark of the S2VT hot path on MI355X (BASELINE.json metric: training frames/s + greedy captions/s).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full optimisation step of train.py:116-127 (zero_grad, forward, MaskCriterion, backward,
+gradient all-reduce when N > 1, Adam) on synthetic [B, 80, 4096] fp32 features with seeded random-init
+weights; the default workload is BASELINE configs[1] (B=64 per GPU, H=E=1000, V=12000, fp32).  Scaling is
+weak: every rank keeps B per GPU.  Rank 0 prints ONE JSON line.  Inputs are resident in HBM before the timed
+region.  Beside the GPU number the line carries
+  * "roofline": the dominant kernel family of the step, timed live with HIP events on the launch stream
+    (s2vt_prof_*), priced with the algorithmic flops/bytes of SURVEY.md §8(d);
+  * "roofline_lstm_step": the fused LSTM timestep (north_star's target kernel) against the HBM roofline;
+  * "cpu_baseline": the reference-shaped CPU model (oracle/, nn.LSTM/nn.Linear -> oneDNN, what the
+    reference's CPU run executes) timed on this host's cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TF = 157.3     # MI355X_MICROARCH.md: fp32-input MFMA = 157.3 TFLOP/s
+
+
+def gemm_flops_train(B, L, F, H, E, V, dfeats=False):
+    """Algorithmic FLOPs of every batched GEMM launch of one train step (forward + backward), structural
+    zeros excluded; the recurrent h·W_hh products live in the step kernels, not here."""
+    T, R = 2 * L - 1, (L - 1) * B
+    f = 0
+    f += 2 * B * L * H * F                 # x1 = feats W_f^T
+    f += 2 * L * B * 4 * H * H             # gx1
+    f += 2 * T * B * 4 * H * H             # gx2 (vid_out half)
+    f += 2 * R * 4 * H * E                 # gx2 (embed half)
+    f += 2 * R * V * H                     # logits
+    f += 2 * 2 * R * V * H                 # dh2dec, dW_o
+    f += 2 * 4 * H * H * (T - 1) * B       # dW_hh2
+    f += 2 * 4 * H * H * T * B             # dW_ih2[:, E:]
+    f += 2 * 4 * H * E * R                 # dW_ih2[:, :E]
+    f += 2 * T * B * H * 4 * H             # dh1
+    f += 2 * R * E * 4 * H                 # d(embedded words)
+    f += 2 * 4 * H * H * (T - 1) * B       # dW_hh1
+    f += 2 * 4 * H * H * L * B             # dW_ih1
+    f += 2 * L * B * H * 4 * H             # dx1
+    f += 2 * H * F * L * B                 # dW_f
+    if dfeats:
+        f += 2 * L * B * F * H
+    return f
+
+
+def step_bytes_fwd(B, H, I, s=4, train=True):
+    """ALGORITHMIC bytes of one fused LSTM timestep, SURVEY.md §8(d):
+    W_ih+W_hh, biases, x_t and h_{t-1}, c_{t-1}, h_t, c_t (+ gate stash in training)."""
+    b = s * 4 * H * (I + H) + 4 * 8 * H + s * B * (I + H) + 4 * B * H + s * B * H + 4 * B * H
+    if train:
+        b += s * B * 4 * H
+    return b
+
+
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    """progress on stderr (stdout carries only the JSON line)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota (on a shared host
+    os.cpu_count() reports every core of the machine and oversubscribes the box's share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, int(os.environ.get("S2VT_CPU_THREADS", "16"))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="batch per GPU (BASELINE configs[1]: 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decode-batch", type=int, default=None)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import S2VTModel
+    import utils
+    from s2vt_video_caption_amd import capi, dp, synth
+    lib = capi.load()
+
+    L, F, H, E, V = 80, 4096, 1000, 1000, 12000
+    B = args.batch
+    sd = synth.make_state_dict(V, F, H, E, seed=0)
+    model = S2VTModel.S2VT(V, F, L, dim_hid=H, dim_embed=E)
+    model.load_state_dict(sd)
+    model.to(dev)
+    crit = utils.MaskCriterion()
+    try:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+    except Exception:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    reducer = dp.FlatGradAllReducer(model.parameters()) if world > 1 else None
+
+    # this rank's shard of the synthetic global batch (seeded recipe); resident in HBM
+    feats, caps, mask = synth.make_batch(B, L, F, V, seed=1234 + rank)
+    feats, caps, mask = feats.to(dev), caps.to(dev), mask.to(dev)
+
+    def one_step():
+        return dp.train_step(model, crit, opt, feats, caps, mask, reducer)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    log("model and data resident; warm-up x%d" % args.warmup)
+    for _ in range(args.warmup):
+        one_step()
+        torch.cuda.synchronize(dev)
+        log("warm-up step done")
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = one_step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    frames_per_s = world * B * L * args.steps / dt
+    final_loss = float(loss)
+    log("timed region: %.3f ms/step, %.0f frames/s" % (ms_per_step, frames_per_s))
+
+    out = None
+    if rank == 0:
+        # ---- live per-kernel timing with HIP events on the launch stream (2 extra steps, not part of `value`)
+        capi.check(lib.s2vt_prof_reset(), "prof_reset")
+        capi.check(lib.s2vt_prof_enable(1), "prof_enable")
+        nprof = 2
+        for _ in range(nprof):
+            model.zero_grad(set_to_none=False)
+            probs = model(feats, targets=caps[:, :-1], mode="train")
+            l2 = crit(probs, caps, mask)
+            l2.backward()
+        torch.cuda.synchronize(dev)
+        capi.check(lib.s2vt_prof_enable(0), "prof_enable")
+        gemm_ms, gemm_n = capi.prof_read(0)
+        sf_ms, sf_n = capi.prof_read(1)
+        sb_ms, sb_n = capi.prof_read(2)
+        ce_ms, ce_n = capi.prof_read(3)
+        capi.check(lib.s2vt_prof_reset(), "prof_reset")
+        log("profiled steps done")
+        gemm_ms /= nprof; sf_ms /= nprof; sb_ms /= nprof; ce_ms /= nprof
+        gflop = gemm_flops_train(B, L, F, H, E, V) / 1e9
+        gemm_tf = gflop / gemm_ms                 # GFLOP / ms = TFLOP/s
+        T = 2 * L - 1
+        pair_bytes = step_bytes_fwd(B, H, H) + step_bytes_fwd(B, H, E + H)
+        step_us = sf_ms * 1e3 / (2 * T)           # average launch of lstm_step_fwd_kernel (both layers)
+        step_gbs = (pair_bytes / 2) / (step_us * 1e-6) / 1e9
+        fam = {"gemm_f32_kernel": gemm_ms, "lstm_step_fwd_kernel": sf_ms, "lstm_step_bwd_kernel": sb_ms, "ce": ce_ms}
+        roof_gemm = {"kernel": "gemm_f32_kernel", "bound": "mfma", "achieved": round(gemm_tf, 2),
+                     "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(gemm_tf / MFMA_F32_PEAK_TF, 4),
+                     "traffic": None, "launches_per_step": gemm_n // nprof, "ms_per_step": round(gemm_ms, 3),
+                     "algorithmic_gflop_per_step": round(gflop, 1)}
+        roof_step = {"kernel": "lstm_step_fwd_kernel", "bound": "hbm", "achieved": round(step_gbs, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "avg_launch_us": round(step_us, 3), "launches_per_step": 2 * T,
+                     "algorithmic_bytes_per_launch": pair_bytes // 2,
+                     "note": "bytes per SURVEY.md §8(d) incl. W_ih although the x-part is hoisted into a batched GEMM; "
+                             "avg over vid+word launches, loop-bracketed events (includes launch gaps)"}
+        dominant = max(fam, key=fam.get)
+        roofline = roof_gemm if dominant == "gemm_f32_kernel" else roof_step
+
+        # ---- greedy decode captions/s (one mode='test' call per measurement)
+        Bd = args.decode_batch or B
+        dfe = feats[:Bd] if Bd <= B else synth.make_batch(Bd, L, F, V, seed=99)[0].to(dev)
+        model.eval()
+        with torch.no_grad():
+            model(dfe, mode="test")
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            nd = 3
+            for _ in range(nd):
+                ids = model(dfe, mode="test")
+            torch.cuda.synchronize(dev)
+            ddt = (time.perf_counter() - t1) / nd
+        decode = {"metric": "greedy-decode captions/sec", "value": round(Bd / ddt, 1), "unit": "captions/s",
+                  "batch": Bd, "ms_per_call": round(ddt * 1e3, 2), "n_gpus": 1}
+
+        log("decode: %s" % decode)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import s2vt_oracle as orc
+            cores = usable_cores()
+            log("cpu_baseline on %d threads" % cores)
+            torch.set_num_threads(cores)
+            Bc = min(16, B)
+            cm = orc.ReferenceShapedCPUModel(sd)
+            copt = torch.optim.Adam(cm.parameters(), lr=1e-4)
+            cf, cc, ck = feats[:Bc].cpu(), caps[:Bc].cpu(), mask[:Bc].cpu()
+
+            def cpu_step():
+                copt.zero_grad()
+                lg = cm(cf, cc[:, :-1])
+                ls = orc.mask_criterion(lg, cc, ck)
+                ls.backward()
+                copt.step()
+            cpu_step()
+            t2 = time.perf_counter()
+            ncpu = 2
+            for _ in range(ncpu):
+                cpu_step()
+            cdt = (time.perf_counter() - t2) / ncpu
+            t3 = time.perf_counter()
+            cm.greedy(cf)
+            gdt = time.perf_counter() - t3
+            cpu = {"value": round(Bc * L / cdt, 1), "unit": "frames/s", "cores": cores, "kind": "port",
+                   "sample": "same dims (L=80,F=4096,H=E=1000,V=12000), B=%d rows of the same batch, 1 warm-up + %d "
+                             "timed train steps with torch-CPU nn.LSTM/nn.Linear (what the reference runs on CPU), "
+                             "Adam(lr=1e-4); greedy: one call" % (Bc, ncpu),
+                   "ms_per_step": round(cdt * 1e3, 1), "greedy_captions_per_s": round(Bc / gdt, 2)}
+
+        out = {
+            "metric": "training frames/sec (whole node)", "value": round(frames_per_s, 1), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: S2VT train step, B=%d per GPU x %d GPU, 80x4096 feats, "
+                                   "hidden=embed=1000, vocab=12000, fp32, Adam" % (B, world),
+                       "global_batch": B * world, "frames": L, "parallelism": "dp%d" % world},
+            "final_loss": round(final_loss, 6),
+            "roofline": roofline,
+            "roofline_gemm": roof_gemm,
+            "roofline_lstm_step": roof_step,
+            "kernel_ms_per_step": {k: round(v, 3) for k, v in fam.items()},
+            "decode": decode,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -80,6 +80,14 @@ def load():
         raise S2VTHipError(
             "libs2vt_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `python s2vt-video-caption_amd/build.py`. There is no CPU fallback for the S2VT hot path." % LIB_PATH)
+    # The library must share torch's HIP runtime (torch owns the device memory and the streams it is handed):
+    # torch bundles its own libamdhip64.so.7, and the dynamic loader binds our DT_NEEDED of the same SONAME to
+    # whichever copy is already mapped.  Loading torch (and its runtime) FIRST guarantees a single runtime; the
+    # other order gives two runtimes in one process ("no ROCm-capable device is detected").
+    import torch
+    rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the library lacks a declared symbol

@@ -64,9 +64,7 @@ def test_lstm_step_fwd_matches_cell(lib, B, H):
     assert (st.cpu() - st_ref).abs().max().item() < 2e-6
     # zero state + bias only (first step of a padded sequence)
     bias = _r(4 * H, seed=6)
-    h2, c2 = ops.lstm_step_fwd(None, bias.to(DEV), w_hh.to(DEV), None, None)
     h_ref2, c_ref2 = orc.lstm_cell(None, torch.zeros(1, H), torch.zeros(1, H), None, w_hh, bias, zeros)
-    assert h2.shape[0] == 0 or True
     hb, cb = ops.lstm_step_fwd(bias.to(DEV).expand(B, 4 * H).contiguous(), None, w_hh.to(DEV), None, None)
     assert (hb.cpu() - h_ref2.expand(B, H)).abs().max().item() < 1e-6
 

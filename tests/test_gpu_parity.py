@@ -101,8 +101,14 @@ def test_c1_against_reference_golden(lib, golden):
         assert abs(float(grads[k].double().norm()) - gn) <= 2e-4 * gn + 1e-7, k
         ref = g["gradhead/" + k]
         assert np.abs(grads[k].reshape(-1)[:32].numpy() - ref).max() <= 1e-6 + 2e-4 * np.abs(ref).max(), k
+
+
+def test_c1_beam_search_against_reference_golden(lib, golden):
+    g = golden("c1")
+    d, sd, feats, caps, mask = _setup(g, "c1")
+    m = _model(d, sd).eval()
     with torch.no_grad():
-        out = m.eval()(feats[:2].to(DEV), mode="beam_search", beam_width=int(g["beam_width"]), max_beam_depth=30)
+        out = m(feats[:2].to(DEV), mode="beam_search", beam_width=int(g["beam_width"]), max_beam_depth=30)
     for b, s in enumerate(out):
         assert [int(t.item()) for t in s] == [int(x) for x in g["beam_ids"][b] if x >= 0]
 
