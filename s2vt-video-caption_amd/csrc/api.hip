@@ -57,11 +57,29 @@ static const RowMap ID = {nullptr, 0, 0};
 static inline RowMap perm(int inner, int outer) { return RowMap{nullptr, inner, outer}; }
 static inline RowMap gather(const int32_t* idx) { return RowMap{idx, 0, 0}; }
 
+// split-K scratch of the driver that is running (set by the whole-path entry points from their workspace)
+static thread_local float* g_gws = nullptr;
+static thread_local size_t g_gws_floats = 0;
+struct GemmWsScope {
+    GemmWsScope(float* p, size_t n) { g_gws = p; g_gws_floats = n; }
+    ~GemmWsScope() { g_gws = nullptr; g_gws_floats = 0; }
+};
+
 static int gemm(hipStream_t st, bool ak, bool bk, int M, int N, int K, const float* A, int64_t lda, RowMap am,
                 const float* B, int64_t ldb, RowMap bm, float* C, int64_t ldc, RowMap cm, const float* bias,
                 bool acc) {
     ProfScope ps(st, K_GEMM, 1);
-    return gemm_f32(st, ak, bk, M, N, K, A, lda, am, B, ldb, bm, C, ldc, cm, bias, acc);
+    return gemm_f32(st, ak, bk, M, N, K, A, lda, am, B, ldb, bm, C, ldc, cm, bias, acc, g_gws, g_gws_floats);
+}
+
+// scratch floats for split-K slabs: up to 4 slices of the largest small-grid GEMM output of the path
+static size_t gemm_ws_floats(const s2vt_dims& d) {
+    const size_t B = d.B, L = d.L, F = d.F, H = d.H, E = d.E, T = 2 * L - 1;
+    size_t m = T * B * H;                       // dh1 / x1-like activations
+    if (4 * H * (E + H) > m) m = 4 * H * (E + H);
+    if (H * F > m) m = H * F;
+    if (L * B * F / 4 > m) m = L * B * F / 4;   // dfeats (rarely split)
+    return 4 * m;
 }
 
 // ------------------------------------------------------------------ workspace carving
@@ -77,7 +95,8 @@ struct Carver {
 
 struct TrainWS {
     float *bsum1, *bsum2, *x1, *s1, *h1, *c1, *s2, *h2, *c2;
-    float *wt, *dh1, *dh2dec, *dx1, *de, *dc, *colsum;
+    float *wt, *dh1, *dh2dec, *dx1, *de, *dc, *colsum, *gws;
+    size_t gws_floats;
     int32_t* tok;
     int* err;
     size_t bytes;
@@ -113,6 +132,8 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     size_t cs2 = colsum_partial_floats((int64_t)(L - 1) * B, (int)V);
     size_t cs3 = colsum_partial_floats((int64_t)L * B, (int)H);
     w.colsum = c.take<float>(cs > cs2 ? (cs > cs3 ? cs : cs3) : (cs2 > cs3 ? cs2 : cs3));
+    w.gws_floats = gemm_ws_floats(d);
+    w.gws = c.take<float>(w.gws_floats);
     w.bytes = align_up(c.off, 256);
     return w;
 }
@@ -185,6 +206,7 @@ int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* fe
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
+    GemmWsScope gscope(w.gws, w.gws_floats);
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
     const int64_t BH = (int64_t)B * H;
     int rc;
@@ -220,6 +242,7 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
+    GemmWsScope gscope(w.gws, w.gws_floats);
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
     const int R = (L - 1) * B;
@@ -279,7 +302,8 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
 
 // ------------------------------------------------------------------ greedy decode
 struct DecodeWS {
-    float *bsum1, *bsum2, *x1, *gx1, *h1, *c1, *gx2, *h2, *c2;
+    float *bsum1, *bsum2, *x1, *gx1, *h1, *c1, *gx2, *h2, *c2, *gws;
+    size_t gws_floats;
     unsigned long long* packed;
     size_t bytes;
 };
@@ -297,6 +321,8 @@ static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
     w.h2 = c.take<float>(2 * B * H);
     w.c2 = c.take<float>(B * H);
     w.packed = c.take<unsigned long long>((L - 1) * B);
+    w.gws_floats = gemm_ws_floats(d);
+    w.gws = c.take<float>(w.gws_floats);
     w.bytes = align_up(c.off, 256);
     return w;
 }
@@ -313,6 +339,7 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
     const DecodeWS w = carve_decode(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_greedy_decode: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
+    GemmWsScope gscope(w.gws, w.gws_floats);
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
     int rc;

@@ -49,6 +49,9 @@ __device__ __forceinline__ int map_row(const RowMap& m, int r) {
     return r;
 }
 
+// 16 bytes of zeros in device memory: the target of redirected out-of-range loads (see load4_guard).
+static __device__ __attribute__((aligned(16))) float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 }  // namespace s2vt

@@ -33,23 +33,37 @@ struct GemmArgs {
     const float* bias;
     int accumulate;
     int vecA, vecB;   // 16-byte vector loads legal (ld % 4 == 0 and base 16-B aligned)
+    int ksplit;       // K range per blockIdx.y slice (multiple of BK); == K when not split
+    float* slabs;     // split-K: slice s writes its partial tile to slabs + s*M*N (row-major [M][N])
 };
 
-__device__ __forceinline__ f32x4 load4_guard(const float* row, int c, int limit, bool vec) {
-    // row may be nullptr (out-of-range stored row) -> zeros
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row == nullptr || c >= limit) return v;
-    if (vec && c + 3 < limit) {
-        v = *reinterpret_cast<const f32x4*>(row + c);
+// Branch-free guarded load of 4 consecutive floats of a stored row.  hipcc turns a load under a runtime
+// condition into a branch around it plus a vmcnt(0) wait per element (cdna_hip_programming.md §5 trap (c)),
+// which serialises the whole staging burst; so out-of-range accesses are redirected to a safe address
+// (`base`) and zeroed with a select instead.  VEC: limit % 4 == 0, c % 4 == 0 and 16-B aligned rows, so a
+// float4 starting below `limit` is entirely in range.
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4_guard(const float* base, const float* row, int c, int limit) {
+    // Out-of-range accesses read a 16-byte block of zeros instead of being masked afterwards: the loaded value
+    // then has NO consumer before the LDS staging store, so the loads stay in flight across the MFMA phase
+    // (a select on the result would pull the vmcnt wait in front of the MFMAs).
+    f32x4 v;
+    if (VEC) {
+        const bool ok = (row != nullptr) && (c < limit);
+        const float* q = ok ? row + c : g_zero4;
+        v = *reinterpret_cast<const f32x4*>(q);
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c + j < limit) v[j] = row[c + j];
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = (row != nullptr) && (c + j < limit);
+            const float* q = ok ? row + c + j : g_zero4;
+            v[j] = *q;
+        }
     }
     return v;
 }
 
-template <bool A_KMAJOR, bool B_KMAJOR>
+template <bool A_KMAJOR, bool B_KMAJOR, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * OPER_FLOATS];
     float* sA = smem;
@@ -60,9 +74,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int ntn = (p.N + BN - 1) / BN;
-    const int tm = blockIdx.x / ntn, tn = blockIdx.x % ntn;
+    // XCD-aware tile order (speed only): blocks are dealt round-robin over the 8 XCDs, so XCD x is handed the
+    // contiguous tile range [x*cpx, (x+1)*cpx); inside it tiles walk 8-row groups column by column, so the
+    // ~100 tiles resident on one XCD form a compact rectangle and share their A/B panels through that XCD's L2.
+    const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
+    const int nwg = ntm * ntn, cpx = (nwg + 7) >> 3;
+    const int t = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= cpx || t >= nwg) return;
+    constexpr int GM = 8;
+    const int gsz = GM * ntn, grp = t / gsz, first_m = grp * GM;
+    const int gm = (ntm - first_m < GM) ? (ntm - first_m) : GM;
+    const int tm = first_m + (t % gsz) % gm, tn = (t % gsz) / gm;
     const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = blockIdx.y * p.ksplit;
+    const int kend = (kbeg + p.ksplit < p.K) ? kbeg + p.ksplit : p.K;
 
     // ---- per-thread staging coordinates
     // k-major operand: 4 x (row = tid/8 + 32 i, kq = (tid%8)*4)
@@ -89,27 +114,27 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         if (A_KMAJOR) {
             const int kq = k0 + (tid & 7) * 4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ra[i] = load4_guard(a_rows[i], kq, p.K, p.vecA);
+            for (int i = 0; i < 4; ++i) ra[i] = load4_guard<VEC>(p.A, a_rows[i], kq, kend);
         } else {
             const int mq = m0 + (tid & 31) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int k = k0 + (tid >> 5) + 8 * i;
-                const float* row = (k < p.K) ? p.A + (int64_t)map_row(p.amap, k) * p.lda : nullptr;
-                ra[i] = load4_guard(row, mq, p.M, p.vecA);
+                const float* row = (k < kend) ? p.A + (int64_t)map_row(p.amap, k) * p.lda : nullptr;
+                ra[i] = load4_guard<VEC>(p.A, row, mq, p.M);
             }
         }
         if (B_KMAJOR) {
             const int kq = k0 + (tid & 7) * 4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rb[i] = load4_guard(b_rows[i], kq, p.K, p.vecB);
+            for (int i = 0; i < 4; ++i) rb[i] = load4_guard<VEC>(p.B, b_rows[i], kq, kend);
         } else {
             const int nq = n0 + (tid & 31) * 4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int k = k0 + (tid >> 5) + 8 * i;
-                const float* row = (k < p.K) ? p.B + (int64_t)map_row(p.bmap, k) * p.ldb : nullptr;
-                rb[i] = load4_guard(row, nq, p.N, p.vecB);
+                const float* row = (k < kend) ? p.B + (int64_t)map_row(p.bmap, k) * p.ldb : nullptr;
+                rb[i] = load4_guard<VEC>(p.B, row, nq, p.N);
             }
         }
     };
@@ -142,12 +167,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const int nkt = (p.K + BK - 1) / BK;
-    load_tile(0);
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+    load_tile(kbeg);
     for (int kt = 0; kt < nkt; ++kt) {
         store_tile();
         __syncthreads();
-        if (kt + 1 < nkt) load_tile((kt + 1) * BK);
+        if (kt + 1 < nkt) load_tile(kbeg + (kt + 1) * BK);
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
             f32x4 a[2], b[2];
@@ -189,6 +214,15 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m >= p.M) continue;
+            if (p.slabs) {   // split-K partial: plain [M][N] slab, combined by splitk_reduce_kernel
+                float* srow = p.slabs + ((int64_t)blockIdx.y * p.M + m) * p.N;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int n = n0 + wn * 64 + ni * 32 + li;
+                    if (n < p.N) srow[n] = acc[mi][ni][r];
+                }
+                continue;
+            }
             float* crow = p.C + (int64_t)map_row(p.cmap, m) * p.ldc;
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
@@ -207,9 +241,40 @@ static inline bool vec_ok(const void* ptr, int64_t ld) {
     return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0);
 }
 
+// C[map(m)][n] (+)= sum_s slabs[s][m][n] (+ bias[n]), fixed summation order (deterministic).
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, int nsplit, int M, int N, float* C,
+                                                            int64_t ldc, RowMap cmap, const float* bias, int accumulate) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one float4 of a row
+    const int nq = (N + 3) / 4;
+    if (q >= (int64_t)M * nq) return;
+    const int m = (int)(q / nq), n = (int)(q % nq) * 4;
+    const int64_t MN = (int64_t)M * N;
+    const float* src = slabs + (int64_t)m * N + n;
+    float* crow = C + (int64_t)map_row(cmap, m) * ldc;
+    const bool vec = (N % 4 == 0);
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < nsplit; ++s) {
+        if (vec) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(src + s * MN);
+            v[0] += x[0]; v[1] += x[1]; v[2] += x[2]; v[3] += x[3];
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (n + j < N) v[j] += src[s * MN + j];
+        }
+    }
+    for (int j = 0; j < 4; ++j) {
+        if (n + j >= N) break;
+        float o = v[j];
+        if (bias) o += bias[n + j];
+        if (accumulate) o += crow[n + j];
+        crow[n + j] = o;
+    }
+}
+
 int gemm_f32(hipStream_t stream, bool a_kmajor, bool b_kmajor, int M, int N, int K,
              const float* A, int64_t lda, RowMap amap, const float* B, int64_t ldb, RowMap bmap,
-             float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate) {
+             float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate,
+             float* splitk_ws, size_t splitk_ws_floats) {
     if (M <= 0 || N <= 0) return 0;
     S2VT_REQUIRE(K >= 0 && A && B && C, "gemm_f32: bad arguments (M=%d N=%d K=%d)", M, N, K);
     S2VT_REQUIRE(a_kmajor || !b_kmajor, "gemm_f32: A^T * B^T form is not used by the S2VT path");
@@ -219,15 +284,34 @@ int gemm_f32(hipStream_t stream, bool a_kmajor, bool b_kmajor, int M, int N, int
     p.B = B; p.ldb = ldb; p.bmap = bmap;
     p.C = C; p.ldc = ldc; p.cmap = cmap;
     p.bias = bias; p.accumulate = accumulate ? 1 : 0;
-    p.vecA = vec_ok(A, lda); p.vecB = vec_ok(B, ldb);
-    const int grid = cdiv(M, BM) * cdiv(N, BN);
-    if (a_kmajor && b_kmajor)
-        hipLaunchKernelGGL((gemm_f32_kernel<true, true>), dim3(grid), dim3(256), 0, stream, p);
-    else if (a_kmajor && !b_kmajor)
-        hipLaunchKernelGGL((gemm_f32_kernel<true, false>), dim3(grid), dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<false, false>), dim3(grid), dim3(256), 0, stream, p);
+    // vector path: every 16-B load of both operands is aligned and never straddles the end of a stored row
+    const bool vec = vec_ok(A, lda) && vec_ok(B, ldb) && ((a_kmajor ? K : M) % 4 == 0) && ((b_kmajor ? K : N) % 4 == 0);
+    p.vecA = p.vecB = vec ? 1 : 0;
+    const int tiles = cdiv(M, BM) * cdiv(N, BN);
+    // Small grids (< 2 workgroups per CU) leave the matrix pipes idle during every staging phase: split K so
+    // that ~3 workgroups per CU are in flight, partial tiles to slabs, fixed-order reduce (deterministic).
+    int nsplit = 1;
+    if (splitk_ws && tiles < 512 && K >= 8 * BK) {
+        nsplit = cdiv(768, tiles);
+        if (nsplit > 8) nsplit = 8;
+        while (nsplit > 1 && (K / nsplit < 4 * BK || (size_t)nsplit * M * N > splitk_ws_floats)) --nsplit;
+    }
+    p.ksplit = (nsplit > 1) ? cdiv(cdiv(K, nsplit), BK) * BK : (K > 0 ? K : 1);
+    if (nsplit > 1) nsplit = cdiv(K, p.ksplit);
+    p.slabs = (nsplit > 1) ? splitk_ws : nullptr;
+    const dim3 grid(cdiv(tiles, 8) * 8, nsplit);
+#define S2VT_GEMM_LAUNCH(AK, BK_, V) hipLaunchKernelGGL((gemm_f32_kernel<AK, BK_, V>), grid, dim3(256), 0, stream, p)
+    if (a_kmajor && b_kmajor) { if (vec) S2VT_GEMM_LAUNCH(true, true, true); else S2VT_GEMM_LAUNCH(true, true, false); }
+    else if (a_kmajor) { if (vec) S2VT_GEMM_LAUNCH(true, false, true); else S2VT_GEMM_LAUNCH(true, false, false); }
+    else { if (vec) S2VT_GEMM_LAUNCH(false, false, true); else S2VT_GEMM_LAUNCH(false, false, false); }
+#undef S2VT_GEMM_LAUNCH
     S2VT_LAUNCH_CHECK("gemm_f32_kernel");
+    if (nsplit > 1) {
+        const int64_t nq = (int64_t)M * ((N + 3) / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, splitk_ws,
+                           nsplit, M, N, C, ldc, cmap, bias, accumulate ? 1 : 0);
+        S2VT_LAUNCH_CHECK("splitk_reduce_kernel");
+    }
     return 0;
 }
 

@@ -7,7 +7,8 @@ namespace s2vt {
 // ---- gemm.hip
 int gemm_f32(hipStream_t stream, bool a_kmajor, bool b_kmajor, int M, int N, int K,
              const float* A, int64_t lda, RowMap amap, const float* B, int64_t ldb, RowMap bmap,
-             float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate);
+             float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate,
+             float* splitk_ws = nullptr, size_t splitk_ws_floats = 0);
 
 // ---- lstm.hip
 struct StepFwdArgs {

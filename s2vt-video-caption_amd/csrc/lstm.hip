@@ -24,25 +24,35 @@ constexpr int KC = 64;       // k chunk per wave iteration
 constexpr int SLD = 68;      // LDS row stride in floats
 constexpr int NWAVE = 4;
 
-__device__ __forceinline__ f32x4 ld4(const float* row, int c, int limit, bool vec) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row == nullptr || c >= limit) return v;
-    if (vec && c + 3 < limit) {
-        v = *reinterpret_cast<const f32x4*>(row + c);
+// Branch-free guarded 4-float load (see gemm.hip load4_guard): out-of-range accesses read a safe address and
+// are zeroed by a select, so the staging burst stays a run of independent loads.
+template <bool VEC>
+__device__ __forceinline__ f32x4 ld4(const float* base, const float* row, int c, int limit) {
+    // Out-of-range accesses read a 16-byte block of zeros instead of being masked afterwards: the loaded value
+    // then has NO consumer before the LDS staging store, so the loads stay in flight across the MFMA phase
+    // (a select on the result would pull the vmcnt wait in front of the MFMAs).
+    f32x4 v;
+    if (VEC) {
+        const bool ok = (row != nullptr) && (c < limit);
+        const float* q = ok ? row + c : g_zero4;
+        v = *reinterpret_cast<const f32x4*>(q);
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (c + j < limit) v[j] = row[c + j];
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = (row != nullptr) && (c + j < limit);
+            const float* q = ok ? row + c + j : g_zero4;
+            v[j] = *q;
+        }
     }
     return v;
 }
 
 // acc[mi][ni][a] += A[16*MT rows, 0:K] · B[16*NT rows, 0:K]^T over this wave's chunks.
 // arow/brow: per-lane row pointers for rows (lane/16 + 4 i); sA/sB: wave-private LDS images.
-template <int MT, int NT, int NA>
-__device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const float* const (&arow)[MT * 4],
-                                             const float* const (&brow)[NT * 4], int K, bool vecA, bool vecB,
-                                             float* sA, float* sB, int wave, int lane) {
+template <int MT, int NT, int NA, bool VEC>
+__device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const float* abase, const float* bbase,
+                                             const float* const (&arow)[MT * 4], const float* const (&brow)[NT * 4],
+                                             int K, float* sA, float* sB, int wave, int lane) {
     const int nch = (K + KC - 1) / KC;
     const int lrow = lane >> 4, kq = (lane & 15) * 4;
     const int fi = lane & 15, fq = lane >> 4;
@@ -50,9 +60,9 @@ __device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const flo
     int c = wave;
     if (c < nch) {
 #pragma unroll
-        for (int i = 0; i < MT * 4; ++i) ra[i] = ld4(arow[i], c * KC + kq, K, vecA);
+        for (int i = 0; i < MT * 4; ++i) ra[i] = ld4<VEC>(abase, arow[i], c * KC + kq, K);
 #pragma unroll
-        for (int i = 0; i < NT * 4; ++i) rb[i] = ld4(brow[i], c * KC + kq, K, vecB);
+        for (int i = 0; i < NT * 4; ++i) rb[i] = ld4<VEC>(bbase, brow[i], c * KC + kq, K);
     }
     while (c < nch) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -65,9 +75,9 @@ __device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const flo
         const int cn = c + NWAVE;
         if (cn < nch) {
 #pragma unroll
-            for (int i = 0; i < MT * 4; ++i) ra[i] = ld4(arow[i], cn * KC + kq, K, vecA);
+            for (int i = 0; i < MT * 4; ++i) ra[i] = ld4<VEC>(abase, arow[i], cn * KC + kq, K);
 #pragma unroll
-            for (int i = 0; i < NT * 4; ++i) rb[i] = ld4(brow[i], cn * KC + kq, K, vecB);
+            for (int i = 0; i < NT * 4; ++i) rb[i] = ld4<VEC>(bbase, brow[i], cn * KC + kq, K);
         }
 #pragma unroll
         for (int s = 0; s < KC / 16; ++s) {
@@ -117,20 +127,35 @@ __device__ __forceinline__ float read_sum(const float* red, int row, int col) {
     return s;
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 labels the XCD group).  All NY batch tiles of
+// one column tile read the same weight slice, so they are given ids that differ by a multiple of 8: the slice
+// is then fetched into ONE XCD's L2 (16 MB of W_hh / 8 XCDs = 2 MB per 4 MB L2) instead of NY of them.
+// Speed only: any placement is correct.  Grid = ceil(NX/8)*8*NY blocks; ids with x >= NX exit.
+__device__ __forceinline__ bool xcd_tile(int NX, int NY, int& x, int& y) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, j = id >> 3;
+    x = (j / NY) * 8 + xcd;
+    y = j % NY;
+    return x < NX;
+}
+static inline int xcd_grid(int NX, int NY) { return ((NX + 7) / 8) * 8 * NY; }
+
 static inline bool vec_ok(const void* ptr, int64_t ld) {
     return ptr != nullptr && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(ptr) & 15) == 0);
 }
 
 // ------------------------------------------------------------------------------ forward step
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepFwdArgs p, int vec1, int vec2) {
+template <int MT, int NT, bool VEC>
+__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepFwdArgs p) {
     constexpr int TM = 16 * MT, TN = 16 * NT, UN = TN / 4;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* sA = smem + wave * (TM + TN) * SLD;
     float* sB = sA + TM * SLD;
-    const int b0 = blockIdx.y * TM, u0 = blockIdx.x * UN;
+    int tx, ty;
+    if (!xcd_tile((p.H + UN - 1) / UN, (p.B + TM - 1) / TM, tx, ty)) return;
+    const int b0 = ty * TM, u0 = tx * UN;
     const int lrow = lane >> 4;
 
     f32x4 acc[MT][NT][NA];
@@ -154,7 +179,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepFwdArgs p, int v
             const int r = lrow + 4 * i, g = r / UN, u = u0 + r % UN;
             brow[i] = (u < p.H) ? p.w_hh + ((int64_t)g * p.H + u) * p.ldw : nullptr;
         }
-        wave_gemm_nt<MT, NT, NA>(acc, arow, brow, p.H, vec1 & 1, vec1 & 2, sA, sB, wave, lane);
+        wave_gemm_nt<MT, NT, NA, VEC>(acc, p.h_prev, p.w_hh, arow, brow, p.H, sA, sB, wave, lane);
     }
     if (p.x2) {
         const float* arow[MT * 4];
@@ -177,7 +202,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepFwdArgs p, int v
             const int r = lrow + 4 * i, g = r / UN, u = u0 + r % UN;
             brow[i] = (u < p.H) ? p.w2 + ((int64_t)g * p.H + u) * p.ldw2 : nullptr;
         }
-        wave_gemm_nt<MT, NT, NA>(acc, arow, brow, p.K2, vec2 & 1, vec2 & 2, sA, sB, wave, lane);
+        wave_gemm_nt<MT, NT, NA, VEC>(acc, p.x2, p.w2, arow, brow, p.K2, sA, sB, wave, lane);
     }
 
     __syncthreads();
@@ -220,29 +245,34 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepFwdArgs p, int v
 int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a) {
     S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.h_out && a.c_out, "lstm_step_fwd: bad arguments");
     S2VT_REQUIRE(a.gx || a.bias, "lstm_step_fwd: need gx or bias");
-    const int vec1 = (vec_ok(a.h_prev, a.ldh) ? 1 : 0) | (vec_ok(a.w_hh, a.ldw) ? 2 : 0);
-    const int vec2 = (vec_ok(a.x2, a.ldx2) ? 1 : 0) | (vec_ok(a.w2, a.ldw2) ? 2 : 0);
+    // vector path: 16-B aligned rows whose length is a multiple of 4 floats, for every operand in use
+    const bool vec = (!a.h_prev || (vec_ok(a.h_prev, a.ldh) && vec_ok(a.w_hh, a.ldw) && a.H % 4 == 0)) &&
+                     (!a.x2 || (vec_ok(a.x2, a.ldx2) && vec_ok(a.w2, a.ldw2) && a.K2 % 4 == 0));
     if (a.B <= 16) {
-        dim3 grid(cdiv(a.H, 8), cdiv(a.B, 16));
-        hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2>), grid, dim3(256), 0, stream, a, vec1, vec2);
+        dim3 grid(xcd_grid(cdiv(a.H, 8), cdiv(a.B, 16)));
+        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, false>), grid, dim3(256), 0, stream, a);
     } else {
-        dim3 grid(cdiv(a.H, 8), cdiv(a.B, 32));
-        hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2>), grid, dim3(256), 0, stream, a, vec1, vec2);
+        dim3 grid(xcd_grid(cdiv(a.H, 8), cdiv(a.B, 32)));
+        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, false>), grid, dim3(256), 0, stream, a);
     }
     S2VT_LAUNCH_CHECK("lstm_step_fwd_kernel");
     return 0;
 }
 
 // ----------------------------------------------------------------------------- backward step
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepBwdArgs p, int vec) {
+template <int MT, int NT, bool VEC>
+__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepBwdArgs p) {
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* sA = smem + wave * (TM + TN) * SLD;
     float* sB = sA + TM * SLD;
-    const int b0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    int tx, ty;
+    if (!xcd_tile((p.H + TN - 1) / TN, (p.B + TM - 1) / TM, tx, ty)) return;
+    const int b0 = ty * TM, n0 = tx * TN;
     const int lrow = lane >> 4;
 
     f32x4 acc[MT][NT][NA];
@@ -266,7 +296,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepBwdArgs p, int v
             const int n = n0 + lrow + 4 * i;
             brow[i] = (n < p.H) ? p.w_hh_t + (int64_t)n * p.ldwt : nullptr;
         }
-        wave_gemm_nt<MT, NT, NA>(acc, arow, brow, 4 * p.H, vec & 1, vec & 2, sA, sB, wave, lane);
+        wave_gemm_nt<MT, NT, NA, VEC>(acc, p.dg_next, p.w_hh_t, arow, brow, 4 * p.H, sA, sB, wave, lane);
     }
     __syncthreads();
     float* red = smem;
@@ -298,9 +328,10 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepBwdArgs p, int v
 
 int lstm_step_bwd(hipStream_t stream, const StepBwdArgs& a) {
     S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.stash && a.c && a.dc && a.dg, "lstm_step_bwd: bad arguments");
-    const int vec = (vec_ok(a.dg_next, a.lddg) ? 1 : 0) | (vec_ok(a.w_hh_t, a.ldwt) ? 2 : 0);
-    dim3 grid(cdiv(a.H, 16), cdiv(a.B, 16));
-    hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1>), grid, dim3(256), 0, stream, a, vec);
+    const bool vec = !a.dg_next || (vec_ok(a.dg_next, a.lddg) && vec_ok(a.w_hh_t, a.ldwt));
+    dim3 grid(xcd_grid(cdiv(a.H, 16), cdiv(a.B, 16)));
+    if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, false>), grid, dim3(256), 0, stream, a);
     S2VT_LAUNCH_CHECK("lstm_step_bwd_kernel");
     return 0;
 }
@@ -311,15 +342,17 @@ __device__ __forceinline__ uint32_t ordered_bits(float x) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-template <int MT, int NT>
-__global__ __launch_bounds__(256) void logits_argmax_kernel(LogitsArgmaxArgs p, int vec) {
+template <int MT, int NT, bool VEC>
+__global__ __launch_bounds__(256) void logits_argmax_kernel(LogitsArgmaxArgs p) {
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float* sA = smem + wave * (TM + TN) * SLD;
     float* sB = sA + TM * SLD;
-    const int b0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    int tx, ty;
+    if (!xcd_tile((p.V + TN - 1) / TN, (p.B + TM - 1) / TM, tx, ty)) return;
+    const int b0 = ty * TM, n0 = tx * TN;
     const int lrow = lane >> 4;
 
     f32x4 acc[MT][NT][NA];
@@ -342,7 +375,7 @@ __global__ __launch_bounds__(256) void logits_argmax_kernel(LogitsArgmaxArgs p, 
             const int n = n0 + lrow + 4 * i;
             brow[i] = (n < p.V) ? p.w_out + (int64_t)n * p.ldw : nullptr;
         }
-        wave_gemm_nt<MT, NT, NA>(acc, arow, brow, p.H, vec & 1, vec & 2, sA, sB, wave, lane);
+        wave_gemm_nt<MT, NT, NA, VEC>(acc, p.h, p.w_out, arow, brow, p.H, sA, sB, wave, lane);
     }
     __syncthreads();
     float* red = smem;
@@ -375,9 +408,10 @@ __global__ __launch_bounds__(256) void logits_argmax_kernel(LogitsArgmaxArgs p, 
 
 int logits_argmax(hipStream_t stream, const LogitsArgmaxArgs& a) {
     S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.V > 0 && a.h && a.w_out && a.packed, "logits_argmax: bad arguments");
-    const int vec = (vec_ok(a.h, a.ldh) ? 1 : 0) | (vec_ok(a.w_out, a.ldw) ? 2 : 0);
-    dim3 grid(cdiv(a.V, 32), cdiv(a.B, 32));
-    hipLaunchKernelGGL((logits_argmax_kernel<2, 2>), grid, dim3(256), 0, stream, a, vec);
+    const bool vec = vec_ok(a.h, a.ldh) && vec_ok(a.w_out, a.ldw) && a.H % 4 == 0;
+    dim3 grid(xcd_grid(cdiv(a.V, 32), cdiv(a.B, 32)));
+    if (vec) hipLaunchKernelGGL((logits_argmax_kernel<2, 2, true>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((logits_argmax_kernel<2, 2, false>), grid, dim3(256), 0, stream, a);
     S2VT_LAUNCH_CHECK("logits_argmax_kernel");
     return 0;
 }
