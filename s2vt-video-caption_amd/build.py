@@ -27,15 +27,16 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link the shared library. Returns its path."""
-    if not force and not needs_build():
+def build(force=False, verbose=False, defines=(), out_path=None):
+    """Compile every HIP source for gfx950 and link the shared library. Returns its path.
+    `defines`/`out` build an experimental variant (tools/bench_step.py) next to the product library."""
+    if out_path is None and not force and not needs_build():
         return LIB
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build" if out_path is None else "build_" + os.path.basename(out_path))
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     flags = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-fno-gpu-rdc", "-Wall",
-             "-Wno-unused-function", "-Wno-unused-variable"]
+             "-Wno-unused-function", "-Wno-unused-variable"] + ["-D" + d for d in defines]
     procs = []
     for s in SOURCES:
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
@@ -51,13 +52,14 @@ def build(force=False, verbose=False):
         if verbose and out:
             print(out.decode(errors="replace"))
         objs.append(obj)
-    tmp = LIB + ".tmp"
+    target = LIB if out_path is None else out_path
+    tmp = target + ".tmp"
     cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout.decode(errors="replace"))
-    os.replace(tmp, LIB)
-    return LIB
+    os.replace(tmp, target)
+    return target
 
 
 if __name__ == "__main__":

@@ -22,7 +22,15 @@ namespace s2vt {
 
 constexpr int KC = 64;       // k chunk per wave iteration
 constexpr int SLD = 68;      // LDS row stride in floats
-constexpr int NWAVE = 4;
+#ifndef S2VT_NWAVE
+#define S2VT_NWAVE 8
+#endif
+#ifndef S2VT_PF
+#define S2VT_PF 2
+#endif
+constexpr int NWAVE = S2VT_NWAVE;      // waves per workgroup = K-split factor inside the workgroup
+constexpr int NTHR = NWAVE * 64;
+constexpr int PF = S2VT_PF;            // staging chunks in flight per wave (register prefetch depth)
 
 // Branch-free guarded 4-float load (see gemm.hip load4_guard): out-of-range accesses read a safe address and
 // are zeroed by a select, so the staging burst stays a run of independent loads.
@@ -32,6 +40,10 @@ __device__ __forceinline__ f32x4 ld4(const float* base, const float* row, int c,
     // then has NO consumer before the LDS staging store, so the loads stay in flight across the MFMA phase
     // (a select on the result would pull the vmcnt wait in front of the MFMAs).
     f32x4 v;
+#if defined(S2VT_ABLATE) && S2VT_ABLATE == 1   // timing experiment: no global traffic
+    v = f32x4{0.f, 0.f, 0.f, 0.f};
+    return v;
+#endif
     if (VEC) {
         const bool ok = (row != nullptr) && (c < limit);
         const float* q = ok ? row + c : g_zero4;
@@ -53,55 +65,70 @@ template <int MT, int NT, int NA, bool VEC>
 __device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const float* abase, const float* bbase,
                                              const float* const (&arow)[MT * 4], const float* const (&brow)[NT * 4],
                                              int K, float* sA, float* sB, int wave, int lane) {
+    // Wave w owns chunks w, w+NWAVE, ...; PF of them are in flight (registers) at any time.  Loads are issued
+    // unconditionally (chunks past K read the zero block), so the body is straight-line code and the compiler's
+    // counted vmcnt leaves the younger chunks in flight while the oldest is staged and multiplied.
     const int nch = (K + KC - 1) / KC;
+    const int per_wave = (nch + NWAVE - 1) / NWAVE;
+    const int n_round = (per_wave + PF - 1) / PF;
     const int lrow = lane >> 4, kq = (lane & 15) * 4;
     const int fi = lane & 15, fq = lane >> 4;
-    f32x4 ra[MT * 4], rb[NT * 4];
-    int c = wave;
-    if (c < nch) {
+    f32x4 ra[PF][MT * 4], rb[PF][NT * 4];
 #pragma unroll
-        for (int i = 0; i < MT * 4; ++i) ra[i] = ld4<VEC>(abase, arow[i], c * KC + kq, K);
+    for (int d = 0; d < PF; ++d) {
+        const int k0 = (wave + d * NWAVE) * KC + kq;
 #pragma unroll
-        for (int i = 0; i < NT * 4; ++i) rb[i] = ld4<VEC>(bbase, brow[i], c * KC + kq, K);
+        for (int i = 0; i < MT * 4; ++i) ra[d][i] = ld4<VEC>(abase, arow[i], k0, K);
+#pragma unroll
+        for (int i = 0; i < NT * 4; ++i) rb[d][i] = ld4<VEC>(bbase, brow[i], k0, K);
     }
-    while (c < nch) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if defined(S2VT_ABLATE) && S2VT_ABLATE == 3   // timing experiment: launch + epilogue only
+    return;
+#endif
+    for (int r = 0; r < n_round; ++r) {
 #pragma unroll
-        for (int i = 0; i < MT * 4; ++i) *reinterpret_cast<f32x4*>(&sA[(lrow + 4 * i) * SLD + kq]) = ra[i];
+        for (int d = 0; d < PF; ++d) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int i = 0; i < NT * 4; ++i) *reinterpret_cast<f32x4*>(&sB[(lrow + 4 * i) * SLD + kq]) = rb[i];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const int cn = c + NWAVE;
-        if (cn < nch) {
+            for (int i = 0; i < MT * 4; ++i) *reinterpret_cast<f32x4*>(&sA[(lrow + 4 * i) * SLD + kq]) = ra[d][i];
 #pragma unroll
-            for (int i = 0; i < MT * 4; ++i) ra[i] = ld4<VEC>(abase, arow[i], cn * KC + kq, K);
+            for (int i = 0; i < NT * 4; ++i) *reinterpret_cast<f32x4*>(&sB[(lrow + 4 * i) * SLD + kq]) = rb[d][i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            {   // refill this stage with the chunk PF rounds ahead
+                const int k0 = (wave + ((r + 1) * PF + d) * NWAVE) * KC + kq;
 #pragma unroll
-            for (int i = 0; i < NT * 4; ++i) rb[i] = ld4<VEC>(bbase, brow[i], cn * KC + kq, K);
-        }
+                for (int i = 0; i < MT * 4; ++i) ra[d][i] = ld4<VEC>(abase, arow[i], k0, K);
 #pragma unroll
-        for (int s = 0; s < KC / 16; ++s) {
-            f32x4 a[MT], b[NT];
+                for (int i = 0; i < NT * 4; ++i) rb[d][i] = ld4<VEC>(bbase, brow[i], k0, K);
+            }
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                a[mi] = *reinterpret_cast<const f32x4*>(&sA[(mi * 16 + fi) * SLD + 16 * s + 4 * fq]);
-#pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-                b[ni] = *reinterpret_cast<const f32x4*>(&sB[(ni * 16 + fi) * SLD + 16 * s + 4 * fq]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int s = 0; s < KC / 16; ++s) {
+                f32x4 a[MT], b[NT];
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
+                    a[mi] = *reinterpret_cast<const f32x4*>(&sA[(mi * 16 + fi) * SLD + 16 * s + 4 * fq]);
 #pragma unroll
-                    for (int ni = 0; ni < NT; ++ni)
-                        acc[mi][ni][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                            a[mi][j], b[ni][j], acc[mi][ni][j & (NA - 1)], 0, 0, 0);
+                for (int ni = 0; ni < NT; ++ni)
+                    b[ni] = *reinterpret_cast<const f32x4*>(&sB[(ni * 16 + fi) * SLD + 16 * s + 4 * fq]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NT; ++ni)
+#if defined(S2VT_ABLATE) && S2VT_ABLATE == 2   // timing experiment: operands staged and read, no MFMA
+                            asm volatile("" ::"v"(a[mi][j]), "v"(b[ni][j]));
+#else
+                            acc[mi][ni][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                a[mi][j], b[ni][j], acc[mi][ni][j & (NA - 1)], 0, 0, 0);
+#endif
+            }
         }
-        c = cn;
     }
 }
 
-// Sum the 4 waves' partial tiles: every wave writes its accumulators to red[wave][row][col],
+// Sum the NWAVE waves' partial tiles: every wave writes its accumulators to red[wave][row][col],
 // after which red holds 4 partials per output.  16x16 C/D layout: col = lane&15, row = 4*(lane>>4)+reg.
 template <int MT, int NT, int NA>
 __device__ __forceinline__ void write_partials(const f32x4 (&acc)[MT][NT][NA], float* red, int wave, int lane) {
@@ -146,7 +173,7 @@ static inline bool vec_ok(const void* ptr, int64_t ld) {
 
 // ------------------------------------------------------------------------------ forward step
 template <int MT, int NT, bool VEC>
-__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepFwdArgs p) {
+__global__ __launch_bounds__(NTHR) void lstm_step_fwd_kernel(StepFwdArgs p) {
     constexpr int TM = 16 * MT, TN = 16 * NT, UN = TN / 4;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
@@ -165,6 +192,24 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepFwdArgs p) {
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
             for (int a = 0; a < NA; ++a) acc[mi][ni][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Epilogue operands (gate inputs, c_{t-1}) are requested NOW, ahead of the K loop, so their HBM/MALL latency
+    // is hidden behind the contraction instead of being exposed after it (one output element per thread).
+    static_assert(TM * UN <= NTHR, "one epilogue element per thread");
+    const int ebl = tid / UN, eu = tid % UN;
+    const int eb = b0 + ebl, eunit = u0 + eu;
+    const bool evalid = (tid < TM * UN) && (eb < p.B) && (eunit < p.H);
+    float gxv[4], cpv;
+    {
+        const float* gsrc = p.gx ? p.gx + (int64_t)eb * p.ldgx : p.bias;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float* q = (evalid && gsrc) ? gsrc + (int64_t)g * p.H + eunit : g_zero4;
+            gxv[g] = *q;
+        }
+        const float* q = (evalid && p.c_prev) ? p.c_prev + (int64_t)eb * p.ldc + eunit : g_zero4;
+        cpv = *q;
+    }
 
     if (p.h_prev) {
         const float* arow[MT * 4];
@@ -210,24 +255,16 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepFwdArgs p) {
     write_partials<MT, NT, NA>(acc, red, wave, lane);
     __syncthreads();
 
-    for (int e = tid; e < TM * UN; e += 256) {
-        const int bl = e / UN, u = e % UN;
-        const int b = b0 + bl, unit = u0 + u;
-        if (b >= p.B || unit >= p.H) continue;
+    if (evalid) {
+        const int bl = ebl, u = eu, b = eb, unit = eunit;
         float pre[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float v = read_sum<MT, NT>(red, bl, g * UN + u);
-            const int col = g * p.H + unit;
-            v += p.gx ? p.gx[(int64_t)b * p.ldgx + col] : (p.bias ? p.bias[col] : 0.f);
-            pre[g] = v;
-        }
+        for (int g = 0; g < 4; ++g) pre[g] = read_sum<MT, NT>(red, bl, g * UN + u) + gxv[g];
         const float ig = 1.0f / (1.0f + expf(-pre[0]));
         const float fg = 1.0f / (1.0f + expf(-pre[1]));
         const float gg = tanhf(pre[2]);
         const float og = 1.0f / (1.0f + expf(-pre[3]));
-        const float cp = p.c_prev ? p.c_prev[(int64_t)b * p.ldc + unit] : 0.f;
-        const float c = fg * cp + ig * gg;
+        const float c = fg * cpv + ig * gg;
         const float h = og * tanhf(c);
         p.h_out[(int64_t)b * p.ldho + unit] = h;
         if (p.h_out2) p.h_out2[(int64_t)b * p.ldho2 + unit] = h;
@@ -250,12 +287,12 @@ int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a) {
                      (!a.x2 || (vec_ok(a.x2, a.ldx2) && vec_ok(a.w2, a.ldw2) && a.K2 % 4 == 0));
     if (a.B <= 16) {
         dim3 grid(xcd_grid(cdiv(a.H, 8), cdiv(a.B, 16)));
-        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, false>), grid, dim3(256), 0, stream, a);
+        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, true>), grid, dim3(NTHR), 0, stream, a);
+        else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, false>), grid, dim3(NTHR), 0, stream, a);
     } else {
         dim3 grid(xcd_grid(cdiv(a.H, 8), cdiv(a.B, 32)));
-        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, true>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, false>), grid, dim3(256), 0, stream, a);
+        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, true>), grid, dim3(NTHR), 0, stream, a);
+        else hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, false>), grid, dim3(NTHR), 0, stream, a);
     }
     S2VT_LAUNCH_CHECK("lstm_step_fwd_kernel");
     return 0;
@@ -263,7 +300,7 @@ int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a) {
 
 // ----------------------------------------------------------------------------- backward step
 template <int MT, int NT, bool VEC>
-__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepBwdArgs p) {
+__global__ __launch_bounds__(NTHR) void lstm_step_bwd_kernel(StepBwdArgs p) {
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
@@ -282,6 +319,25 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepBwdArgs p) {
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
             for (int a = 0; a < NA; ++a) acc[mi][ni][a] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // epilogue operands requested ahead of the K loop (see the forward kernel)
+    static_assert(TM * TN <= NTHR, "one epilogue element per thread");
+    const int ebl = tid / TN, eul = tid % TN;
+    const int eb = b0 + ebl, eunit = n0 + eul;
+    const bool evalid = (tid < TM * TN) && (eb < p.B) && (eunit < p.H);
+    float stv[4], cv, cpv, dcv, dhov;
+    {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float* q = evalid ? p.stash + (int64_t)eb * p.ldst + (int64_t)g * p.H + eunit : g_zero4;
+            stv[g] = *q;
+        }
+        const float* q1 = evalid ? p.c + (int64_t)eb * p.ldc + eunit : g_zero4;
+        const float* q2 = (evalid && p.c_prev) ? p.c_prev + (int64_t)eb * p.ldcp + eunit : g_zero4;
+        const float* q3 = (evalid && !p.dc_is_zero) ? p.dc + (int64_t)eb * p.lddc + eunit : g_zero4;
+        const float* q4 = (evalid && p.dh_out) ? p.dh_out + (int64_t)eb * p.lddho + eunit : g_zero4;
+        cv = *q1; cpv = *q2; dcv = *q3; dhov = *q4;
+    }
 
     if (p.dg_next) {
         const float* arow[MT * 4];
@@ -303,23 +359,16 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepBwdArgs p) {
     write_partials<MT, NT, NA>(acc, red, wave, lane);
     __syncthreads();
 
-    for (int e = tid; e < TM * TN; e += 256) {
-        const int bl = e / TN, ul = e % TN;
-        const int b = b0 + bl, unit = n0 + ul;
-        if (b >= p.B || unit >= p.H) continue;
-        float dh = read_sum<MT, NT>(red, bl, ul);
-        if (p.dh_out) dh += p.dh_out[(int64_t)b * p.lddho + unit];
-        const float* st = p.stash + (int64_t)b * p.ldst + unit;
-        const float ig = st[0], fg = st[(int64_t)p.H], gg = st[(int64_t)2 * p.H], og = st[(int64_t)3 * p.H];
-        const float c = p.c[(int64_t)b * p.ldc + unit];
-        const float cp = p.c_prev ? p.c_prev[(int64_t)b * p.ldcp + unit] : 0.f;
-        const float tc = tanhf(c);
-        float dc = dh * og * (1.0f - tc * tc);
-        if (!p.dc_is_zero) dc += p.dc[(int64_t)b * p.lddc + unit];
+    if (evalid) {
+        const int b = eb, unit = eunit;
+        const float dh = read_sum<MT, NT>(red, ebl, eul) + dhov;
+        const float ig = stv[0], fg = stv[1], gg = stv[2], og = stv[3];
+        const float tc = tanhf(cv);
+        const float dc = dh * og * (1.0f - tc * tc) + dcv;
         const float d_o = dh * tc;
         float* dg = p.dg + (int64_t)b * p.lddg_out + unit;
         dg[0] = dc * gg * ig * (1.0f - ig);
-        dg[(int64_t)p.H] = dc * cp * fg * (1.0f - fg);
+        dg[(int64_t)p.H] = dc * cpv * fg * (1.0f - fg);
         dg[(int64_t)2 * p.H] = dc * ig * (1.0f - gg * gg);
         dg[(int64_t)3 * p.H] = d_o * og * (1.0f - og);
         p.dc[(int64_t)b * p.lddc + unit] = dc * fg;
@@ -330,8 +379,8 @@ int lstm_step_bwd(hipStream_t stream, const StepBwdArgs& a) {
     S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.stash && a.c && a.dc && a.dg, "lstm_step_bwd: bad arguments");
     const bool vec = !a.dg_next || (vec_ok(a.dg_next, a.lddg) && vec_ok(a.w_hh_t, a.ldwt));
     dim3 grid(xcd_grid(cdiv(a.H, 16), cdiv(a.B, 16)));
-    if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, false>), grid, dim3(256), 0, stream, a);
+    if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, true>), grid, dim3(NTHR), 0, stream, a);
+    else hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, false>), grid, dim3(NTHR), 0, stream, a);
     S2VT_LAUNCH_CHECK("lstm_step_bwd_kernel");
     return 0;
 }
@@ -343,7 +392,7 @@ __device__ __forceinline__ uint32_t ordered_bits(float x) {
 }
 
 template <int MT, int NT, bool VEC>
-__global__ __launch_bounds__(256) void logits_argmax_kernel(LogitsArgmaxArgs p) {
+__global__ __launch_bounds__(NTHR) void logits_argmax_kernel(LogitsArgmaxArgs p) {
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
@@ -385,13 +434,14 @@ __global__ __launch_bounds__(256) void logits_argmax_kernel(LogitsArgmaxArgs p) 
     // 8 threads per batch row, TN/8 columns each; first-max (lowest index) wins ties.
     constexpr int CPT = TN / 8;
     static_assert(TM * 8 == 256, "one pass over the tile");
-    const int bl = tid >> 3, sub = tid & 7;
+    const int bl = (tid >> 3) % TM, sub = tid & 7;
     const int b = b0 + bl;
+    const bool active = tid < TM * 8;
     unsigned long long best = 0ull;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int nl = sub * CPT + j, n = n0 + nl;
-        if (b < p.B && n < p.V) {
+        if (active && b < p.B && n < p.V) {
             const float v = read_sum<MT, NT>(red, bl, nl) + (p.b_out ? p.b_out[n] : 0.f);
             const unsigned long long key =
                 ((unsigned long long)ordered_bits(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)n);
@@ -403,15 +453,15 @@ __global__ __launch_bounds__(256) void logits_argmax_kernel(LogitsArgmaxArgs p) 
         const unsigned long long o = __shfl_xor(best, off);
         best = o > best ? o : best;
     }
-    if (sub == 0 && b < p.B && best) atomicMax(&p.packed[b], best);
+    if (active && sub == 0 && b < p.B && best) atomicMax(&p.packed[b], best);
 }
 
 int logits_argmax(hipStream_t stream, const LogitsArgmaxArgs& a) {
     S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.V > 0 && a.h && a.w_out && a.packed, "logits_argmax: bad arguments");
     const bool vec = vec_ok(a.h, a.ldh) && vec_ok(a.w_out, a.ldw) && a.H % 4 == 0;
     dim3 grid(xcd_grid(cdiv(a.V, 32), cdiv(a.B, 32)));
-    if (vec) hipLaunchKernelGGL((logits_argmax_kernel<2, 2, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((logits_argmax_kernel<2, 2, false>), grid, dim3(256), 0, stream, a);
+    if (vec) hipLaunchKernelGGL((logits_argmax_kernel<2, 2, true>), grid, dim3(NTHR), 0, stream, a);
+    else hipLaunchKernelGGL((logits_argmax_kernel<2, 2, false>), grid, dim3(NTHR), 0, stream, a);
     S2VT_LAUNCH_CHECK("logits_argmax_kernel");
     return 0;
 }
