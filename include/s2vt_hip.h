@@ -103,6 +103,12 @@ int s2vt_gemm_f32(int32_t a_kmajor, int32_t b_kmajor, int32_t M, int32_t N, int3
                   const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t accumulate,
                   void* stream);
 
+/* Same contraction with caller-provided scratch (`ws`, ws_floats floats) that lets small grids split K into
+ * slices combined in a fixed order (deterministic); this is the form the whole-path drivers use. */
+int s2vt_gemm_f32_splitk(int32_t a_kmajor, int32_t b_kmajor, int32_t M, int32_t N, int32_t K, const float* A,
+                         int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                         int32_t accumulate, float* ws, size_t ws_floats, void* stream);
+
 /* feat_linear (S2VTModel.py:54): x1[l*B+b, :] = feats[b, l, :]·W^T + bias  (time-major output [L*B, H]). */
 int s2vt_feat_proj_fwd(const s2vt_dims* d, const float* feats, const float* w, const float* bias, float* x1,
                        void* stream);

@@ -263,8 +263,11 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
     if ((rc = gemm(st, false, false, 4 * H, H, T * B, w.s2, 4 * H, ID, w.h1, H, ID, g->word_w_ih + E, E + H, ID, nullptr,
                    false)))
         return rc;
-    if ((rc = gemm(st, false, false, 4 * H, E, R, w.s2 + (int64_t)L * B4H, 4 * H, ID, p->emb_w, E, gather(w.tok),
-                   g->word_w_ih, E + H, ID, nullptr, false)))
+    // dW_ih2[:, :E] = dG2[L..]^T · Emb[tok]: the embedded rows are gathered once (time-major) into w.de, which
+    // is free until the d(embedded words) GEMM below overwrites it
+    if ((rc = gather_rows_f32(st, p->emb_w, E, w.tok, R, E, w.de))) return rc;
+    if ((rc = gemm(st, false, false, 4 * H, E, R, w.s2 + (int64_t)L * B4H, 4 * H, ID, w.de, E, ID, g->word_w_ih, E + H,
+                   ID, nullptr, false)))
         return rc;
     if ((rc = colsum_f32(st, w.s2, (int64_t)T * B, 4 * H, 4 * H, w.colsum, g->word_b_ih, false))) return rc;
     S2VT_HIP(hipMemcpyAsync(g->word_b_hh, g->word_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
@@ -421,6 +424,14 @@ int s2vt_mean_ce_backward(int32_t B, int32_t Lm1, int32_t V, const float* logits
 int s2vt_gemm_f32(int32_t a_kmajor, int32_t b_kmajor, int32_t M, int32_t N, int32_t K, const float* A, int64_t lda,
                   const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t accumulate,
                   void* stream) {
+    return gemm((hipStream_t)stream, a_kmajor != 0, b_kmajor != 0, M, N, K, A, lda, ID, B, ldb, ID, C, ldc, ID, bias,
+                accumulate != 0);
+}
+
+int s2vt_gemm_f32_splitk(int32_t a_kmajor, int32_t b_kmajor, int32_t M, int32_t N, int32_t K, const float* A,
+                         int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
+                         int32_t accumulate, float* ws, size_t ws_floats, void* stream) {
+    GemmWsScope gscope(ws, ws_floats);
     return gemm((hipStream_t)stream, a_kmajor != 0, b_kmajor != 0, M, N, K, A, lda, ID, B, ldb, ID, C, ldc, ID, bias,
                 accumulate != 0);
 }

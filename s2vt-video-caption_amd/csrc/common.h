@@ -49,6 +49,15 @@ __device__ __forceinline__ int map_row(const RowMap& m, int r) {
     return r;
 }
 
+// Permutation-only row map (no gather): pure integer arithmetic, usable inside a software-pipelined loop without
+// introducing a dependent load (a gather index would make every staging load wait for the index load, and with
+// the in-order vmcnt counter, for every older prefetch as well).
+__device__ __forceinline__ int map_row_perm(const RowMap& m, int r) {
+    const int inner = m.inner ? m.inner : 1;
+    const int pr = (r % inner) * m.outer + r / inner;
+    return m.inner ? pr : r;
+}
+
 // 16 bytes of zeros in device memory: the target of redirected out-of-range loads (see load4_guard).
 static __device__ __attribute__((aligned(16))) float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};
 

@@ -24,6 +24,14 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDK = BK + 4;    // k-major image row stride (floats)
 constexpr int LDM = BM + 4;    // m-major image row stride (floats)
 constexpr int OPER_FLOATS = BM * LDK;  // 4608 >= BK*LDM = 4224
+#ifndef S2VT_GEMM_NBUF
+#define S2VT_GEMM_NBUF 1
+#endif
+#ifndef S2VT_GEMM_PF
+#define S2VT_GEMM_PF 1
+#endif
+constexpr int GPF = S2VT_GEMM_PF;      // staging register sets (tiles of global-load lookahead)
+constexpr int NBUF = S2VT_GEMM_NBUF;   // LDS images per operand (2 = double buffered, one barrier per k-tile)
 
 struct GemmArgs {
     int M, N, K;
@@ -48,6 +56,10 @@ __device__ __forceinline__ f32x4 load4_guard(const float* base, const float* row
     // then has NO consumer before the LDS staging store, so the loads stay in flight across the MFMA phase
     // (a select on the result would pull the vmcnt wait in front of the MFMAs).
     f32x4 v;
+#if defined(S2VT_GEMM_ABLATE) && S2VT_GEMM_ABLATE == 1   // timing experiment: no global traffic
+    v = f32x4{1.f, 0.f, 0.f, 0.f};
+    return v;
+#endif
     if (VEC) {
         const bool ok = (row != nullptr) && (c < limit);
         const float* q = ok ? row + c : g_zero4;
@@ -65,9 +77,7 @@ __device__ __forceinline__ f32x4 load4_guard(const float* base, const float* row
 
 template <bool A_KMAJOR, bool B_KMAJOR, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * OPER_FLOATS];
-    float* sA = smem;
-    float* sB = smem + OPER_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[NBUF * 2 * OPER_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -109,8 +119,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
         }
     }
 
-    f32x4 ra[4], rb[4];
-    auto load_tile = [&](int k0) {
+    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];   // two staging register sets: tiles kt+1 and kt+2 in flight
+    auto load_tile = [&](int k0, f32x4 (&ra)[4], f32x4 (&rb)[4]) {
         if (A_KMAJOR) {
             const int kq = k0 + (tid & 7) * 4;
 #pragma unroll
@@ -120,7 +130,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int k = k0 + (tid >> 5) + 8 * i;
-                const float* row = (k < kend) ? p.A + (int64_t)map_row(p.amap, k) * p.lda : nullptr;
+                const float* row = (k < kend) ? p.A + (int64_t)map_row_perm(p.amap, k) * p.lda : nullptr;
                 ra[i] = load4_guard<VEC>(p.A, row, mq, p.M);
             }
         }
@@ -133,12 +143,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 int k = k0 + (tid >> 5) + 8 * i;
-                const float* row = (k < kend) ? p.B + (int64_t)map_row(p.bmap, k) * p.ldb : nullptr;
+                const float* row = (k < kend) ? p.B + (int64_t)map_row_perm(p.bmap, k) * p.ldb : nullptr;
                 rb[i] = load4_guard<VEC>(p.B, row, nq, p.N);
             }
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf, const f32x4 (&ra)[4], const f32x4 (&rb)[4]) {
+        float* sA = smem + buf * 2 * OPER_FLOATS;
+        float* sB = sA + OPER_FLOATS;
         if (A_KMAJOR) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -167,12 +179,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const int nkt = (kend - kbeg + BK - 1) / BK;
-    load_tile(kbeg);
-    for (int kt = 0; kt < nkt; ++kt) {
-        store_tile();
-        __syncthreads();
-        if (kt + 1 < nkt) load_tile(kbeg + (kt + 1) * BK);
+    auto compute_tile = [&](int buf) {
+        const float* sA = smem + buf * 2 * OPER_FLOATS;
+        const float* sB = sA + OPER_FLOATS;
 #pragma unroll
         for (int c = 0; c < BK / 8; ++c) {
             f32x4 a[2], b[2];
@@ -202,9 +211,60 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
+#if defined(S2VT_GEMM_ABLATE) && S2VT_GEMM_ABLATE == 2   // timing experiment: operands read, no MFMA
+                        asm volatile("" ::"v"(a[mi][j]), "v"(b[ni][j]));
+#else
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
+#endif
         }
+    };
+
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+    if (NBUF == 1 && GPF == 1) {
+        // One LDS image, one staging register set: stage -> barrier -> request tile kt+1 -> MFMAs -> barrier.
+        // With 3-4 workgroups per CU sharing the matrix pipes, one tile of lookahead covers the load latency
+        // (80 VGPRs keep 4 workgroups resident; the two-set form below needs ~200 and halves residency).
+        load_tile(kbeg, ra0, rb0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            store_tile(0, ra0, rb0);
+            __syncthreads();
+            load_tile(kbeg + (kt + 1) * BK, ra0, rb0);       // past-the-end tiles read the zero block
+            compute_tile(0);
+            __syncthreads();
+        }
+    } else if (NBUF == 1) {
+        // One LDS image, two register sets: tile kt is staged from the set requested TWO iterations earlier;
+        // unrolled by two so both sets are statically indexed.  Best for a workgroup alone on its CU.
+        load_tile(kbeg, ra0, rb0);
+        load_tile(kbeg + BK, ra1, rb1);
+        for (int kt = 0; kt < nkt; kt += 2) {
+            store_tile(0, ra0, rb0);
+            __syncthreads();
+            load_tile(kbeg + (kt + 2) * BK, ra0, rb0);
+            compute_tile(0);
+            __syncthreads();
+            if (kt + 1 < nkt) {
+                store_tile(0, ra1, rb1);
+                __syncthreads();
+                load_tile(kbeg + (kt + 3) * BK, ra1, rb1);
+                compute_tile(0);
+                __syncthreads();
+            }
+        }
+    } else {
+        // two LDS images, ONE barrier per k-tile (kept as an experiment; measured slower than the form above)
+        load_tile(kbeg, ra0, rb0);
+        store_tile(0, ra0, rb0);
+        load_tile(kbeg + BK, ra0, rb0);
         __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            compute_tile(kt & 1);
+            if (kt + 1 < nkt) {
+                store_tile((kt + 1) & 1, ra0, rb0);
+                load_tile(kbeg + (kt + 2) * BK, ra0, rb0);
+            }
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -278,6 +338,9 @@ int gemm_f32(hipStream_t stream, bool a_kmajor, bool b_kmajor, int M, int N, int
     if (M <= 0 || N <= 0) return 0;
     S2VT_REQUIRE(K >= 0 && A && B && C, "gemm_f32: bad arguments (M=%d N=%d K=%d)", M, N, K);
     S2VT_REQUIRE(a_kmajor || !b_kmajor, "gemm_f32: A^T * B^T form is not used by the S2VT path");
+    S2VT_REQUIRE((a_kmajor || !amap.idx) && (b_kmajor || !bmap.idx),
+                 "gemm_f32: a gather index is only supported on operands whose stored rows are m / n (gather k-rows "
+                 "with gather_rows_f32 first)");
     GemmArgs p;
     p.M = M; p.N = N; p.K = K;
     p.A = A; p.lda = lda; p.amap = amap;
@@ -290,11 +353,21 @@ int gemm_f32(hipStream_t stream, bool a_kmajor, bool b_kmajor, int M, int N, int
     const int tiles = cdiv(M, BM) * cdiv(N, BN);
     // Small grids (< 2 workgroups per CU) leave the matrix pipes idle during every staging phase: split K so
     // that ~3 workgroups per CU are in flight, partial tiles to slabs, fixed-order reduce (deterministic).
+    // The grid is sized in units of 256 CUs: a workgroup count that is not close to a multiple of 256 (with at
+    // least ~3 per CU) leaves CUs idle during the last round.  Pick the smallest K split that fills >= 92 % of
+    // its last round; slices write slabs that are combined in a fixed order (deterministic).
     int nsplit = 1;
-    if (splitk_ws && tiles < 512 && K >= 8 * BK) {
-        nsplit = cdiv(768, tiles);
-        if (nsplit > 8) nsplit = 8;
-        while (nsplit > 1 && (K / nsplit < 4 * BK || (size_t)nsplit * M * N > splitk_ws_floats)) --nsplit;
+    if (splitk_ws && tiles < 1024 && K >= 8 * BK) {
+        double best_eff = 0.0;
+        for (int n = 1; n <= 8; ++n) {
+            if (n > 1 && (K / n < 4 * BK || (size_t)n * M * N > splitk_ws_floats)) break;
+            const int total = tiles * n;
+            const double rounds = total / 256.0;
+            double eff = rounds / (double)((total + 255) / 256);
+            if (total < 768) eff *= total / 768.0;          // fewer than 3 workgroups per CU: latency exposed
+            if (eff > best_eff + 0.02) { best_eff = eff; nsplit = n; }
+            if (eff >= 0.92) break;
+        }
     }
     p.ksplit = (nsplit > 1) ? cdiv(cdiv(K, nsplit), BK) * BK : (K > 0 ? K : 1);
     if (nsplit > 1) nsplit = cdiv(K, p.ksplit);

@@ -113,6 +113,27 @@ int embedding_scatter_add(hipStream_t s, const float* d_rows, int64_t rows, int 
     return 0;
 }
 
+// out[r, :] = src[idx[r], :]  (embedding rows in time-major caption order, S2VTModel.py:71)
+__global__ void gather_rows_kernel(const float* src, int64_t ld, const int32_t* idx, int64_t rows, int cols, float* out) {
+    const int64_t r = blockIdx.y;
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (r >= rows || c >= cols) return;
+    const float* s = src + (int64_t)idx[r] * ld;
+    float* o = out + r * cols;
+    if ((cols & 3) == 0 && (ld & 3) == 0) {
+        *reinterpret_cast<f32x4*>(o + c) = *reinterpret_cast<const f32x4*>(s + c);
+    } else {
+        for (int j = 0; j < 4 && c + j < cols; ++j) o[c + j] = s[c + j];
+    }
+}
+int gather_rows_f32(hipStream_t s, const float* src, int64_t ld, const int32_t* idx, int64_t rows, int cols, float* out) {
+    if (rows <= 0 || cols <= 0) return 0;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(cdiv(cols, 4), 256), (unsigned)rows), dim3(256), 0, s, src, ld, idx,
+                       rows, cols, out);
+    S2VT_LAUNCH_CHECK("gather_rows_kernel");
+    return 0;
+}
+
 // packed[step][b] -> ids[b][step] (int64, the reference's output layout S2VTModel.py:108-110)
 __global__ void unpack_tokens_kernel(const unsigned long long* packed, int steps, int B, int64_t* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
