@@ -171,41 +171,57 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- live per-kernel timing with HIP events on the launch stream (2 extra steps, not part of `value`)
-        capi.check(lib.s2vt_prof_reset(), "prof_reset")
-        capi.check(lib.s2vt_prof_enable(1), "prof_enable")
-        nprof = 2
-        for _ in range(nprof):
-            model.zero_grad(set_to_none=False)
-            probs = model(feats, targets=caps[:, :-1], mode="train")
-            l2 = crit(probs, caps, mask)
-            l2.backward()
-        torch.cuda.synchronize(dev)
-        capi.check(lib.s2vt_prof_enable(0), "prof_enable")
-        gemm_ms, gemm_n = capi.prof_read(0)
-        sf_ms, sf_n = capi.prof_read(1)
-        sb_ms, sb_n = capi.prof_read(2)
-        ce_ms, ce_n = capi.prof_read(3)
-        capi.check(lib.s2vt_prof_reset(), "prof_reset")
-        log("profiled steps done")
-        gemm_ms /= nprof; sf_ms /= nprof; sb_ms /= nprof; ce_ms /= nprof
-        gflop = gemm_flops_train(B, L, F, H, E, V) / 1e9
-        gemm_tf = gflop / gemm_ms                 # GFLOP / ms = TFLOP/s
+        # ---- live per-kernel timing with HIP events on the launch stream (extra steps, not part of `value`).
+        # Pass 1 in the timed configuration (layers pipelined on two streams: kernels of the two lanes overlap,
+        # so a launch's duration includes the share of the chip it cedes to the other lane); pass 2 with the
+        # pipeline off (s2vt_set_pipeline_block(0)): every kernel alone on the GPU.
+        def profile(nprof=2):
+            capi.check(lib.s2vt_prof_reset(), "prof_reset")
+            capi.check(lib.s2vt_prof_enable(1), "prof_enable")
+            for _ in range(nprof):
+                model.zero_grad(set_to_none=False)
+                probs = model(feats, targets=caps[:, :-1], mode="train")
+                l2 = crit(probs, caps, mask)
+                l2.backward()
+            torch.cuda.synchronize(dev)
+            capi.check(lib.s2vt_prof_enable(0), "prof_enable")
+            r = {k: capi.prof_read(i) for i, k in enumerate(("gemm", "step_fwd", "step_bwd", "ce"))}
+            capi.check(lib.s2vt_prof_reset(), "prof_reset")
+            return {k: (ms / nprof, n // nprof) for k, (ms, n) in r.items()}
+
         T = 2 * L - 1
+        gflop = gemm_flops_train(B, L, F, H, E, V) / 1e9
         pair_bytes = step_bytes_fwd(B, H, H) + step_bytes_fwd(B, H, E + H)
-        step_us = sf_ms * 1e3 / (2 * T)           # average launch of lstm_step_fwd_kernel (both layers)
-        step_gbs = (pair_bytes / 2) / (step_us * 1e-6) / 1e9
-        fam = {"gemm_f32_kernel": gemm_ms, "lstm_step_fwd_kernel": sf_ms, "lstm_step_bwd_kernel": sb_ms, "ce": ce_ms}
-        roof_gemm = {"kernel": "gemm_f32_kernel", "bound": "mfma", "achieved": round(gemm_tf, 2),
-                     "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(gemm_tf / MFMA_F32_PEAK_TF, 4),
-                     "traffic": None, "launches_per_step": gemm_n // nprof, "ms_per_step": round(gemm_ms, 3),
-                     "algorithmic_gflop_per_step": round(gflop, 1)}
-        roof_step = {"kernel": "lstm_step_fwd_kernel", "bound": "hbm", "achieved": round(step_gbs, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                     "avg_launch_us": round(step_us, 3), "launches_per_step": 2 * T,
-                     "algorithmic_bytes_per_launch": pair_bytes // 2,
-                     "note": "bytes per SURVEY.md §8(d) incl. W_ih although the x-part is hoisted into a batched GEMM; "
-                             "avg over vid+word launches, loop-bracketed events (includes launch gaps)"}
+
+        def rooflines(pr, how):
+            gemm_ms, gemm_n = pr["gemm"]
+            sf_ms = pr["step_fwd"][0]
+            gemm_tf = gflop / gemm_ms                 # GFLOP / ms = TFLOP/s
+            step_us = sf_ms * 1e3 / (2 * T)           # average launch of lstm_step_fwd_kernel (both layers)
+            step_gbs = (pair_bytes / 2) / (step_us * 1e-6) / 1e9
+            rg = {"kernel": "gemm_f32_kernel", "bound": "mfma", "achieved": round(gemm_tf, 2),
+                  "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(gemm_tf / MFMA_F32_PEAK_TF, 4),
+                  "traffic": None, "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 3),
+                  "algorithmic_gflop_per_step": round(gflop, 1), "timing": how}
+            rs = {"kernel": "lstm_step_fwd_kernel", "bound": "hbm", "achieved": round(step_gbs, 1),
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                  "avg_launch_us": round(step_us, 3), "launches_per_step": 2 * T,
+                  "algorithmic_bytes_per_launch": pair_bytes // 2, "timing": how,
+                  "note": "bytes per SURVEY.md §8(d) incl. W_ih although the x-part is hoisted into a batched GEMM; "
+                          "avg over vid+word launches, loop-bracketed events (includes launch gaps)"}
+            return rg, rs
+
+        live = profile()
+        prev_blk = lib.s2vt_set_pipeline_block(0)
+        alone = profile()
+        lib.s2vt_set_pipeline_block(prev_blk)
+        log("profiled steps done (pipeline block %d)" % prev_blk)
+        roof_gemm, roof_step = rooflines(live, "live, layers pipelined on two streams (block %d)" % prev_blk)
+        roof_gemm_alone, roof_step_alone = rooflines(alone, "pipeline off: every kernel alone on the GPU")
+        fam = {"gemm_f32_kernel": live["gemm"][0], "lstm_step_fwd_kernel": live["step_fwd"][0],
+               "lstm_step_bwd_kernel": live["step_bwd"][0], "ce": live["ce"][0]}
+        fam_alone = {"gemm_f32_kernel": alone["gemm"][0], "lstm_step_fwd_kernel": alone["step_fwd"][0],
+                     "lstm_step_bwd_kernel": alone["step_bwd"][0], "ce": alone["ce"][0]}
         dominant = max(fam, key=fam.get)
         roofline = roof_gemm if dominant == "gemm_f32_kernel" else roof_step
 
@@ -269,7 +285,9 @@ def main():
             "roofline": roofline,
             "roofline_gemm": roof_gemm,
             "roofline_lstm_step": roof_step,
+            "roofline_isolated": {"gemm": roof_gemm_alone, "lstm_step": roof_step_alone},
             "kernel_ms_per_step": {k: round(v, 3) for k, v in fam.items()},
+            "kernel_ms_per_step_isolated": {k: round(v, 3) for k, v in fam_alone.items()},
             "decode": decode,
             "cpu_baseline": cpu,
         }

@@ -145,6 +145,11 @@ int s2vt_lstm_seq_bwd(int32_t T, int32_t B, int32_t H, const float* w_hh, const 
 int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, const float* w_out, const float* b_out,
                             unsigned long long* packed, void* stream);
 
+/* Layer pipelining of the whole-path drivers: the two LSTM layers run as a software pipeline on two streams in
+ * blocks of `steps` timesteps (default 16, or env S2VT_PIPE_BLOCK); 0 runs everything on the caller's stream
+ * (kernels then never overlap: used to time kernels in isolation).  Returns the previous value. */
+int s2vt_set_pipeline_block(int32_t steps);
+
 /* ---------------------------------------------------------------- live kernel timing (bench.py)
  * When enabled, launch sites bracket kernels of one kind with hipEvents on the launch stream.
  * kinds: 0 gemm, 1 lstm_step_fwd (whole sequence loop), 2 lstm_step_bwd (whole sequence loop),

@@ -2,6 +2,7 @@
 // carving and the stream-ordered launch sequences of the S2VT train forward/backward and greedy
 // decode.  Host code only; every kernel lives in gemm/lstm/ce/misc.hip.
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -95,7 +96,7 @@ struct Carver {
 
 struct TrainWS {
     float *bsum1, *bsum2, *x1, *s1, *h1, *c1, *s2, *h2, *c2;
-    float *wt, *dh1, *dh2dec, *dx1, *de, *dc, *colsum, *gws;
+    float *wt1, *wt2, *dh1, *dh2dec, *dx1, *de, *dc1, *dc2, *colsum_a, *colsum_b, *gws_a, *gws_b;
     size_t gws_floats;
     int32_t* tok;
     int* err;
@@ -121,29 +122,91 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     w.c2 = c.take<float>(T * B * H);
     w.tok = c.take<int32_t>((L - 1) * B);
     w.err = c.take<int>(4);
-    // backward-only scratch
-    w.wt = c.take<float>(H * 4 * H);
+    // backward-only scratch (two of everything that the two concurrently running layers touch)
+    w.wt1 = c.take<float>(H * 4 * H);
+    w.wt2 = c.take<float>(H * 4 * H);
     w.dh1 = c.take<float>(T * B * H);
     w.dh2dec = c.take<float>((L - 1) * B * H);
     w.dx1 = c.take<float>(L * B * H);
     w.de = c.take<float>((L - 1) * B * E);
-    w.dc = c.take<float>(B * H);
+    w.dc1 = c.take<float>(B * H);
+    w.dc2 = c.take<float>(B * H);
     size_t cs = colsum_partial_floats((int64_t)T * B, (int)(4 * H));
     size_t cs2 = colsum_partial_floats((int64_t)(L - 1) * B, (int)V);
     size_t cs3 = colsum_partial_floats((int64_t)L * B, (int)H);
-    w.colsum = c.take<float>(cs > cs2 ? (cs > cs3 ? cs : cs3) : (cs2 > cs3 ? cs2 : cs3));
+    const size_t csm = cs > cs2 ? (cs > cs3 ? cs : cs3) : (cs2 > cs3 ? cs2 : cs3);
+    w.colsum_a = c.take<float>(csm);
+    w.colsum_b = c.take<float>(csm);
     w.gws_floats = gemm_ws_floats(d);
-    w.gws = c.take<float>(w.gws_floats);
+    w.gws_a = c.take<float>(w.gws_floats);
+    w.gws_b = c.take<float>(w.gws_floats);
     w.bytes = align_up(c.off, 256);
     return w;
 }
 
-// One LSTM layer forward over T steps (time-major buffers).
-static int seq_fwd(hipStream_t st, int T, int B, int H, float* gx_stash, int n_gx, const float* bias,
+// ------------------------------------------------------------------ two-lane execution
+// The two LSTM layers are independent except through h1: word_rnn step t needs vid_rnn step t only.  A single
+// timestep kernel cannot fill the chip's latency (launch + prologue + epilogue ~4 us of a ~12 us step), so the
+// layers run as a software pipeline on TWO streams: while lane A (the caller's stream) runs vid_rnn block k+1,
+// lane B runs the batched input GEMM and the word_rnn steps of block k (backward: mirrored).  The step kernels
+// are sized (69.6 KB LDS) so that one workgroup of each lane fits a CU.  Events order the hand-offs; nothing is
+// allocated per call (stream + events are created once per process).
+struct Lane {
+    hipStream_t s;
+    float* gws;
+    size_t gws_floats;
+    float* colsum;
+};
+
+static hipStream_t g_side = nullptr;
+static std::vector<hipEvent_t> g_events;
+static int g_pipe_block = -1;      // timesteps per pipeline block; 0 = both layers on the caller's stream
+static int pipe_block() {
+    if (g_pipe_block < 0) {
+        const char* e = getenv("S2VT_PIPE_BLOCK");
+        g_pipe_block = e ? atoi(e) : 16;
+        if (g_pipe_block < 0) g_pipe_block = 0;
+    }
+    return g_pipe_block;
+}
+static int side_stream(hipStream_t* out) {
+    if (!g_side) S2VT_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+    *out = g_side;
+    return 0;
+}
+static int get_event(size_t i, hipEvent_t* out) {
+    while (g_events.size() <= i) {
+        hipEvent_t e;
+        S2VT_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        g_events.push_back(e);
+    }
+    *out = g_events[i];
+    return 0;
+}
+// `to` waits for everything enqueued so far on `from`
+static int handoff(hipStream_t from, hipStream_t to, size_t ev_index) {
+    if (from == to) return 0;
+    hipEvent_t e;
+    int rc = get_event(ev_index, &e);
+    if (rc) return rc;
+    S2VT_HIP(hipEventRecord(e, from));
+    S2VT_HIP(hipStreamWaitEvent(to, e, 0));
+    return 0;
+}
+
+static int lgemm(const Lane& ln, bool ak, bool bk, int M, int N, int K, const float* A, int64_t lda, RowMap am,
+                 const float* B, int64_t ldb, RowMap bm, float* C, int64_t ldc, RowMap cm, const float* bias, bool acc) {
+    ProfScope ps(ln.s, K_GEMM, 1);
+    return gemm_f32(ln.s, ak, bk, M, N, K, A, lda, am, B, ldb, bm, C, ldc, cm, bias, acc, ln.gws, ln.gws_floats);
+}
+
+// LSTM layer forward over steps [t0, t1) (time-major buffers, zero initial state at t = 0).
+static int seq_fwd(hipStream_t st, int t0, int t1, int B, int H, float* gx_stash, int n_gx, const float* bias,
                    const float* w_hh, float* h_all, float* c_all, bool write_stash) {
-    ProfScope ps(st, K_STEP_FWD, T);
+    if (t1 <= t0) return 0;
+    ProfScope ps(st, K_STEP_FWD, t1 - t0);
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
-    for (int t = 0; t < T; ++t) {
+    for (int t = t0; t < t1; ++t) {
         StepFwdArgs a;
         memset(&a, 0, sizeof(a));
         a.B = B; a.H = H;
@@ -162,12 +225,13 @@ static int seq_fwd(hipStream_t st, int T, int B, int H, float* gx_stash, int n_g
     return 0;
 }
 
-// BPTT over one layer; stash_dg [T*B,4H] holds the activated gates on entry and dG on exit.
-static int seq_bwd(hipStream_t st, int T, int B, int H, const float* w_hh_t, const float* dh_out, int dh_first,
-                   const float* c_all, float* stash_dg, float* dc) {
-    ProfScope ps(st, K_STEP_BWD, T);
+// BPTT over steps t1-1 .. t0 of a T-step layer; stash_dg [T*B,4H] holds activated gates on entry, dG on exit.
+static int seq_bwd(hipStream_t st, int T, int t0, int t1, int B, int H, const float* w_hh_t, const float* dh_out,
+                   int dh_first, const float* c_all, float* stash_dg, float* dc) {
+    if (t1 <= t0) return 0;
+    ProfScope ps(st, K_STEP_BWD, t1 - t0);
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
-    for (int t = T - 1; t >= 0; --t) {
+    for (int t = t1 - 1; t >= t0; --t) {
         StepBwdArgs a;
         memset(&a, 0, sizeof(a));
         a.B = B; a.H = H;
@@ -184,6 +248,16 @@ static int seq_bwd(hipStream_t st, int T, int B, int H, const float* w_hh_t, con
         if (rc) return rc;
     }
     return 0;
+}
+
+// Block boundaries over [0, T) with L (first caption step) forced to be a boundary.
+static std::vector<int> pipe_bounds(int T, int L, int blk) {
+    std::vector<int> b;
+    if (blk <= 0) { b.push_back(0); b.push_back(L); b.push_back(T); return b; }
+    for (int t = 0; t < L; t += blk) b.push_back(t);
+    for (int t = L; t < T; t += blk) b.push_back(t);
+    b.push_back(T);
+    return b;
 }
 
 }  // namespace s2vt
@@ -206,34 +280,48 @@ int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* fe
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
-    GemmWsScope gscope(w.gws, w.gws_floats);
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
-    const int64_t BH = (int64_t)B * H;
+    const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
+    const int blk = pipe_block();
+    hipStream_t sx = st;
     int rc;
+    if (blk > 0 && (rc = side_stream(&sx))) return rc;
+    const Lane la{st, w.gws_a, w.gws_floats, w.colsum_a};     // vid_rnn lane (caller's stream)
+    const Lane lb{sx, w.gws_b, w.gws_floats, w.colsum_b};     // word_rnn lane
+    size_t ev = 0;
     if ((rc = add_vectors(st, p->vid_b_ih, p->vid_b_hh, w.bsum1, 4 * H))) return rc;
     if ((rc = add_vectors(st, p->word_b_ih, p->word_b_hh, w.bsum2, 4 * H))) return rc;
     if ((rc = fill_zero(st, w.err, 4 * sizeof(int)))) return rc;
     if ((rc = targets_to_time_major(st, targets, B, L - 1, targets_ld, V, w.tok, w.err))) return rc;
-    // x1 (time-major) = feats·W_f^T + b_f                                     S2VTModel.py:54
-    if ((rc = gemm(st, true, true, B * L, H, F, feats, F, ID, p->feat_w, F, ID, w.x1, H, perm(L, B), p->feat_b, false)))
+    if ((rc = handoff(st, sx, ev++))) return rc;
+    // lane B, independent of vid_rnn: embedded-word half of the word_rnn gate input (+ both biases) for the
+    // L-1 caption steps                                                             S2VTModel.py:71-75
+    if ((rc = lgemm(lb, true, true, (L - 1) * B, 4 * H, E, p->emb_w, E, gather(w.tok), p->word_w_ih, E + H, ID,
+                    w.s2 + (int64_t)L * B4H, 4 * H, ID, w.bsum2, false)))
         return rc;
-    // gx1 = x1·W_ih1^T + (b_ih1 + b_hh1) for the L real frames                 S2VTModel.py:64-67
-    if ((rc = gemm(st, true, true, L * B, 4 * H, H, w.x1, H, ID, p->vid_w_ih, H, ID, w.s1, 4 * H, ID, w.bsum1, false)))
+    // lane A: x1 (time-major) = feats·W_f^T + b_f ; gx1 = x1·W_ih1^T + biases       S2VTModel.py:54, 64-67
+    if ((rc = lgemm(la, true, true, B * L, H, F, feats, F, ID, p->feat_w, F, ID, w.x1, H, perm(L, B), p->feat_b, false)))
         return rc;
-    if ((rc = seq_fwd(st, T, B, H, w.s1, L, w.bsum1, p->vid_w_hh, w.h1, w.c1, true))) return rc;
-    // gx2 = [embed | h1]·W_ih2^T + biases: vid_out half for all T steps, embed half for steps >= L   :71-77
-    if ((rc = gemm(st, true, true, T * B, 4 * H, H, w.h1, H, ID, p->word_w_ih + E, E + H, ID, w.s2, 4 * H, ID, w.bsum2,
-                   false)))
+    if ((rc = lgemm(la, true, true, L * B, 4 * H, H, w.x1, H, ID, p->vid_w_ih, H, ID, w.s1, 4 * H, ID, w.bsum1, false)))
         return rc;
-    if ((rc = gemm(st, true, true, (L - 1) * B, 4 * H, E, p->emb_w, E, gather(w.tok), p->word_w_ih, E + H, ID,
-                   w.s2 + (int64_t)L * B * 4 * H, 4 * H, ID, nullptr, true)))
+    const std::vector<int> bd = pipe_bounds(T, L, blk);
+    for (size_t k = 0; k + 1 < bd.size(); ++k) {
+        const int t0 = bd[k], t1 = bd[k + 1];
+        if ((rc = seq_fwd(st, t0, t1, B, H, w.s1, L, w.bsum1, p->vid_w_hh, w.h1, w.c1, true))) return rc;
+        if ((rc = handoff(st, sx, ev++))) return rc;
+        // vid_out half of the word_rnn gate input for this block: rows < L get the biases here, rows >= L
+        // accumulate onto the embedded-word half                                    S2VTModel.py:75-77
+        const bool cap = t0 >= L;
+        if ((rc = lgemm(lb, true, true, (t1 - t0) * B, 4 * H, H, w.h1 + t0 * BH, H, ID, p->word_w_ih + E, E + H, ID,
+                        w.s2 + t0 * B4H, 4 * H, ID, cap ? nullptr : w.bsum2, cap)))
+            return rc;
+        if ((rc = seq_fwd(sx, t0, t1, B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, true))) return rc;
+    }
+    // logits[b, j, :] = h2[L + j]·W_o^T + b_o                                        S2VTModel.py:78-80
+    if ((rc = lgemm(lb, true, true, (L - 1) * B, V, H, w.h2 + L * BH, H, ID, p->out_w, H, ID, logits, V, perm(B, L - 1),
+                    p->out_b, false)))
         return rc;
-    if ((rc = seq_fwd(st, T, B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, true))) return rc;
-    // logits[b, j, :] = h2[L + j]·W_o^T + b_o                                   S2VTModel.py:78-80
-    if ((rc = gemm(st, true, true, (L - 1) * B, V, H, w.h2 + L * BH, H, ID, p->out_w, H, ID, logits, V, perm(B, L - 1),
-                   p->out_b, false)))
-        return rc;
-    return 0;
+    return handoff(sx, st, ev++);
 }
 
 int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
@@ -242,65 +330,76 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
-    GemmWsScope gscope(w.gws, w.gws_floats);
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
     const int R = (L - 1) * B;
+    const int blk = pipe_block();
+    hipStream_t sx = st;
     int rc;
-    // ---- out_linear                                                        (autograd of S2VTModel.py:80)
-    if ((rc = gemm(st, true, false, R, H, V, dlogits, V, ID, p->out_w, H, ID, w.dh2dec, H, perm(L - 1, B), nullptr, false)))
+    if (blk > 0 && (rc = side_stream(&sx))) return rc;
+    const Lane la{st, w.gws_a, w.gws_floats, w.colsum_a};     // word_rnn lane (caller's stream)
+    const Lane lb{sx, w.gws_b, w.gws_floats, w.colsum_b};     // vid_rnn lane
+    size_t ev = 0;
+    if ((rc = handoff(st, sx, ev++))) return rc;
+    // lane A: gradient into the decode-step hidden states, then word_rnn BPTT       (autograd of S2VTModel.py:80, :77)
+    if ((rc = lgemm(la, true, false, R, H, V, dlogits, V, ID, p->out_w, H, ID, w.dh2dec, H, perm(L - 1, B), nullptr, false)))
         return rc;
-    if ((rc = gemm(st, false, false, V, H, R, dlogits, V, ID, w.h2 + L * BH, H, perm(L - 1, B), g->out_w, H, ID, nullptr,
-                   false)))
+    if ((rc = transpose_f32(st, p->word_w_hh, 4 * H, H, w.wt2))) return rc;
+    // lane B meanwhile: out_linear weight/bias gradients (need only dlogits and h2) and W_hh1^T
+    if ((rc = lgemm(lb, false, false, V, H, R, dlogits, V, ID, w.h2 + L * BH, H, perm(L - 1, B), g->out_w, H, ID, nullptr,
+                    false)))
         return rc;
-    if ((rc = colsum_f32(st, dlogits, R, V, V, w.colsum, g->out_b, false))) return rc;
-    // ---- word_rnn BPTT                                                     (autograd of :77)
-    if ((rc = transpose_f32(st, p->word_w_hh, 4 * H, H, w.wt))) return rc;
-    if ((rc = seq_bwd(st, T, B, H, w.wt, w.dh2dec, L, w.c2, w.s2, w.dc))) return rc;
-    if ((rc = gemm(st, false, false, 4 * H, H, (T - 1) * B, w.s2 + B4H, 4 * H, ID, w.h2, H, ID, g->word_w_hh, H, ID,
-                   nullptr, false)))
+    if ((rc = colsum_f32(sx, dlogits, R, V, V, lb.colsum, g->out_b, false))) return rc;
+    if ((rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
+    const std::vector<int> bd = pipe_bounds(T, L, blk);
+    for (size_t k = bd.size() - 1; k >= 1; --k) {
+        const int t0 = bd[k - 1], t1 = bd[k];
+        if ((rc = seq_bwd(st, T, t0, t1, B, H, w.wt2, w.dh2dec, L, w.c2, w.s2, w.dc2))) return rc;
+        // gradient into vid_out for this block: dh1 = dG2·W_v                        (autograd of :75)
+        if ((rc = lgemm(la, true, false, (t1 - t0) * B, H, 4 * H, w.s2 + t0 * B4H, 4 * H, ID, p->word_w_ih + E, E + H, ID,
+                        w.dh1 + t0 * BH, H, ID, nullptr, false)))
+            return rc;
+        if ((rc = handoff(st, sx, ev++))) return rc;
+        if ((rc = seq_bwd(sx, T, t0, t1, B, H, w.wt1, w.dh1, 0, w.c1, w.s1, w.dc1))) return rc;   // (autograd of :67)
+    }
+    // lane A: word_rnn parameter gradients + embedding gradient (run while lane B finishes the vid_rnn BPTT)
+    if ((rc = lgemm(la, false, false, 4 * H, H, (T - 1) * B, w.s2 + B4H, 4 * H, ID, w.h2, H, ID, g->word_w_hh, H, ID,
+                    nullptr, false)))
         return rc;
-    if ((rc = gemm(st, false, false, 4 * H, H, T * B, w.s2, 4 * H, ID, w.h1, H, ID, g->word_w_ih + E, E + H, ID, nullptr,
-                   false)))
+    if ((rc = lgemm(la, false, false, 4 * H, H, T * B, w.s2, 4 * H, ID, w.h1, H, ID, g->word_w_ih + E, E + H, ID, nullptr,
+                    false)))
         return rc;
     // dW_ih2[:, :E] = dG2[L..]^T · Emb[tok]: the embedded rows are gathered once (time-major) into w.de, which
     // is free until the d(embedded words) GEMM below overwrites it
     if ((rc = gather_rows_f32(st, p->emb_w, E, w.tok, R, E, w.de))) return rc;
-    if ((rc = gemm(st, false, false, 4 * H, E, R, w.s2 + (int64_t)L * B4H, 4 * H, ID, w.de, E, ID, g->word_w_ih, E + H,
-                   ID, nullptr, false)))
+    if ((rc = lgemm(la, false, false, 4 * H, E, R, w.s2 + (int64_t)L * B4H, 4 * H, ID, w.de, E, ID, g->word_w_ih, E + H,
+                    ID, nullptr, false)))
         return rc;
-    if ((rc = colsum_f32(st, w.s2, (int64_t)T * B, 4 * H, 4 * H, w.colsum, g->word_b_ih, false))) return rc;
+    if ((rc = colsum_f32(st, w.s2, (int64_t)T * B, 4 * H, 4 * H, la.colsum, g->word_b_ih, false))) return rc;
     S2VT_HIP(hipMemcpyAsync(g->word_b_hh, g->word_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
-    // gradient into vid_out (dh1) and into the embedded words                (autograd of :71-75)
-    if ((rc = gemm(st, true, false, T * B, H, 4 * H, w.s2, 4 * H, ID, p->word_w_ih + E, E + H, ID, w.dh1, H, ID, nullptr,
-                   false)))
-        return rc;
-    if ((rc = gemm(st, true, false, R, E, 4 * H, w.s2 + (int64_t)L * B4H, 4 * H, ID, p->word_w_ih, E + H, ID, w.de, E, ID,
-                   nullptr, false)))
+    if ((rc = lgemm(la, true, false, R, E, 4 * H, w.s2 + (int64_t)L * B4H, 4 * H, ID, p->word_w_ih, E + H, ID, w.de, E, ID,
+                    nullptr, false)))
         return rc;
     if ((rc = fill_zero(st, g->emb_w, sizeof(float) * (size_t)V * E))) return rc;
     if ((rc = embedding_scatter_add(st, w.de, R, E, w.tok, g->emb_w))) return rc;
-    // ---- vid_rnn BPTT                                                      (autograd of :67)
-    if ((rc = transpose_f32(st, p->vid_w_hh, 4 * H, H, w.wt))) return rc;
-    if ((rc = seq_bwd(st, T, B, H, w.wt, w.dh1, 0, w.c1, w.s1, w.dc))) return rc;
-    if ((rc = gemm(st, false, false, 4 * H, H, (T - 1) * B, w.s1 + B4H, 4 * H, ID, w.h1, H, ID, g->vid_w_hh, H, ID,
-                   nullptr, false)))
+    // lane B: vid_rnn and feat_linear parameter gradients                           (autograd of :67, :54)
+    if ((rc = lgemm(lb, false, false, 4 * H, H, (T - 1) * B, w.s1 + B4H, 4 * H, ID, w.h1, H, ID, g->vid_w_hh, H, ID,
+                    nullptr, false)))
         return rc;
-    if ((rc = gemm(st, false, false, 4 * H, H, L * B, w.s1, 4 * H, ID, w.x1, H, ID, g->vid_w_ih, H, ID, nullptr, false)))
+    if ((rc = lgemm(lb, false, false, 4 * H, H, L * B, w.s1, 4 * H, ID, w.x1, H, ID, g->vid_w_ih, H, ID, nullptr, false)))
         return rc;
-    if ((rc = colsum_f32(st, w.s1, (int64_t)T * B, 4 * H, 4 * H, w.colsum, g->vid_b_ih, false))) return rc;
-    S2VT_HIP(hipMemcpyAsync(g->vid_b_hh, g->vid_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
-    // ---- feat_linear                                                       (autograd of :54)
-    if ((rc = gemm(st, true, false, L * B, H, 4 * H, w.s1, 4 * H, ID, p->vid_w_ih, H, ID, w.dx1, H, ID, nullptr, false)))
+    if ((rc = colsum_f32(sx, w.s1, (int64_t)T * B, 4 * H, 4 * H, lb.colsum, g->vid_b_ih, false))) return rc;
+    S2VT_HIP(hipMemcpyAsync(g->vid_b_hh, g->vid_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, sx));
+    if ((rc = lgemm(lb, true, false, L * B, H, 4 * H, w.s1, 4 * H, ID, p->vid_w_ih, H, ID, w.dx1, H, ID, nullptr, false)))
         return rc;
-    if ((rc = gemm(st, false, false, H, F, L * B, w.dx1, H, ID, feats, F, perm(B, L), g->feat_w, F, ID, nullptr, false)))
+    if ((rc = lgemm(lb, false, false, H, F, L * B, w.dx1, H, ID, feats, F, perm(B, L), g->feat_w, F, ID, nullptr, false)))
         return rc;
-    if ((rc = colsum_f32(st, w.dx1, (int64_t)L * B, H, H, w.colsum, g->feat_b, false))) return rc;
+    if ((rc = colsum_f32(sx, w.dx1, (int64_t)L * B, H, H, lb.colsum, g->feat_b, false))) return rc;
     if (dfeats) {
-        if ((rc = gemm(st, true, false, L * B, F, H, w.dx1, H, ID, p->feat_w, F, ID, dfeats, F, perm(B, L), nullptr, false)))
+        if ((rc = lgemm(lb, true, false, L * B, F, H, w.dx1, H, ID, p->feat_w, F, ID, dfeats, F, perm(B, L), nullptr, false)))
             return rc;
     }
-    return 0;
+    return handoff(sx, st, ev++);
 }
 
 // ------------------------------------------------------------------ greedy decode
@@ -500,8 +599,8 @@ int s2vt_lstm_seq_fwd(int32_t T, int32_t B, int32_t H, const float* gx, int32_t 
     S2VT_REQUIRE(stash == nullptr || stash == gx || n_gx == 0,
                  "s2vt_lstm_seq_fwd: stash must alias gx (in-place) or gx must be absent");
     hipStream_t st = (hipStream_t)stream;
-    if (stash) return seq_fwd(st, T, B, H, stash, n_gx, bias, w_hh, h_all, c_all, true);
-    return seq_fwd(st, T, B, H, const_cast<float*>(gx), n_gx, bias, w_hh, h_all, c_all, false);
+    if (stash) return seq_fwd(st, 0, T, B, H, stash, n_gx, bias, w_hh, h_all, c_all, true);
+    return seq_fwd(st, 0, T, B, H, const_cast<float*>(gx), n_gx, bias, w_hh, h_all, c_all, false);
 }
 
 int s2vt_lstm_seq_bwd(int32_t T, int32_t B, int32_t H, const float* w_hh, const float* dh_out, int32_t dh_first,
@@ -510,7 +609,7 @@ int s2vt_lstm_seq_bwd(int32_t T, int32_t B, int32_t H, const float* w_hh, const 
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if ((rc = transpose_f32(st, w_hh, 4 * H, H, w_hh_t))) return rc;
-    return seq_bwd(st, T, B, H, w_hh_t, dh_out, dh_first, c_all, stash_dg, dc);
+    return seq_bwd(st, T, 0, T, B, H, w_hh_t, dh_out, dh_first, c_all, stash_dg, dc);
 }
 
 int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, const float* w_out, const float* b_out,
@@ -520,6 +619,12 @@ int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, con
     la.packed = packed;
     ProfScope ps((hipStream_t)stream, K_ARGMAX, 1);
     return logits_argmax((hipStream_t)stream, la);
+}
+
+int s2vt_set_pipeline_block(int32_t steps) {
+    const int prev = pipe_block();
+    g_pipe_block = steps < 0 ? 0 : steps;
+    return prev;
 }
 
 // ------------------------------------------------------------------ live timing

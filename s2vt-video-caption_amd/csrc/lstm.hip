@@ -22,14 +22,19 @@ namespace s2vt {
 
 constexpr int KC = 64;       // k chunk per wave iteration
 constexpr int SLD = 68;      // LDS row stride in floats
-#ifndef S2VT_NWAVE
-#define S2VT_NWAVE 8
+#ifndef S2VT_NWAVE_FWD
+#define S2VT_NWAVE_FWD 4
+#endif
+#ifndef S2VT_NWAVE_BWD
+#define S2VT_NWAVE_BWD 8
 #endif
 #ifndef S2VT_PF
 #define S2VT_PF 2
 #endif
-constexpr int NWAVE = S2VT_NWAVE;      // waves per workgroup = K-split factor inside the workgroup
-constexpr int NTHR = NWAVE * 64;
+// waves per workgroup = K-split factor inside the workgroup.  Both choices keep the LDS footprint at 69.6 KB so
+// that two workgroups (e.g. a vid_rnn step and a word_rnn step launched on two streams) fit one CU.
+constexpr int NW_FWD = S2VT_NWAVE_FWD;
+constexpr int NW_BWD = S2VT_NWAVE_BWD;
 constexpr int PF = S2VT_PF;            // staging chunks in flight per wave (register prefetch depth)
 
 // Branch-free guarded 4-float load (see gemm.hip load4_guard): out-of-range accesses read a safe address and
@@ -61,7 +66,7 @@ __device__ __forceinline__ f32x4 ld4(const float* base, const float* row, int c,
 
 // acc[mi][ni][a] += A[16*MT rows, 0:K] · B[16*NT rows, 0:K]^T over this wave's chunks.
 // arow/brow: per-lane row pointers for rows (lane/16 + 4 i); sA/sB: wave-private LDS images.
-template <int MT, int NT, int NA, bool VEC>
+template <int MT, int NT, int NA, bool VEC, int NWAVE>
 __device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const float* abase, const float* bbase,
                                              const float* const (&arow)[MT * 4], const float* const (&brow)[NT * 4],
                                              int K, float* sA, float* sB, int wave, int lane) {
@@ -145,7 +150,7 @@ __device__ __forceinline__ void write_partials(const f32x4 (&acc)[MT][NT][NA], f
             }
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int NWAVE>
 __device__ __forceinline__ float read_sum(const float* red, int row, int col) {
     constexpr int TM = 16 * MT, RLD = 16 * NT + 1;
     float s = red[row * RLD + col];
@@ -173,8 +178,9 @@ static inline bool vec_ok(const void* ptr, int64_t ld) {
 
 // ------------------------------------------------------------------------------ forward step
 template <int MT, int NT, bool VEC>
-__global__ __launch_bounds__(NTHR) void lstm_step_fwd_kernel(StepFwdArgs p) {
+__global__ __launch_bounds__(NW_FWD * 64) void lstm_step_fwd_kernel(StepFwdArgs p) {
     constexpr int TM = 16 * MT, TN = 16 * NT, UN = TN / 4;
+    constexpr int NWAVE = NW_FWD, NTHR = NWAVE * 64;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(NTHR) void lstm_step_fwd_kernel(StepFwdArgs p) {
             const int r = lrow + 4 * i, g = r / UN, u = u0 + r % UN;
             brow[i] = (u < p.H) ? p.w_hh + ((int64_t)g * p.H + u) * p.ldw : nullptr;
         }
-        wave_gemm_nt<MT, NT, NA, VEC>(acc, p.h_prev, p.w_hh, arow, brow, p.H, sA, sB, wave, lane);
+        wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.h_prev, p.w_hh, arow, brow, p.H, sA, sB, wave, lane);
     }
     if (p.x2) {
         const float* arow[MT * 4];
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(NTHR) void lstm_step_fwd_kernel(StepFwdArgs p) {
             const int r = lrow + 4 * i, g = r / UN, u = u0 + r % UN;
             brow[i] = (u < p.H) ? p.w2 + ((int64_t)g * p.H + u) * p.ldw2 : nullptr;
         }
-        wave_gemm_nt<MT, NT, NA, VEC>(acc, p.x2, p.w2, arow, brow, p.K2, sA, sB, wave, lane);
+        wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.x2, p.w2, arow, brow, p.K2, sA, sB, wave, lane);
     }
 
     __syncthreads();
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(NTHR) void lstm_step_fwd_kernel(StepFwdArgs p) {
         const int bl = ebl, u = eu, b = eb, unit = eunit;
         float pre[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pre[g] = read_sum<MT, NT>(red, bl, g * UN + u) + gxv[g];
+        for (int g = 0; g < 4; ++g) pre[g] = read_sum<MT, NT, NWAVE>(red, bl, g * UN + u) + gxv[g];
         const float ig = 1.0f / (1.0f + expf(-pre[0]));
         const float fg = 1.0f / (1.0f + expf(-pre[1]));
         const float gg = tanhf(pre[2]);
@@ -287,12 +293,12 @@ int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a) {
                      (!a.x2 || (vec_ok(a.x2, a.ldx2) && vec_ok(a.w2, a.ldw2) && a.K2 % 4 == 0));
     if (a.B <= 16) {
         dim3 grid(xcd_grid(cdiv(a.H, 8), cdiv(a.B, 16)));
-        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, true>), grid, dim3(NTHR), 0, stream, a);
-        else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, false>), grid, dim3(NTHR), 0, stream, a);
+        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, true>), grid, dim3(NW_FWD * 64), 0, stream, a);
+        else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, false>), grid, dim3(NW_FWD * 64), 0, stream, a);
     } else {
         dim3 grid(xcd_grid(cdiv(a.H, 8), cdiv(a.B, 32)));
-        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, true>), grid, dim3(NTHR), 0, stream, a);
-        else hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, false>), grid, dim3(NTHR), 0, stream, a);
+        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, true>), grid, dim3(NW_FWD * 64), 0, stream, a);
+        else hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, false>), grid, dim3(NW_FWD * 64), 0, stream, a);
     }
     S2VT_LAUNCH_CHECK("lstm_step_fwd_kernel");
     return 0;
@@ -300,8 +306,9 @@ int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a) {
 
 // ----------------------------------------------------------------------------- backward step
 template <int MT, int NT, bool VEC>
-__global__ __launch_bounds__(NTHR) void lstm_step_bwd_kernel(StepBwdArgs p) {
+__global__ __launch_bounds__(NW_BWD * 64) void lstm_step_bwd_kernel(StepBwdArgs p) {
     constexpr int TM = 16 * MT, TN = 16 * NT;
+    constexpr int NWAVE = NW_BWD, NTHR = NWAVE * 64;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -352,7 +359,7 @@ __global__ __launch_bounds__(NTHR) void lstm_step_bwd_kernel(StepBwdArgs p) {
             const int n = n0 + lrow + 4 * i;
             brow[i] = (n < p.H) ? p.w_hh_t + (int64_t)n * p.ldwt : nullptr;
         }
-        wave_gemm_nt<MT, NT, NA, VEC>(acc, p.dg_next, p.w_hh_t, arow, brow, 4 * p.H, sA, sB, wave, lane);
+        wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.dg_next, p.w_hh_t, arow, brow, 4 * p.H, sA, sB, wave, lane);
     }
     __syncthreads();
     float* red = smem;
@@ -361,7 +368,7 @@ __global__ __launch_bounds__(NTHR) void lstm_step_bwd_kernel(StepBwdArgs p) {
 
     if (evalid) {
         const int b = eb, unit = eunit;
-        const float dh = read_sum<MT, NT>(red, ebl, eul) + dhov;
+        const float dh = read_sum<MT, NT, NWAVE>(red, ebl, eul) + dhov;
         const float ig = stv[0], fg = stv[1], gg = stv[2], og = stv[3];
         const float tc = tanhf(cv);
         const float dc = dh * og * (1.0f - tc * tc) + dcv;
@@ -379,8 +386,8 @@ int lstm_step_bwd(hipStream_t stream, const StepBwdArgs& a) {
     S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.stash && a.c && a.dc && a.dg, "lstm_step_bwd: bad arguments");
     const bool vec = !a.dg_next || (vec_ok(a.dg_next, a.lddg) && vec_ok(a.w_hh_t, a.ldwt));
     dim3 grid(xcd_grid(cdiv(a.H, 16), cdiv(a.B, 16)));
-    if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, true>), grid, dim3(NTHR), 0, stream, a);
-    else hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, false>), grid, dim3(NTHR), 0, stream, a);
+    if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, true>), grid, dim3(NW_BWD * 64), 0, stream, a);
+    else hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, false>), grid, dim3(NW_BWD * 64), 0, stream, a);
     S2VT_LAUNCH_CHECK("lstm_step_bwd_kernel");
     return 0;
 }
@@ -392,8 +399,9 @@ __device__ __forceinline__ uint32_t ordered_bits(float x) {
 }
 
 template <int MT, int NT, bool VEC>
-__global__ __launch_bounds__(NTHR) void logits_argmax_kernel(LogitsArgmaxArgs p) {
+__global__ __launch_bounds__(NW_FWD * 64) void logits_argmax_kernel(LogitsArgmaxArgs p) {
     constexpr int TM = 16 * MT, TN = 16 * NT;
+    constexpr int NWAVE = NW_FWD, NTHR = NWAVE * 64;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -424,7 +432,7 @@ __global__ __launch_bounds__(NTHR) void logits_argmax_kernel(LogitsArgmaxArgs p)
             const int n = n0 + lrow + 4 * i;
             brow[i] = (n < p.V) ? p.w_out + (int64_t)n * p.ldw : nullptr;
         }
-        wave_gemm_nt<MT, NT, NA, VEC>(acc, p.h, p.w_out, arow, brow, p.H, sA, sB, wave, lane);
+        wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.h, p.w_out, arow, brow, p.H, sA, sB, wave, lane);
     }
     __syncthreads();
     float* red = smem;
@@ -442,7 +450,7 @@ __global__ __launch_bounds__(NTHR) void logits_argmax_kernel(LogitsArgmaxArgs p)
     for (int j = 0; j < CPT; ++j) {
         const int nl = sub * CPT + j, n = n0 + nl;
         if (active && b < p.B && n < p.V) {
-            const float v = read_sum<MT, NT>(red, bl, nl) + (p.b_out ? p.b_out[n] : 0.f);
+            const float v = read_sum<MT, NT, NWAVE>(red, bl, nl) + (p.b_out ? p.b_out[n] : 0.f);
             const unsigned long long key =
                 ((unsigned long long)ordered_bits(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)n);
             best = key > best ? key : best;
@@ -460,8 +468,8 @@ int logits_argmax(hipStream_t stream, const LogitsArgmaxArgs& a) {
     S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.V > 0 && a.h && a.w_out && a.packed, "logits_argmax: bad arguments");
     const bool vec = vec_ok(a.h, a.ldh) && vec_ok(a.w_out, a.ldw) && a.H % 4 == 0;
     dim3 grid(xcd_grid(cdiv(a.V, 32), cdiv(a.B, 32)));
-    if (vec) hipLaunchKernelGGL((logits_argmax_kernel<2, 2, true>), grid, dim3(NTHR), 0, stream, a);
-    else hipLaunchKernelGGL((logits_argmax_kernel<2, 2, false>), grid, dim3(NTHR), 0, stream, a);
+    if (vec) hipLaunchKernelGGL((logits_argmax_kernel<2, 2, true>), grid, dim3(NW_FWD * 64), 0, stream, a);
+    else hipLaunchKernelGGL((logits_argmax_kernel<2, 2, false>), grid, dim3(NW_FWD * 64), 0, stream, a);
     S2VT_LAUNCH_CHECK("logits_argmax_kernel");
     return 0;
 }
