@@ -109,6 +109,20 @@ int s2vt_gemm_f32_splitk(int32_t a_kmajor, int32_t b_kmajor, int32_t M, int32_t 
                          int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
                          int32_t accumulate, float* ws, size_t ws_floats, void* stream);
 
+/* Split-precision path (gemm_bf16.hip).  An fp32 matrix [rows][cols] is rewritten as `nplanes` (1 or 3) bf16 planes
+ * p0+p1+p2 = x (24 mantissa bits) of a k-major GEMM operand in the PACKED layout
+ *   element (row r, k, plane pl) at r*ldo + (k/32)*(32*nplanes) + pl*32 + k%32,  ldo >= nplanes*kpad, kpad % 32 == 0,
+ * zero-filled beyond the data.  transpose = 0: operand rows = input rows, k = input columns; transpose = 1: operand
+ * rows = input columns (out_rows_pad >= cols), k = input rows (kpad >= rows). */
+int s2vt_split_planes(int32_t nplanes, int32_t transpose, const float* in, int64_t ld, int32_t rows, int32_t cols,
+                      uint16_t* out, int64_t ldo, int32_t kpad, int32_t out_rows_pad, void* stream);
+/* C[M,N] (+)= A[M,K]·B[N,K]^T (+bias) from packed bf16 planes on the bf16 matrix cores, fp32 accumulate; K = kpad.
+ * nplanes = 3 sums the six leading plane products (fp32-equivalent, ~2^-23 relative); nplanes = 1 is a plain bf16
+ * GEMM. */
+int s2vt_gemm_bf16_nt(int32_t nplanes, int32_t M, int32_t N, int32_t K, const uint16_t* A, int64_t lda, const uint16_t* B,
+                      int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t accumulate, float* ws,
+                      size_t ws_floats, void* stream);
+
 /* feat_linear (S2VTModel.py:54): x1[l*B+b, :] = feats[b, l, :]·W^T + bias  (time-major output [L*B, H]). */
 int s2vt_feat_proj_fwd(const s2vt_dims* d, const float* feats, const float* w, const float* bias, float* x1,
                        void* stream);

@@ -52,6 +52,10 @@ SIGNATURES = {
                                 c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
     "s2vt_gemm_f32_splitk": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64,
                                        c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "s2vt_split_planes": (c_int32, [c_int32, c_int32, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int64, c_int32,
+                                    c_int32, c_void_p]),
+    "s2vt_gemm_bf16_nt": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                    c_int64, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "s2vt_feat_proj_fwd": (c_int32, [POINTER(Dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "s2vt_feat_proj_bwd": (c_int32, [POINTER(Dims), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),

@@ -535,6 +535,19 @@ int s2vt_gemm_f32_splitk(int32_t a_kmajor, int32_t b_kmajor, int32_t M, int32_t 
                 accumulate != 0);
 }
 
+int s2vt_split_planes(int32_t nplanes, int32_t transpose, const float* in, int64_t ld, int32_t rows, int32_t cols,
+                      uint16_t* out, int64_t ldo, int32_t kpad, int32_t out_rows_pad, void* stream) {
+    return split_planes((hipStream_t)stream, nplanes, transpose != 0, in, ld, ID, rows, cols, out, ldo, kpad, out_rows_pad);
+}
+
+int s2vt_gemm_bf16_nt(int32_t nplanes, int32_t M, int32_t N, int32_t K, const uint16_t* A, int64_t lda, const uint16_t* B,
+                      int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t accumulate, float* ws,
+                      size_t ws_floats, void* stream) {
+    ProfScope ps((hipStream_t)stream, K_GEMM, 1);
+    return gemm_bf16_nt((hipStream_t)stream, nplanes, M, N, K, A, lda, B, ldb, C, ldc, ID, bias, accumulate != 0, ws,
+                        ws_floats);
+}
+
 int s2vt_feat_proj_fwd(const s2vt_dims* d, const float* feats, const float* w, const float* bias, float* x1,
                        void* stream) {
     S2VT_REQUIRE(dims_ok(d) && feats && w && x1, "s2vt_feat_proj_fwd: null/invalid argument");

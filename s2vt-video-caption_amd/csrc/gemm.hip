@@ -331,6 +331,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* slabs, 
     }
 }
 
+int splitk_reduce(hipStream_t stream, const float* slabs, int nsplit, int M, int N, float* C, int64_t ldc, RowMap cmap,
+                  const float* bias, bool accumulate) {
+    const int64_t nq = (int64_t)M * ((N + 3) / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, slabs, nsplit, M,
+                       N, C, ldc, cmap, bias, accumulate ? 1 : 0);
+    S2VT_LAUNCH_CHECK("splitk_reduce_kernel");
+    return 0;
+}
+
 int gemm_f32(hipStream_t stream, bool a_kmajor, bool b_kmajor, int M, int N, int K,
              const float* A, int64_t lda, RowMap amap, const float* B, int64_t ldb, RowMap bmap,
              float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate,
@@ -379,12 +388,7 @@ int gemm_f32(hipStream_t stream, bool a_kmajor, bool b_kmajor, int M, int N, int
     else { if (vec) S2VT_GEMM_LAUNCH(false, false, true); else S2VT_GEMM_LAUNCH(false, false, false); }
 #undef S2VT_GEMM_LAUNCH
     S2VT_LAUNCH_CHECK("gemm_f32_kernel");
-    if (nsplit > 1) {
-        const int64_t nq = (int64_t)M * ((N + 3) / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, stream, splitk_ws,
-                           nsplit, M, N, C, ldc, cmap, bias, accumulate ? 1 : 0);
-        S2VT_LAUNCH_CHECK("splitk_reduce_kernel");
-    }
+    if (nsplit > 1) return splitk_reduce(stream, splitk_ws, nsplit, M, N, C, ldc, cmap, bias, accumulate);
     return 0;
 }
 
