@@ -159,6 +159,12 @@ int s2vt_lstm_seq_bwd(int32_t T, int32_t B, int32_t H, const float* w_hh, const 
 int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, const float* w_out, const float* b_out,
                             unsigned long long* packed, void* stream);
 
+/* Arithmetic of the batched GEMMs inside the whole-path train drivers: 0 = fp32-input MFMA (exact fp32 products),
+ * 3 = split precision (3 bf16 planes per operand, six plane products on the bf16 matrix cores: fp32-equivalent to
+ * ~2^-23 relative; default when B % 64 == 0, env S2VT_GEMM_MODE).  Returns the previous mode; a negative argument only queries.  Call it between a
+ * forward and its backward only if you also re-query the workspace size. */
+int s2vt_set_gemm_mode(int32_t mode);
+
 /* Layer pipelining of the whole-path drivers: the two LSTM layers run as a software pipeline on two streams in
  * blocks of `steps` timesteps (default 16, or env S2VT_PIPE_BLOCK); 0 runs everything on the caller's stream
  * (kernels then never overlap: used to time kernels in isolation).  Returns the previous value. */

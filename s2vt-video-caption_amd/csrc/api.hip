@@ -260,6 +260,190 @@ static std::vector<int> pipe_bounds(int T, int L, int blk) {
     return b;
 }
 
+// ------------------------------------------------------------------ split-precision (bf16 x 3) drivers
+// Same launch structure as the fp32-MFMA drivers below, but every batched GEMM runs on the bf16 matrix cores
+// from 3-plane operands (gemm_bf16.hip: fp32-equivalent products).  Each fp32 tensor that feeds a GEMM is
+// rewritten ONCE per consumer orientation into packed planes by the memory-bound split kernels (split.hip),
+// which also perform every transpose / gather / batch-major<->time-major permutation, so the MFMA kernel only
+// sees k-contiguous operands.  The timestep kernels stay fp32 (they are latency/bandwidth bound, not MFMA bound).
+static int g_gemm_mode = -1;       // 0: fp32 MFMA GEMMs, 3: bf16 x 3 planes
+static int gemm_mode() {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("S2VT_GEMM_MODE");
+        g_gemm_mode = e ? atoi(e) : 3;
+        if (g_gemm_mode != 3) g_gemm_mode = 0;
+    }
+    return g_gemm_mode;
+}
+// plane mode needs every k-offset inside a packed operand to be a multiple of 64 (k = time*B + b): B % 64 == 0
+static bool planes_ok(const s2vt_dims& d) { return gemm_mode() == 3 && d.B % 64 == 0; }
+
+constexpr int XP = 3;
+static inline int pad64(int x) { return (x + 63) / 64 * 64; }
+struct PB { unsigned short* p; int64_t ld; int kpad; };       // packed planes of a k-major operand [rows][k]
+
+struct PlaneWS {
+    // forward
+    PB feats, wf, x1, wih1, h1, we, wv, emb, h2dec, wo;
+    // backward
+    PB dlog, woT, dlogT, h2decT, wvT, weT, wih1T, dg2, dg2T, h2T, h1T, embT, dg1, dg1T, x1T, dx1T, featsT;
+    size_t bytes;
+};
+
+static PlaneWS carve_planes(const s2vt_dims& d, void* base) {
+    const size_t B = d.B, L = d.L, F = d.F, H = d.H, E = d.E, V = d.V, T = 2 * L - 1, R = (L - 1) * B;
+    Carver c{reinterpret_cast<char*>(base), 0, 0};
+    auto mk = [&](size_t rows, size_t k) {
+        PB b;
+        b.kpad = pad64((int)k);
+        b.ld = (int64_t)XP * b.kpad;
+        b.p = c.take<unsigned short>(rows * (size_t)b.ld);
+        return b;
+    };
+    PlaneWS w;
+    w.feats = mk(B * L, F);   w.wf = mk(H, F);       w.x1 = mk(L * B, H);    w.wih1 = mk(4 * H, H);
+    w.h1 = mk(T * B, H);      w.we = mk(4 * H, E);   w.wv = mk(4 * H, H);    w.emb = mk(R, E);
+    w.h2dec = mk(R, H);       w.wo = mk(V, H);
+    w.dlog = mk(R, V);        w.woT = mk(H, V);      w.dlogT = mk(V, R);     w.h2decT = mk(H, R);
+    w.wvT = mk(H, 4 * H);     w.weT = mk(E, 4 * H);  w.wih1T = mk(H, 4 * H); w.dg2 = mk(T * B, 4 * H);
+    w.dg2T = mk(4 * H, T * B); w.h2T = mk(H, T * B); w.h1T = mk(H, T * B);   w.embT = mk(E, R);
+    w.dg1 = mk(L * B, 4 * H); w.dg1T = mk(4 * H, T * B); w.x1T = mk(H, L * B); w.dx1T = mk(H, L * B);
+    w.featsT = mk(F, L * B);
+    w.bytes = align_up(c.off, 256);
+    return w;
+}
+
+// rows [r0, r0+rows) of the operand <- planes of in[rows][cols]
+static int psplit(const Lane& ln, const PB& dst, int r0, const float* in, int64_t ld, RowMap imap, int rows, int cols) {
+    return split_planes(ln.s, XP, false, in, ld, imap, rows, cols, dst.p + (int64_t)r0 * dst.ld, dst.ld, dst.kpad, rows);
+}
+// operand rows = input columns (all `cols` of them), k range [k0, k0+rows) <- planes of in[rows][cols]^T
+static int psplitT(const Lane& ln, const PB& dst, int k0, const float* in, int64_t ld, RowMap imap, int rows, int cols) {
+    return split_planes(ln.s, XP, true, in, ld, imap, rows, cols, dst.p + (int64_t)k0 * XP, dst.ld, pad64(rows), cols);
+}
+// C[M,N] (+)= A[rows a0.., k ka..ka+K) · B[rows b0.., k kb..kb+K)^T
+static int pgemm(const Lane& ln, int M, int N, int K, const PB& A, int a0, int ka, const PB& B, int b0, int kb, float* C,
+                 int64_t ldc, RowMap cm, const float* bias, bool acc) {
+    ProfScope ps(ln.s, K_GEMM, 1);
+    return gemm_bf16_nt(ln.s, XP, M, N, pad64(K), A.p + (int64_t)a0 * A.ld + (int64_t)ka * XP, A.ld,
+                        B.p + (int64_t)b0 * B.ld + (int64_t)kb * XP, B.ld, C, ldc, cm, bias, acc, ln.gws, ln.gws_floats);
+}
+
+static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
+                            int64_t targets_ld, float* logits, const TrainWS& w, const PlaneWS& q, hipStream_t st) {
+    const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1, R = (L - 1) * B;
+    const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
+    const int blk = pipe_block();
+    hipStream_t sx = st;
+    int rc;
+    if (blk > 0 && (rc = side_stream(&sx))) return rc;
+    const Lane la{st, w.gws_a, w.gws_floats, w.colsum_a};
+    const Lane lb{sx, w.gws_b, w.gws_floats, w.colsum_b};
+    size_t ev = 0;
+    if ((rc = add_vectors(st, p->vid_b_ih, p->vid_b_hh, w.bsum1, 4 * H))) return rc;
+    if ((rc = add_vectors(st, p->word_b_ih, p->word_b_hh, w.bsum2, 4 * H))) return rc;
+    if ((rc = fill_zero(st, w.err, 4 * sizeof(int)))) return rc;
+    if ((rc = targets_to_time_major(st, targets, B, L - 1, targets_ld, V, w.tok, w.err))) return rc;
+    if ((rc = handoff(st, sx, ev++))) return rc;
+    // lane B: word_rnn / out_linear weights and the embedded caption words as planes; embedded-word half of gx2
+    if ((rc = psplit(lb, q.we, 0, p->word_w_ih, E + H, ID, 4 * H, E))) return rc;
+    if ((rc = psplit(lb, q.wv, 0, p->word_w_ih + E, E + H, ID, 4 * H, H))) return rc;
+    if ((rc = psplit(lb, q.wo, 0, p->out_w, H, ID, V, H))) return rc;
+    if ((rc = psplit(lb, q.emb, 0, p->emb_w, E, gather(w.tok), R, E))) return rc;
+    if ((rc = pgemm(lb, R, 4 * H, E, q.emb, 0, 0, q.we, 0, 0, w.s2 + (int64_t)L * B4H, 4 * H, ID, w.bsum2, false))) return rc;
+    // lane A: feature projection and vid_rnn input GEMM                       S2VTModel.py:54, 64-67
+    if ((rc = psplit(la, q.feats, 0, feats, F, ID, B * L, F))) return rc;
+    if ((rc = psplit(la, q.wf, 0, p->feat_w, F, ID, H, F))) return rc;
+    if ((rc = psplit(la, q.wih1, 0, p->vid_w_ih, H, ID, 4 * H, H))) return rc;
+    if ((rc = pgemm(la, B * L, H, F, q.feats, 0, 0, q.wf, 0, 0, w.x1, H, perm(L, B), p->feat_b, false))) return rc;
+    if ((rc = psplit(la, q.x1, 0, w.x1, H, ID, L * B, H))) return rc;
+    if ((rc = pgemm(la, L * B, 4 * H, H, q.x1, 0, 0, q.wih1, 0, 0, w.s1, 4 * H, ID, w.bsum1, false))) return rc;
+    const std::vector<int> bd = pipe_bounds(T, L, blk);
+    for (size_t k = 0; k + 1 < bd.size(); ++k) {
+        const int t0 = bd[k], t1 = bd[k + 1];
+        if ((rc = seq_fwd(st, t0, t1, B, H, w.s1, L, w.bsum1, p->vid_w_hh, w.h1, w.c1, true))) return rc;
+        if ((rc = handoff(st, sx, ev++))) return rc;
+        const bool cap = t0 >= L;
+        if ((rc = psplit(lb, q.h1, t0 * B, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H))) return rc;
+        if ((rc = pgemm(lb, (t1 - t0) * B, 4 * H, H, q.h1, t0 * B, 0, q.wv, 0, 0, w.s2 + t0 * B4H, 4 * H, ID,
+                        cap ? nullptr : w.bsum2, cap)))
+            return rc;
+        if ((rc = seq_fwd(sx, t0, t1, B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, true))) return rc;
+    }
+    if ((rc = psplit(lb, q.h2dec, 0, w.h2 + L * BH, H, ID, R, H))) return rc;
+    if ((rc = pgemm(lb, R, V, H, q.h2dec, 0, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false))) return rc;
+    return handoff(sx, st, ev++);
+}
+
+static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
+                             const s2vt_grads* g, float* dfeats, const TrainWS& w, const PlaneWS& q, hipStream_t st) {
+    const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1, R = (L - 1) * B;
+    const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
+    const int blk = pipe_block();
+    hipStream_t sx = st;
+    int rc;
+    if (blk > 0 && (rc = side_stream(&sx))) return rc;
+    const Lane la{st, w.gws_a, w.gws_floats, w.colsum_a};     // word_rnn lane
+    const Lane lb{sx, w.gws_b, w.gws_floats, w.colsum_b};     // vid_rnn lane
+    size_t ev = 0;
+    if ((rc = handoff(st, sx, ev++))) return rc;
+    // lane A: gradient into the decode-step hidden states (k = V), W_v^T / W_e^T planes, then word_rnn BPTT
+    if ((rc = psplit(la, q.dlog, 0, dlogits, V, ID, R, V))) return rc;
+    if ((rc = psplitT(la, q.woT, 0, p->out_w, H, ID, V, H))) return rc;
+    if ((rc = pgemm(la, R, H, V, q.dlog, 0, 0, q.woT, 0, 0, w.dh2dec, H, perm(L - 1, B), nullptr, false))) return rc;
+    if ((rc = transpose_f32(st, p->word_w_hh, 4 * H, H, w.wt2))) return rc;
+    if ((rc = psplitT(la, q.wvT, 0, p->word_w_ih + E, E + H, ID, 4 * H, H))) return rc;
+    if ((rc = psplitT(la, q.weT, 0, p->word_w_ih, E + H, ID, 4 * H, E))) return rc;
+    if ((rc = psplitT(la, q.h1T, 0, w.h1, H, ID, T * B, H))) return rc;
+    // lane B meanwhile: out_linear weight/bias gradients (k = batch-major row index), W_hh1^T, W_ih1^T, x1^T
+    if ((rc = psplitT(lb, q.dlogT, 0, dlogits, V, ID, R, V))) return rc;
+    if ((rc = psplitT(lb, q.h2decT, 0, w.h2 + L * BH, H, perm(L - 1, B), R, H))) return rc;
+    if ((rc = pgemm(lb, V, H, R, q.dlogT, 0, 0, q.h2decT, 0, 0, g->out_w, H, ID, nullptr, false))) return rc;
+    if ((rc = colsum_f32(sx, dlogits, R, V, V, lb.colsum, g->out_b, false))) return rc;
+    if ((rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
+    if ((rc = psplitT(lb, q.wih1T, 0, p->vid_w_ih, H, ID, 4 * H, H))) return rc;
+    if ((rc = psplitT(lb, q.x1T, 0, w.x1, H, ID, L * B, H))) return rc;
+    const std::vector<int> bd = pipe_bounds(T, L, blk);
+    for (size_t k = bd.size() - 1; k >= 1; --k) {
+        const int t0 = bd[k - 1], t1 = bd[k];
+        if ((rc = seq_bwd(st, T, t0, t1, B, H, w.wt2, w.dh2dec, L, w.c2, w.s2, w.dc2))) return rc;
+        if ((rc = psplit(la, q.dg2, t0 * B, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H))) return rc;
+        if ((rc = pgemm(la, (t1 - t0) * B, H, 4 * H, q.dg2, t0 * B, 0, q.wvT, 0, 0, w.dh1 + t0 * BH, H, ID, nullptr, false)))
+            return rc;
+        if ((rc = handoff(st, sx, ev++))) return rc;
+        if ((rc = seq_bwd(sx, T, t0, t1, B, H, w.wt1, w.dh1, 0, w.c1, w.s1, w.dc1))) return rc;
+    }
+    // lane A: word_rnn parameter gradients + embedding gradient
+    if ((rc = psplitT(la, q.dg2T, 0, w.s2, 4 * H, ID, T * B, 4 * H))) return rc;
+    if ((rc = psplitT(la, q.h2T, 0, w.h2, H, ID, T * B, H))) return rc;
+    if ((rc = pgemm(la, 4 * H, H, (T - 1) * B, q.dg2T, 0, B, q.h2T, 0, 0, g->word_w_hh, H, ID, nullptr, false))) return rc;
+    if ((rc = pgemm(la, 4 * H, H, T * B, q.dg2T, 0, 0, q.h1T, 0, 0, g->word_w_ih + E, E + H, ID, nullptr, false))) return rc;
+    if ((rc = psplitT(la, q.embT, 0, p->emb_w, E, gather(w.tok), R, E))) return rc;
+    if ((rc = pgemm(la, 4 * H, E, R, q.dg2T, 0, L * B, q.embT, 0, 0, g->word_w_ih, E + H, ID, nullptr, false))) return rc;
+    if ((rc = colsum_f32(st, w.s2, (int64_t)T * B, 4 * H, 4 * H, la.colsum, g->word_b_ih, false))) return rc;
+    S2VT_HIP(hipMemcpyAsync(g->word_b_hh, g->word_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
+    if ((rc = pgemm(la, R, E, 4 * H, q.dg2, L * B, 0, q.weT, 0, 0, w.de, E, ID, nullptr, false))) return rc;
+    if ((rc = fill_zero(st, g->emb_w, sizeof(float) * (size_t)V * E))) return rc;
+    if ((rc = embedding_scatter_add(st, w.de, R, E, w.tok, g->emb_w))) return rc;
+    // lane B: vid_rnn and feat_linear parameter gradients
+    if ((rc = psplitT(lb, q.dg1T, 0, w.s1, 4 * H, ID, T * B, 4 * H))) return rc;
+    if ((rc = pgemm(lb, 4 * H, H, (T - 1) * B, q.dg1T, 0, B, q.h1T, 0, 0, g->vid_w_hh, H, ID, nullptr, false))) return rc;
+    if ((rc = pgemm(lb, 4 * H, H, L * B, q.dg1T, 0, 0, q.x1T, 0, 0, g->vid_w_ih, H, ID, nullptr, false))) return rc;
+    if ((rc = colsum_f32(sx, w.s1, (int64_t)T * B, 4 * H, 4 * H, lb.colsum, g->vid_b_ih, false))) return rc;
+    S2VT_HIP(hipMemcpyAsync(g->vid_b_hh, g->vid_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, sx));
+    if ((rc = psplit(lb, q.dg1, 0, w.s1, 4 * H, ID, L * B, 4 * H))) return rc;
+    if ((rc = pgemm(lb, L * B, H, 4 * H, q.dg1, 0, 0, q.wih1T, 0, 0, w.dx1, H, ID, nullptr, false))) return rc;
+    if ((rc = psplitT(lb, q.dx1T, 0, w.dx1, H, ID, L * B, H))) return rc;
+    if ((rc = psplitT(lb, q.featsT, 0, feats, F, perm(B, L), L * B, F))) return rc;
+    if ((rc = pgemm(lb, H, F, L * B, q.dx1T, 0, 0, q.featsT, 0, 0, g->feat_w, F, ID, nullptr, false))) return rc;
+    if ((rc = colsum_f32(sx, w.dx1, (int64_t)L * B, H, H, lb.colsum, g->feat_b, false))) return rc;
+    if (dfeats) {   // rarely requested (nothing reads it in the reference): fp32-MFMA GEMM
+        if ((rc = lgemm(lb, true, false, L * B, F, H, w.dx1, H, ID, p->feat_w, F, ID, dfeats, F, perm(B, L), nullptr, false)))
+            return rc;
+    }
+    return handoff(sx, st, ev++);
+}
+
 }  // namespace s2vt
 
 using namespace s2vt;
@@ -271,7 +455,9 @@ const char* s2vt_last_error(void) { return g_err; }
 
 size_t s2vt_train_workspace_bytes(const s2vt_dims* d) {
     if (!dims_ok(d)) return 0;
-    return carve_train(*d, nullptr).bytes;
+    size_t n = carve_train(*d, nullptr).bytes;
+    if (planes_ok(*d)) n += carve_planes(*d, nullptr).bytes;
+    return n;
 }
 
 int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
@@ -280,6 +466,12 @@ int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* fe
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
+    if (planes_ok(*d)) {
+        const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
+        S2VT_REQUIRE(workspace_bytes >= w.bytes + q.bytes, "s2vt_train_forward: workspace %zu < %zu bytes",
+                     workspace_bytes, w.bytes + q.bytes);
+        return train_forward_x3(d, p, feats, targets, targets_ld, logits, w, q, st);
+    }
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
     const int blk = pipe_block();
@@ -330,6 +522,12 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
+    if (planes_ok(*d)) {
+        const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
+        S2VT_REQUIRE(workspace_bytes >= w.bytes + q.bytes, "s2vt_train_backward: workspace %zu < %zu bytes",
+                     workspace_bytes, w.bytes + q.bytes);
+        return train_backward_x3(d, p, feats, dlogits, g, dfeats, w, q, st);
+    }
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
     const int R = (L - 1) * B;
@@ -632,6 +830,12 @@ int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, con
     la.packed = packed;
     ProfScope ps((hipStream_t)stream, K_ARGMAX, 1);
     return logits_argmax((hipStream_t)stream, la);
+}
+
+int s2vt_set_gemm_mode(int32_t mode) {
+    const int prev = gemm_mode();
+    if (mode >= 0) g_gemm_mode = (mode == 3) ? 3 : 0;     // negative: query only
+    return prev;
 }
 
 int s2vt_set_pipeline_block(int32_t steps) {
