@@ -96,7 +96,7 @@ struct Carver {
 
 struct TrainWS {
     float *bsum1, *bsum2, *x1, *s1, *h1, *c1, *s2, *h2, *c2;
-    float *wt1, *wt2, *dh1, *dh2dec, *dx1, *de, *dc1, *dc2, *colsum_a, *colsum_b, *gws_a, *gws_b;
+    float *wt1, *wt2, *dh1, *dh2dec, *dx1, *de, *dc1, *dc2, *colsum_a, *colsum_b, *colsum_c, *gws_a, *gws_b;
     size_t gws_floats;
     int32_t* tok;
     int* err;
@@ -137,6 +137,7 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     const size_t csm = cs > cs2 ? (cs > cs3 ? cs : cs3) : (cs2 > cs3 ? cs2 : cs3);
     w.colsum_a = c.take<float>(csm);
     w.colsum_b = c.take<float>(csm);
+    w.colsum_c = c.take<float>(csm);
     w.gws_floats = gemm_ws_floats(d);
     w.gws_a = c.take<float>(w.gws_floats);
     w.gws_b = c.take<float>(w.gws_floats);
@@ -321,6 +322,14 @@ static int psplit(const Lane& ln, const PB& dst, int r0, const float* in, int64_
 static int psplitT(const Lane& ln, const PB& dst, int k0, const float* in, int64_t ld, RowMap imap, int rows, int cols) {
     return split_planes(ln.s, XP, true, in, ld, imap, rows, cols, dst.p + (int64_t)k0 * XP, dst.ld, pad64(rows), cols);
 }
+// one pass over in[rows][cols]: row planes into r (operand rows r0..), transposed planes into t (k range k0..),
+// 64-row partial column sums into colpart (each may be null)
+static int pdual(const Lane& ln, const float* in, int64_t ld, RowMap imap, int rows, int cols, const PB* r, int r0,
+                 const PB* t, int k0, float* colpart) {
+    return split_planes_dual(ln.s, XP, in, ld, imap, rows, cols, r ? r->p + (int64_t)r0 * r->ld : nullptr, r ? r->ld : 0,
+                             r ? r->kpad : 0, t ? t->p + (int64_t)k0 * XP : nullptr, t ? t->ld : 0, t ? pad64(rows) : 0,
+                             colpart);
+}
 // C[M,N] (+)= A[rows a0.., k ka..ka+K) · B[rows b0.., k kb..kb+K)^T
 static int pgemm(const Lane& ln, int M, int N, int K, const PB& A, int a0, int ka, const PB& B, int b0, int kb, float* C,
                  int64_t ldc, RowMap cm, const float* bias, bool acc) {
@@ -346,17 +355,18 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
     if ((rc = targets_to_time_major(st, targets, B, L - 1, targets_ld, V, w.tok, w.err))) return rc;
     if ((rc = handoff(st, sx, ev++))) return rc;
     // lane B: word_rnn / out_linear weights and the embedded caption words as planes; embedded-word half of gx2
-    if ((rc = psplit(lb, q.we, 0, p->word_w_ih, E + H, ID, 4 * H, E))) return rc;
-    if ((rc = psplit(lb, q.wv, 0, p->word_w_ih + E, E + H, ID, 4 * H, H))) return rc;
-    if ((rc = psplit(lb, q.wo, 0, p->out_w, H, ID, V, H))) return rc;
-    if ((rc = psplit(lb, q.emb, 0, p->emb_w, E, gather(w.tok), R, E))) return rc;
+    // (row planes for this forward, transposed planes for the coming backward: one read of each tensor)
+    if ((rc = pdual(lb, p->word_w_ih, E + H, ID, 4 * H, E, &q.we, 0, &q.weT, 0, nullptr))) return rc;
+    if ((rc = pdual(lb, p->word_w_ih + E, E + H, ID, 4 * H, H, &q.wv, 0, &q.wvT, 0, nullptr))) return rc;
+    if ((rc = pdual(lb, p->out_w, H, ID, V, H, &q.wo, 0, &q.woT, 0, nullptr))) return rc;
+    if ((rc = pdual(lb, p->emb_w, E, gather(w.tok), R, E, &q.emb, 0, &q.embT, 0, nullptr))) return rc;
     if ((rc = pgemm(lb, R, 4 * H, E, q.emb, 0, 0, q.we, 0, 0, w.s2 + (int64_t)L * B4H, 4 * H, ID, w.bsum2, false))) return rc;
     // lane A: feature projection and vid_rnn input GEMM                       S2VTModel.py:54, 64-67
     if ((rc = psplit(la, q.feats, 0, feats, F, ID, B * L, F))) return rc;
     if ((rc = psplit(la, q.wf, 0, p->feat_w, F, ID, H, F))) return rc;
-    if ((rc = psplit(la, q.wih1, 0, p->vid_w_ih, H, ID, 4 * H, H))) return rc;
+    if ((rc = pdual(la, p->vid_w_ih, H, ID, 4 * H, H, &q.wih1, 0, &q.wih1T, 0, nullptr))) return rc;
     if ((rc = pgemm(la, B * L, H, F, q.feats, 0, 0, q.wf, 0, 0, w.x1, H, perm(L, B), p->feat_b, false))) return rc;
-    if ((rc = psplit(la, q.x1, 0, w.x1, H, ID, L * B, H))) return rc;
+    if ((rc = pdual(la, w.x1, H, ID, L * B, H, &q.x1, 0, &q.x1T, 0, nullptr))) return rc;
     if ((rc = pgemm(la, L * B, 4 * H, H, q.x1, 0, 0, q.wih1, 0, 0, w.s1, 4 * H, ID, w.bsum1, false))) return rc;
     const std::vector<int> bd = pipe_bounds(T, L, blk);
     for (size_t k = 0; k + 1 < bd.size(); ++k) {
@@ -364,13 +374,16 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
         if ((rc = seq_fwd(st, t0, t1, B, H, w.s1, L, w.bsum1, p->vid_w_hh, w.h1, w.c1, true))) return rc;
         if ((rc = handoff(st, sx, ev++))) return rc;
         const bool cap = t0 >= L;
-        if ((rc = psplit(lb, q.h1, t0 * B, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H))) return rc;
+        if ((rc = pdual(lb, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H, &q.h1, t0 * B, &q.h1T, t0 * B, nullptr))) return rc;
         if ((rc = pgemm(lb, (t1 - t0) * B, 4 * H, H, q.h1, t0 * B, 0, q.wv, 0, 0, w.s2 + t0 * B4H, 4 * H, ID,
                         cap ? nullptr : w.bsum2, cap)))
             return rc;
         if ((rc = seq_fwd(sx, t0, t1, B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, true))) return rc;
+        // h2 planes: transposed (k = time-major row) for dW_hh2; row planes of the decode steps for the logits GEMM
+        if ((rc = pdual(lb, w.h2 + t0 * BH, H, ID, (t1 - t0) * B, H, cap ? &q.h2dec : nullptr, cap ? (t0 - L) * B : 0,
+                        &q.h2T, t0 * B, nullptr)))
+            return rc;
     }
-    if ((rc = psplit(lb, q.h2dec, 0, w.h2 + L * BH, H, ID, R, H))) return rc;
     if ((rc = pgemm(lb, R, V, H, q.h2dec, 0, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false))) return rc;
     return handoff(sx, st, ev++);
 }
@@ -387,56 +400,53 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     const Lane lb{sx, w.gws_b, w.gws_floats, w.colsum_b};     // vid_rnn lane
     size_t ev = 0;
     if ((rc = handoff(st, sx, ev++))) return rc;
-    // lane A: gradient into the decode-step hidden states (k = V), W_v^T / W_e^T planes, then word_rnn BPTT
-    if ((rc = psplit(la, q.dlog, 0, dlogits, V, ID, R, V))) return rc;
-    if ((rc = psplitT(la, q.woT, 0, p->out_w, H, ID, V, H))) return rc;
+    // lane A: dlogits planes in both orientations + its column sums (one read), gradient into the decode-step
+    // hidden states (k = V), then word_rnn BPTT.  (W^T planes were written by the forward.)
+    if ((rc = pdual(la, dlogits, V, ID, R, V, &q.dlog, 0, &q.dlogT, 0, w.colsum_c))) return rc;
+    if ((rc = handoff(st, sx, ev++))) return rc;
     if ((rc = pgemm(la, R, H, V, q.dlog, 0, 0, q.woT, 0, 0, w.dh2dec, H, perm(L - 1, B), nullptr, false))) return rc;
     if ((rc = transpose_f32(st, p->word_w_hh, 4 * H, H, w.wt2))) return rc;
-    if ((rc = psplitT(la, q.wvT, 0, p->word_w_ih + E, E + H, ID, 4 * H, H))) return rc;
-    if ((rc = psplitT(la, q.weT, 0, p->word_w_ih, E + H, ID, 4 * H, E))) return rc;
-    if ((rc = psplitT(la, q.h1T, 0, w.h1, H, ID, T * B, H))) return rc;
-    // lane B meanwhile: out_linear weight/bias gradients (k = batch-major row index), W_hh1^T, W_ih1^T, x1^T
-    if ((rc = psplitT(lb, q.dlogT, 0, dlogits, V, ID, R, V))) return rc;
+    // lane B meanwhile: out_linear weight/bias gradients (k = batch-major row index) and W_hh1^T
     if ((rc = psplitT(lb, q.h2decT, 0, w.h2 + L * BH, H, perm(L - 1, B), R, H))) return rc;
     if ((rc = pgemm(lb, V, H, R, q.dlogT, 0, 0, q.h2decT, 0, 0, g->out_w, H, ID, nullptr, false))) return rc;
-    if ((rc = colsum_f32(sx, dlogits, R, V, V, lb.colsum, g->out_b, false))) return rc;
+    if ((rc = colsum_finish(sx, w.colsum_c, cdiv(R, 64), V, g->out_b, false))) return rc;
     if ((rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
-    if ((rc = psplitT(lb, q.wih1T, 0, p->vid_w_ih, H, ID, 4 * H, H))) return rc;
-    if ((rc = psplitT(lb, q.x1T, 0, w.x1, H, ID, L * B, H))) return rc;
     const std::vector<int> bd = pipe_bounds(T, L, blk);
     for (size_t k = bd.size() - 1; k >= 1; --k) {
         const int t0 = bd[k - 1], t1 = bd[k];
         if ((rc = seq_bwd(st, T, t0, t1, B, H, w.wt2, w.dh2dec, L, w.c2, w.s2, w.dc2))) return rc;
-        if ((rc = psplit(la, q.dg2, t0 * B, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H))) return rc;
+        // dG2 of this block: row planes (dh1, d-embedding GEMMs), transposed planes (weight gradients) and the
+        // bias-gradient partial sums, all from one read
+        if ((rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, &q.dg2, t0 * B, &q.dg2T, t0 * B,
+                        w.colsum_a + (int64_t)(t0 * B / 64) * 4 * H)))
+            return rc;
         if ((rc = pgemm(la, (t1 - t0) * B, H, 4 * H, q.dg2, t0 * B, 0, q.wvT, 0, 0, w.dh1 + t0 * BH, H, ID, nullptr, false)))
             return rc;
         if ((rc = handoff(st, sx, ev++))) return rc;
         if ((rc = seq_bwd(sx, T, t0, t1, B, H, w.wt1, w.dh1, 0, w.c1, w.s1, w.dc1))) return rc;
+        if ((rc = pdual(lb, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, (t0 < L) ? &q.dg1 : nullptr, t0 * B, &q.dg1T,
+                        t0 * B, w.colsum_b + (int64_t)(t0 * B / 64) * 4 * H)))
+            return rc;
     }
     // lane A: word_rnn parameter gradients + embedding gradient
-    if ((rc = psplitT(la, q.dg2T, 0, w.s2, 4 * H, ID, T * B, 4 * H))) return rc;
-    if ((rc = psplitT(la, q.h2T, 0, w.h2, H, ID, T * B, H))) return rc;
     if ((rc = pgemm(la, 4 * H, H, (T - 1) * B, q.dg2T, 0, B, q.h2T, 0, 0, g->word_w_hh, H, ID, nullptr, false))) return rc;
     if ((rc = pgemm(la, 4 * H, H, T * B, q.dg2T, 0, 0, q.h1T, 0, 0, g->word_w_ih + E, E + H, ID, nullptr, false))) return rc;
-    if ((rc = psplitT(la, q.embT, 0, p->emb_w, E, gather(w.tok), R, E))) return rc;
     if ((rc = pgemm(la, 4 * H, E, R, q.dg2T, 0, L * B, q.embT, 0, 0, g->word_w_ih, E + H, ID, nullptr, false))) return rc;
-    if ((rc = colsum_f32(st, w.s2, (int64_t)T * B, 4 * H, 4 * H, la.colsum, g->word_b_ih, false))) return rc;
+    if ((rc = colsum_finish(st, w.colsum_a, T * B / 64, 4 * H, g->word_b_ih, false))) return rc;
     S2VT_HIP(hipMemcpyAsync(g->word_b_hh, g->word_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
     if ((rc = pgemm(la, R, E, 4 * H, q.dg2, L * B, 0, q.weT, 0, 0, w.de, E, ID, nullptr, false))) return rc;
     if ((rc = fill_zero(st, g->emb_w, sizeof(float) * (size_t)V * E))) return rc;
     if ((rc = embedding_scatter_add(st, w.de, R, E, w.tok, g->emb_w))) return rc;
     // lane B: vid_rnn and feat_linear parameter gradients
-    if ((rc = psplitT(lb, q.dg1T, 0, w.s1, 4 * H, ID, T * B, 4 * H))) return rc;
     if ((rc = pgemm(lb, 4 * H, H, (T - 1) * B, q.dg1T, 0, B, q.h1T, 0, 0, g->vid_w_hh, H, ID, nullptr, false))) return rc;
     if ((rc = pgemm(lb, 4 * H, H, L * B, q.dg1T, 0, 0, q.x1T, 0, 0, g->vid_w_ih, H, ID, nullptr, false))) return rc;
-    if ((rc = colsum_f32(sx, w.s1, (int64_t)T * B, 4 * H, 4 * H, lb.colsum, g->vid_b_ih, false))) return rc;
+    if ((rc = colsum_finish(sx, w.colsum_b, T * B / 64, 4 * H, g->vid_b_ih, false))) return rc;
     S2VT_HIP(hipMemcpyAsync(g->vid_b_hh, g->vid_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, sx));
-    if ((rc = psplit(lb, q.dg1, 0, w.s1, 4 * H, ID, L * B, 4 * H))) return rc;
     if ((rc = pgemm(lb, L * B, H, 4 * H, q.dg1, 0, 0, q.wih1T, 0, 0, w.dx1, H, ID, nullptr, false))) return rc;
-    if ((rc = psplitT(lb, q.dx1T, 0, w.dx1, H, ID, L * B, H))) return rc;
+    if ((rc = pdual(lb, w.dx1, H, ID, L * B, H, nullptr, 0, &q.dx1T, 0, w.colsum_b))) return rc;
     if ((rc = psplitT(lb, q.featsT, 0, feats, F, perm(B, L), L * B, F))) return rc;
     if ((rc = pgemm(lb, H, F, L * B, q.dx1T, 0, 0, q.featsT, 0, 0, g->feat_w, F, ID, nullptr, false))) return rc;
-    if ((rc = colsum_f32(sx, w.dx1, (int64_t)L * B, H, H, lb.colsum, g->feat_b, false))) return rc;
+    if ((rc = colsum_finish(sx, w.colsum_b, L * B / 64, H, g->feat_b, false))) return rc;
     if (dfeats) {   // rarely requested (nothing reads it in the reference): fp32-MFMA GEMM
         if ((rc = lgemm(lb, true, false, L * B, F, H, w.dx1, H, ID, p->feat_w, F, ID, dfeats, F, perm(B, L), nullptr, false)))
             return rc;

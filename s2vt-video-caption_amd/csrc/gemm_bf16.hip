@@ -49,7 +49,12 @@ template <int NP>
 __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmBfArgs p) {
     typedef BfCfg<NP> Cf;
     constexpr int HBK = Cf::BK, HROW = Cf::HROW, PPR = Cf::PPR, NPC = Cf::NPC;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Cf::IMG];
+#ifndef S2VT_X3_LDS_PAD
+#define S2VT_X3_LDS_PAD 0
+#endif
+    // S2VT_X3_LDS_PAD > 0 (experiment): inflate the LDS footprint so fewer GEMM workgroups share a CU, leaving room
+    // for timestep workgroups of the other pipeline lane to co-reside
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Cf::IMG + S2VT_X3_LDS_PAD];
     unsigned char* sA = smem;
     unsigned char* sB = smem + Cf::IMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

@@ -17,6 +17,11 @@ int gemm_bf16_nt(hipStream_t stream, int nplanes, int M, int N, int K, const uns
 int split_planes(hipStream_t s, int nplanes, bool transpose, const float* in, int64_t ld, RowMap imap, int rows, int cols,
                  unsigned short* out, int64_t ldo, int kpad, int out_rows_pad);
 
+int split_planes_dual(hipStream_t s, int nplanes, const float* in, int64_t ld, RowMap imap, int rows, int cols,
+                      unsigned short* out_r, int64_t ldo_r, int kpad_r, unsigned short* out_t, int64_t ldo_t, int kpad_t,
+                      float* colpart);
+int colsum_finish(hipStream_t s, const float* partial, int nchunks, int cols, float* out, bool accumulate);
+
 // ---- lstm.hip
 struct StepFwdArgs {
     int B, H;

@@ -41,7 +41,7 @@ int transpose_f32(hipStream_t s, const float* in, int rows, int cols, float* out
 
 // Deterministic column sum in two passes: partial[chunk][col] over CS_ROWS-row chunks, then a fixed-
 // order sum over chunks (bias gradients must not depend on atomics' arrival order).
-constexpr int CS_ROWS = 128;
+constexpr int CS_ROWS = 64;   // = the row-tile of split_dual_kernel, which can produce the same partials
 size_t colsum_partial_floats(int64_t rows, int cols) { return (size_t)((rows + CS_ROWS - 1) / CS_ROWS) * cols; }
 
 __global__ void colsum_partial_kernel(const float* x, int64_t rows, int cols, int64_t ld, float* partial) {
@@ -60,6 +60,15 @@ __global__ void colsum_final_kernel(const float* partial, int nchunks, int cols,
     for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * cols + c];
     out[c] = s;
 }
+// fixed-order sum of `nchunks` partial rows (written by colsum_partial_kernel or split_dual_kernel)
+int colsum_finish(hipStream_t s, const float* partial, int nchunks, int cols, float* out, bool accumulate) {
+    if (cols <= 0) return 0;
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, partial, nchunks, cols, out,
+                       accumulate ? 1 : 0);
+    S2VT_LAUNCH_CHECK("colsum_final_kernel");
+    return 0;
+}
+
 int colsum_f32(hipStream_t s, const float* x, int64_t rows, int cols, int64_t ld, float* partial, float* out,
                bool accumulate) {
     if (cols <= 0) return 0;

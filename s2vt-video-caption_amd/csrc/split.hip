@@ -105,6 +105,96 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const float* in, i
     }
 }
 
+// One pass over a 64x64 tile of in[rows][cols] producing any of: (a) row planes (operand rows = input rows),
+// (b) transposed planes (operand rows = input columns, k = input row index), (c) per-tile column sums
+// partial[tile_row][col] (the bias gradients: summed afterwards in a fixed order by colsum_final_kernel).
+// Tensors that feed both a data-gradient GEMM (row planes) and a weight-gradient GEMM (transposed planes) — dG,
+// dlogits, h, x1, the weights themselves — are read from HBM once.
+template <int NP>
+__global__ __launch_bounds__(256) void split_dual_kernel(const float* in, int64_t ld, RowMap imap, int rows, int cols,
+                                                         unsigned short* out_r, int64_t ldo_r, int kpad_r,
+                                                         unsigned short* out_t, int64_t ldo_t, int kpad_t,
+                                                         float* colpart) {
+    __shared__ float tile[64][65];
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? in[(int64_t)map_row(imap, r) * ld + c] : 0.f;
+    }
+    __syncthreads();
+    if (colpart && threadIdx.x < 64 && c0 + (int)threadIdx.x < cols) {
+        float sum = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 64; ++i) sum += tile[i][threadIdx.x];
+        colpart[(int64_t)blockIdx.y * cols + c0 + threadIdx.x] = sum;
+    }
+    for (int s = threadIdx.x; s < 64 * 8; s += 256) {
+        const int a = s >> 3, bq = (s & 7) * 8;       // a: line index, bq: start of an 8-element run
+        if (out_r) {                                   // operand row = input row r0+a, k = input cols c0+bq..+7
+            const int r = r0 + a, c = c0 + bq;
+            if (r < rows && c < kpad_r) {
+                unsigned short o[3][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    unsigned short t[3];
+                    split3<NP>(tile[a][bq + j], t);
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) o[pl][j] = t[pl];
+                }
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    *reinterpret_cast<u32x4*>(out_r + packed_off(r, c, pl, ldo_r, NP)) =
+                        u32x4{o[pl][0] | ((u_int32_t)o[pl][1] << 16), o[pl][2] | ((u_int32_t)o[pl][3] << 16),
+                              o[pl][4] | ((u_int32_t)o[pl][5] << 16), o[pl][6] | ((u_int32_t)o[pl][7] << 16)};
+            }
+        }
+        if (out_t) {                                   // operand row = input col c0+a, k = input rows r0+bq..+7
+            const int c = c0 + a, r = r0 + bq;
+            if (c < cols && r < kpad_t) {
+                unsigned short o[3][8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    unsigned short t[3];
+                    split3<NP>(tile[bq + j][a], t);
+#pragma unroll
+                    for (int pl = 0; pl < NP; ++pl) o[pl][j] = t[pl];
+                }
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+                    *reinterpret_cast<u32x4*>(out_t + packed_off(c, r, pl, ldo_t, NP)) =
+                        u32x4{o[pl][0] | ((u_int32_t)o[pl][1] << 16), o[pl][2] | ((u_int32_t)o[pl][3] << 16),
+                              o[pl][4] | ((u_int32_t)o[pl][5] << 16), o[pl][6] | ((u_int32_t)o[pl][7] << 16)};
+            }
+        }
+    }
+}
+
+// Dual split.  out_r (nullable): row planes, rows [0, rows) of the operand at out_r, k padded to kpad_r >= cols.
+// out_t (nullable): transposed planes, operand rows = input columns, k range [0, kpad_t >= rows) at out_t.
+// colpart (nullable): cdiv(rows, 64) x cols partial column sums.  Padding (k beyond the data) is zero-filled as long
+// as kpad_r <= 64*cdiv(cols,64) and kpad_t <= 64*cdiv(rows,64), which holds for kpad = pad64(.).
+int split_planes_dual(hipStream_t s, int nplanes, const float* in, int64_t ld, RowMap imap, int rows, int cols,
+                      unsigned short* out_r, int64_t ldo_r, int kpad_r, unsigned short* out_t, int64_t ldo_t, int kpad_t,
+                      float* colpart) {
+    S2VT_REQUIRE(nplanes == 1 || nplanes == 3, "split_planes_dual: planes must be 1 or 3");
+    if (rows <= 0 || cols <= 0) return 0;
+    S2VT_REQUIRE(!out_r || (kpad_r % 64 == 0 && kpad_r >= cols && kpad_r <= 64 * cdiv(cols, 64) && ldo_r >= (int64_t)nplanes * kpad_r),
+                 "split_planes_dual: bad row-plane geometry");
+    S2VT_REQUIRE(!out_t || (kpad_t % 64 == 0 && kpad_t >= rows && kpad_t <= 64 * cdiv(rows, 64) && ldo_t >= (int64_t)nplanes * kpad_t),
+                 "split_planes_dual: bad transposed-plane geometry");
+    const dim3 grid(cdiv(cols, 64), cdiv(rows, 64));
+    if (nplanes == 3)
+        hipLaunchKernelGGL((split_dual_kernel<3>), grid, dim3(256), 0, s, in, ld, imap, rows, cols, out_r, ldo_r, kpad_r, out_t,
+                           ldo_t, kpad_t, colpart);
+    else
+        hipLaunchKernelGGL((split_dual_kernel<1>), grid, dim3(256), 0, s, in, ld, imap, rows, cols, out_r, ldo_r, kpad_r, out_t,
+                           ldo_t, kpad_t, colpart);
+    S2VT_LAUNCH_CHECK("split_dual_kernel");
+    return 0;
+}
+
 // in: fp32 [rows][cols] (row stride ld, rows mapped through imap) -> packed planes of a k-major operand:
 //   transpose == false: operand rows = input rows (out_rows_pad >= rows), k = input columns (kpad >= cols);
 //   transpose == true : operand rows = input columns (out_rows_pad >= cols), k = input rows (kpad >= rows).
