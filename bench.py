@@ -115,7 +115,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_pg = world > 1 or ("RANK" in os.environ and os.environ.get("S2VT_BENCH_PG", "0") == "1")
+    if use_pg:      # one process per GPU over RCCL ("nccl" backend); a 1-rank group exercises the same code path
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
@@ -135,7 +136,7 @@ def main():
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
     except Exception:
         opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    reducer = dp.FlatGradAllReducer(model.parameters()) if world > 1 else None
+    reducer = dp.FlatGradAllReducer(model.parameters()) if use_pg else None
 
     # this rank's shard of the synthetic global batch (seeded recipe); resident in HBM
     feats, caps, mask = synth.make_batch(B, L, F, V, seed=1234 + rank)
@@ -146,7 +147,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -161,13 +162,20 @@ def main():
         loss = one_step()
     sync_all()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     frames_per_s = world * B * L * args.steps / dt
     final_loss = float(loss)
+    # host-side enqueue cost of one step (no sync inside): must stay well below ms_per_step or the run is launch-bound
+    torch.cuda.synchronize(dev)
+    th = time.perf_counter()
+    for _ in range(3):
+        one_step()
+    host_ms = (time.perf_counter() - th) / 3 * 1e3
+    torch.cuda.synchronize(dev)
     log("timed region: %.3f ms/step, %.0f frames/s" % (ms_per_step, frames_per_s))
 
     out = None
@@ -293,7 +301,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: S2VT train step, B=%d per GPU x %d GPU, 80x4096 feats, "
                                    "hidden=embed=1000, vocab=12000, fp32, Adam" % (B, world),
                        "global_batch": B * world, "frames": L, "parallelism": "dp%d" % world},
-            "final_loss": round(final_loss, 6),
+            "final_loss": round(final_loss, 6), "host_enqueue_ms_per_step": round(host_ms, 3),
+            "pipeline_streams_overlap": int(lib.s2vt_pipeline_overlaps()),
             "roofline": roofline,
             "roofline_gemm": roof_gemm,
             "roofline_lstm_step": roof_step,
@@ -304,7 +313,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -169,6 +169,10 @@ int s2vt_set_gemm_mode(int32_t mode);
  * blocks of `steps` timesteps (default 16, or env S2VT_PIPE_BLOCK); 0 runs everything on the caller's stream
  * (kernels then never overlap: used to time kernels in isolation).  Returns the previous value. */
 int s2vt_set_pipeline_block(int32_t steps);
+/* 1 if the internal side stream was verified to execute concurrently with the caller's stream (it is chosen by a
+ * one-time calibration at the first pipelined call: HIP may map two streams onto one hardware queue), 0 if no
+ * candidate overlapped (the drivers still run, serially), -1 before the first pipelined call. */
+int s2vt_pipeline_overlaps(void);
 
 /* ---------------------------------------------------------------- live kernel timing (bench.py)
  * When enabled, launch sites bracket kernels of one kind with hipEvents on the launch stream.

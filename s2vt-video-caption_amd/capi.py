@@ -67,6 +67,7 @@ SIGNATURES = {
     "s2vt_decode_step_argmax": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5),
     "s2vt_set_gemm_mode": (c_int32, [c_int32]),
     "s2vt_set_pipeline_block": (c_int32, [c_int32]),
+    "s2vt_pipeline_overlaps": (c_int32, []),
     "s2vt_prof_enable": (c_int32, [c_int32]),
     "s2vt_prof_read": (c_int32, [c_int32, POINTER(c_double), POINTER(c_int64)]),
     "s2vt_prof_reset": (c_int32, []),

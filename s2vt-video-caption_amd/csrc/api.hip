@@ -170,8 +170,49 @@ static int pipe_block() {
     }
     return g_pipe_block;
 }
-static int side_stream(hipStream_t* out) {
-    if (!g_side) S2VT_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+// HIP multiplexes streams onto a small number of hardware queues (GPU_MAX_HW_QUEUES, default 4); two streams that
+// land on the same queue execute in order and the layer pipeline silently degenerates to serial execution (seen
+// as soon as RCCL has created its own streams).  So the side stream is CHOSEN: candidates are created until one
+// demonstrably runs concurrently with the caller's stream (two ~40 us spin kernels finish in about the time of one).
+__global__ void spin_kernel(unsigned long long ticks_100mhz) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz) {}
+}
+static bool streams_overlap(hipStream_t a, hipStream_t b) {
+    hipEvent_t e0, e1, e2;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventCreate(&e2) != hipSuccess)
+        return true;   // cannot test: accept
+    float both = 0.f, single = 0.f;
+    for (int rep = 0; rep < 2; ++rep) {   // first repetition warms the code object up
+        (void)hipEventRecord(e0, a);
+        (void)hipStreamWaitEvent(b, e0, 0);
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, 4000ull);
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, 4000ull);
+        (void)hipEventRecord(e1, b);
+        (void)hipStreamWaitEvent(a, e1, 0);
+        (void)hipEventRecord(e2, a);
+        (void)hipEventSynchronize(e2);
+        (void)hipEventElapsedTime(&both, e0, e2);
+        (void)hipEventRecord(e0, a);
+        hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, 4000ull);
+        (void)hipEventRecord(e2, a);
+        (void)hipEventSynchronize(e2);
+        (void)hipEventElapsedTime(&single, e0, e2);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    return both < 1.6f * single;
+}
+static int g_side_overlaps = -1;    // 1: verified concurrent with the first caller stream, 0: no candidate overlapped
+static int side_stream(hipStream_t caller, hipStream_t* out) {
+    if (!g_side) {
+        hipStream_t cand = nullptr;
+        g_side_overlaps = 0;
+        for (int attempt = 0; attempt < 8 && !g_side_overlaps; ++attempt) {
+            S2VT_HIP(hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));   // rejected candidates stay alive so
+            if (streams_overlap(caller, cand)) g_side_overlaps = 1;            // the next one gets another queue
+        }
+        g_side = cand;
+    }
     *out = g_side;
     return 0;
 }
@@ -345,7 +386,7 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
     const int blk = pipe_block();
     hipStream_t sx = st;
     int rc;
-    if (blk > 0 && (rc = side_stream(&sx))) return rc;
+    if (blk > 0 && (rc = side_stream(st, &sx))) return rc;
     const Lane la{st, w.gws_a, w.gws_floats, w.colsum_a};
     const Lane lb{sx, w.gws_b, w.gws_floats, w.colsum_b};
     size_t ev = 0;
@@ -395,7 +436,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     const int blk = pipe_block();
     hipStream_t sx = st;
     int rc;
-    if (blk > 0 && (rc = side_stream(&sx))) return rc;
+    if (blk > 0 && (rc = side_stream(st, &sx))) return rc;
     const Lane la{st, w.gws_a, w.gws_floats, w.colsum_a};     // word_rnn lane
     const Lane lb{sx, w.gws_b, w.gws_floats, w.colsum_b};     // vid_rnn lane
     size_t ev = 0;
@@ -487,7 +528,7 @@ int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* fe
     const int blk = pipe_block();
     hipStream_t sx = st;
     int rc;
-    if (blk > 0 && (rc = side_stream(&sx))) return rc;
+    if (blk > 0 && (rc = side_stream(st, &sx))) return rc;
     const Lane la{st, w.gws_a, w.gws_floats, w.colsum_a};     // vid_rnn lane (caller's stream)
     const Lane lb{sx, w.gws_b, w.gws_floats, w.colsum_b};     // word_rnn lane
     size_t ev = 0;
@@ -544,7 +585,7 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
     const int blk = pipe_block();
     hipStream_t sx = st;
     int rc;
-    if (blk > 0 && (rc = side_stream(&sx))) return rc;
+    if (blk > 0 && (rc = side_stream(st, &sx))) return rc;
     const Lane la{st, w.gws_a, w.gws_floats, w.colsum_a};     // word_rnn lane (caller's stream)
     const Lane lb{sx, w.gws_b, w.gws_floats, w.colsum_b};     // vid_rnn lane
     size_t ev = 0;
@@ -847,6 +888,8 @@ int s2vt_set_gemm_mode(int32_t mode) {
     if (mode >= 0) g_gemm_mode = (mode == 3) ? 3 : 0;     // negative: query only
     return prev;
 }
+
+int s2vt_pipeline_overlaps(void) { return g_side_overlaps; }
 
 int s2vt_set_pipeline_block(int32_t steps) {
     const int prev = pipe_block();

@@ -66,7 +66,7 @@ class FlatGradAllReducer:
 
     def all_reduce(self):
         """Average gradients over ranks (sum all-reduce, then * 1/W). No-op for a single process."""
-        if self.world == 1:
+        if self.world == 1 and not dist.is_initialized():
             return
         works = [dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                  for (lo, hi) in reversed(self.buckets)]
