@@ -203,6 +203,19 @@ def main():
         gflop = gemm_flops_train(B, L, F, H, E, V) / 1e9
         pair_bytes = step_bytes_fwd(B, H, H) + step_bytes_fwd(B, H, E + H)
 
+        # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh), committed
+        # under profiles/ — counters cannot be collected from inside this process.  Only valid for the default workload.
+        pmc = {}
+        try:
+            if B == 64:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic_pmc.json")))["kernels"]
+        except Exception:
+            pmc = {}
+
+        def traffic(kernel):
+            e = pmc.get(kernel)
+            return int(e["hbm_bytes_per_launch"]) if e and "hbm_bytes_per_launch" in e else None
+
         def rooflines(pr, how):
             gemm_ms, gemm_n = pr["gemm"]
             sf_ms = pr["step_fwd"][0]
@@ -217,10 +230,12 @@ def main():
                 gk, gpeak, gnote = "gemm_f32_kernel", MFMA_F32_PEAK_TF, "fp32-input MFMA"
             rg = {"kernel": gk, "bound": "mfma", "achieved": round(gemm_tf, 2),
                   "peak": round(gpeak, 1), "unit": "TFLOP/s", "frac": round(gemm_tf / gpeak, 4),
-                  "traffic": None, "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 3),
+                  "traffic": traffic(gk), "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 3),
+                  "algorithmic_bytes_or_flops_per_launch": round(gflop * 1e9 / max(gemm_n, 1)),
                   "algorithmic_gflop_per_step": round(gflop, 1), "timing": how, "note": gnote}
             rs = {"kernel": "lstm_step_fwd_kernel", "bound": "hbm", "achieved": round(step_gbs, 1),
-                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
+                  "traffic": traffic("lstm_step_fwd_kernel"),
                   "avg_launch_us": round(step_us, 3), "launches_per_step": 2 * T,
                   "algorithmic_bytes_per_launch": pair_bytes // 2, "timing": how,
                   "note": "bytes per SURVEY.md §8(d) incl. W_ih although the x-part is hoisted into a batched GEMM; "

@@ -143,6 +143,35 @@ def gen(name, seed, n_steps, out_scale, do_beam, beam_b=None, beam_width=3, full
     return S2VT, d, sd
 
 
+def gen_beam_only(name, cfg, seed, beam_b, beam_width):
+    """BASELINE config 5 dims (H=E=1000, V=12000), a few samples: reference beam-search ids (beam 5, depth 30) and
+    greedy ids; the reference needs ~16 s per caption on CPU, so only `beam_b` samples are generated."""
+    S2VT, _ = _reference()
+    d = dict(synth.CONFIGS[cfg]); d["B"] = beam_b
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed)
+    feats, caps, mask = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
+    m = _ref_model(S2VT, d, sd)
+    m.eval()
+    t0 = time.time()
+    with torch.no_grad():
+        ref_beam = m(feats, mode="beam_search", beam_width=beam_width, max_beam_depth=30)
+        ids = m(feats, mode="test")
+    ref_beam = [[int(t.item()) for t in s] for s in ref_beam]
+    print(f"[{name}] reference beam(bw={beam_width}, B={beam_b}): {time.time()-t0:.1f}s")
+    o_beam = orc.beam_search(sd, feats, beam_width=beam_width, max_depth=30)
+    assert o_beam == ref_beam, (o_beam, ref_beam)
+    oids, marg = orc.greedy_decode(sd, feats, return_margins=True)
+    assert (ids == oids).all()
+    mx = max(len(s) for s in ref_beam)
+    arr = -np.ones((beam_b, mx), dtype=np.int64)
+    for i, s in enumerate(ref_beam):
+        arr[i, :len(s)] = s
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), seed=seed, out_scale=1.0, beam_width=np.array(beam_width),
+                        dims=np.array([d[k] for k in "BLFHEV"], dtype=np.int64), beam_ids=arr, greedy_ids=ids.numpy(),
+                        greedy_margin=marg.numpy())
+    print(f"[{name}] wrote {name}.npz; oracle beam == reference beam")
+
+
 def gen_pickle():
     """A full-module pickle WRITTEN BY THE REFERENCE class (train.py:167-168 style) at tiny
     dims, to test that the drop-in S2VTModel.S2VT loads reference checkpoints."""
@@ -174,3 +203,5 @@ if __name__ == "__main__":
         gen("c1", seed=11, n_steps=3, out_scale=1.0, do_beam=True, beam_b=2, beam_width=5)
     if "c2" in which:
         gen("c2", seed=21, n_steps=2, out_scale=1.0, do_beam=False)
+    if "c5beam" in which:
+        gen_beam_only("c5beam", "c5", seed=31, beam_b=4, beam_width=5)
