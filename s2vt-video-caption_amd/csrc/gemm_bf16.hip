@@ -12,6 +12,8 @@
 // (split.hip), which write each consumer's k-major planes once, so this kernel stays a pure streaming MFMA loop:
 // 128x128x32 tile, 4 waves x (2x2) 32x32 MFMA tiles, padded LDS rows (80 B: conflict-free ds_read_b128),
 // register prefetch of the next k-tile, XCD-aware grouped tile order, optional deterministic split-K.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -25,13 +27,16 @@ constexpr int HBM_ = 128, HBN = 128;
 //   r * ld + (k / 32) * (32 * NP) + pl * 32 + (k % 32),   ld = NP * Kpad, Kpad = K rounded up to 32 (zero filled)
 // so the NP planes of one 32-wide k chunk of a row are adjacent: a k-tile reads NP*64 contiguous bytes per row
 // (192 B for NP = 3) instead of NP scattered 64-B segments.
-template <int NP> struct BfCfg {
-    static constexpr int BK = (NP == 3) ? 32 : 64;         // k per tile (NP = 3: 2 workgroups/CU by LDS; NP = 1: full lines)
+template <int NP, int WM> struct BfCfg {
+    static constexpr int TM = 64 * WM;                     // tile rows: WM x 2 waves, each 64x64
+    static constexpr int NTH = 128 * WM;                   // threads
+    static constexpr int BK = (NP == 3) ? 32 : 64;         // k per tile (NP = 3: LDS budget; NP = 1: full 128-B lines)
     static constexpr int ROWB = NP * BK * 2;               // data bytes per tile row
     static constexpr int HROW = ROWB + 16;                 // + 16 B pad: odd number of 16-B slots, conflict-free b128
     static constexpr int PPR = ROWB / 16;                  // 16-B pieces per row
-    static constexpr int NPC = HBM_ * PPR / 256;           // pieces per thread per operand
-    static constexpr int IMG = HBM_ * HROW;                // bytes per operand image
+    static constexpr int NPA = TM * PPR / NTH;             // pieces per thread, A operand
+    static constexpr int NPB = HBN * PPR / NTH;            // pieces per thread, B operand
+    static constexpr int IMGA = TM * HROW, IMGB = HBN * HROW;
 };
 
 struct GemmBfArgs {
@@ -45,64 +50,77 @@ struct GemmBfArgs {
     float* slabs;
 };
 
-template <int NP>
-__global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmBfArgs p) {
-    typedef BfCfg<NP> Cf;
-    constexpr int HBK = Cf::BK, HROW = Cf::HROW, PPR = Cf::PPR, NPC = Cf::NPC;
+template <int NP, int WM>
+__global__ __launch_bounds__(128 * WM) void gemm_bf16_nt_kernel(GemmBfArgs p) {
+    typedef BfCfg<NP, WM> Cf;
+    constexpr int HBK = Cf::BK, HROW = Cf::HROW, PPR = Cf::PPR, NPA = Cf::NPA, NPB = Cf::NPB, NTH = Cf::NTH, TM = Cf::TM;
 #ifndef S2VT_X3_LDS_PAD
 #define S2VT_X3_LDS_PAD 0
 #endif
-    // S2VT_X3_LDS_PAD > 0 (experiment): inflate the LDS footprint so fewer GEMM workgroups share a CU, leaving room
-    // for timestep workgroups of the other pipeline lane to co-reside
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * Cf::IMG + S2VT_X3_LDS_PAD];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Cf::IMGA + Cf::IMGB + S2VT_X3_LDS_PAD];
     unsigned char* sA = smem;
-    unsigned char* sB = smem + Cf::IMG;
+    unsigned char* sB = smem + Cf::IMGA;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int ntn = (p.N + HBN - 1) / HBN, ntm = (p.M + HBM_ - 1) / HBM_;
+    const int ntn = (p.N + HBN - 1) / HBN, ntm = (p.M + TM - 1) / TM;
     const int nwg = ntm * ntn, cpx = (nwg + 7) >> 3;
     const int t = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= cpx || t >= nwg) return;
-    constexpr int GM = 8;
+    constexpr int GM = (WM == 2) ? 8 : 4;
     const int gsz = GM * ntn, grp = t / gsz, first_m = grp * GM;
     const int gm = (ntm - first_m < GM) ? (ntm - first_m) : GM;
     const int tm = first_m + (t % gsz) % gm, tn = (t % gsz) / gm;
-    const int m0 = tm * HBM_, n0 = tn * HBN;
+    const int m0 = tm * TM, n0 = tn * HBN;
     const int kbeg = blockIdx.y * p.ksplit;
     const int kend = (kbeg + p.ksplit < p.K) ? kbeg + p.ksplit : p.K;      // multiples of HBK (K is padded)
 
-    // staging: 128 rows x PPR 16-B pieces per operand; thread -> pieces tid + 256 i; piece q: row q / PPR,
-    // byte column (q % PPR) * 16 of the row's contiguous NP*BK*2-byte run -> consecutive lanes sweep whole rows
-    const unsigned short* a_src[NPC];
-    const unsigned short* b_src[NPC];
+    // staging: rows x PPR 16-B pieces per operand; thread -> pieces tid + NTH i; piece q: row q / PPR, byte column
+    // (q % PPR) * 16 of the row's contiguous NP*BK*2-byte run -> consecutive lanes sweep whole rows
+    const unsigned short* a_src[NPA];
+    const unsigned short* b_src[NPB];
     const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero4);
 #pragma unroll
-    for (int i = 0; i < NPC; ++i) {
-        const int q = tid + 256 * i, row = q / PPR;
+    for (int i = 0; i < NPA; ++i) {
+        const int q = tid + NTH * i, row = q / PPR;
         a_src[i] = (m0 + row < p.M) ? p.A + (int64_t)(m0 + row) * p.lda + (q % PPR) * 8 : nullptr;
+    }
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int q = tid + NTH * i, row = q / PPR;
         b_src[i] = (n0 + row < p.N) ? p.B + (int64_t)(n0 + row) * p.ldb + (q % PPR) * 8 : nullptr;
     }
 
-    u32x4 ra[NPC], rb[NPC];
-    auto load_tile = [&](int k0) {
+    u32x4 ra0[NPA], rb0[NPB], ra1[NPA], rb1[NPB];   // two staging sets: tiles kt+1 and kt+2 in flight
+    auto load_tile = [&](int k0, u32x4 (&ra)[NPA], u32x4 (&rb)[NPB]) {
+#if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE == 1     // timing experiment: no global traffic
+        for (int i = 0; i < NPA; ++i) ra[i] = u32x4{0x3f803f80u, 0, 0, 0};
+        for (int i = 0; i < NPB; ++i) rb[i] = u32x4{0x3f803f80u, 0, 0, 0};
+        return;
+#endif
         const bool kin = k0 < kend;
 #pragma unroll
-        for (int i = 0; i < NPC; ++i) {
+        for (int i = 0; i < NPA; ++i) {
             const unsigned short* qa = (kin && a_src[i]) ? a_src[i] + (int64_t)k0 * NP : zero;
-            const unsigned short* qb = (kin && b_src[i]) ? b_src[i] + (int64_t)k0 * NP : zero;
             ra[i] = *reinterpret_cast<const u32x4*>(qa);
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const unsigned short* qb = (kin && b_src[i]) ? b_src[i] + (int64_t)k0 * NP : zero;
             rb[i] = *reinterpret_cast<const u32x4*>(qb);
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](const u32x4 (&ra)[NPA], const u32x4 (&rb)[NPB]) {
 #pragma unroll
-        for (int i = 0; i < NPC; ++i) {
-            const int q = tid + 256 * i;
-            const int off = (q / PPR) * HROW + (q % PPR) * 16;
-            *reinterpret_cast<u32x4*>(sA + off) = ra[i];
-            *reinterpret_cast<u32x4*>(sB + off) = rb[i];
+        for (int i = 0; i < NPA; ++i) {
+            const int q = tid + NTH * i;
+            *reinterpret_cast<u32x4*>(sA + (q / PPR) * HROW + (q % PPR) * 16) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int q = tid + NTH * i;
+            *reinterpret_cast<u32x4*>(sB + (q / PPR) * HROW + (q % PPR) * 16) = rb[i];
         }
     };
 
@@ -114,12 +132,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmBfArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const int nkt = (kend - kbeg + HBK - 1) / HBK;
-    load_tile(kbeg);
-    for (int kt = 0; kt < nkt; ++kt) {
-        store_tile();
-        __syncthreads();
-        load_tile(kbeg + (kt + 1) * HBK);      // past-the-end tiles read the zero block
+    auto compute_tile = [&]() {
 #pragma unroll
         for (int c = 0; c < HBK / 16; ++c) {
             // A operand lane map of 32x32x16 bf16: lane (r = l&31, h = l>>5) holds A[row r][k = 8h .. 8h+7].
@@ -135,6 +148,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmBfArgs p) {
                 for (int ni = 0; ni < 2; ++ni)
                     b[pl][ni] = *reinterpret_cast<const bf16x8*>(sB + (wn * 64 + ni * 32 + li) * HROW + koff);
             }
+#if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE == 2     // timing experiment: operands staged and read, no MFMA
+#pragma unroll
+            for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) asm volatile("" ::"v"(a[pl][mi]), "v"(b[pl][mi]));
+            if (true) continue;
+#endif
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -149,7 +169,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_nt_kernel(GemmBfArgs p) {
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0][mi], b[0][ni], acc[mi][ni], 0, 0, 0);
                 }
         }
+    };
+    // The L2->LDS path of this kernel runs near the L2 bandwidth limit, so a load's latency exceeds one tile's MFMA
+    // phase: tiles are requested TWO iterations ahead (two register sets, loop unrolled by two so both are
+    // statically indexed).  LDS (61 KB at NP = 3) already limits residency to 2 workgroups/CU, so the extra
+    // registers cost no occupancy.
+    const int nkt = (kend - kbeg + HBK - 1) / HBK;
+    load_tile(kbeg, ra0, rb0);
+    load_tile(kbeg + HBK, ra1, rb1);               // past-the-end tiles read the zero block
+    for (int kt = 0; kt < nkt; kt += 2) {
+        store_tile(ra0, rb0);
         __syncthreads();
+        load_tile(kbeg + (kt + 2) * HBK, ra0, rb0);
+        compute_tile();
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            store_tile(ra1, rb1);
+            __syncthreads();
+            load_tile(kbeg + (kt + 3) * HBK, ra1, rb1);
+            compute_tile();
+            __syncthreads();
+        }
     }
 
 #pragma unroll
@@ -199,7 +239,12 @@ int gemm_bf16_nt(hipStream_t stream, int nplanes, int M, int N, int K, const uns
     p.A = A; p.lda = lda;
     p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.cmap = cmap; p.bias = bias; p.accumulate = accumulate ? 1 : 0;
-    const int tiles = cdiv(M, HBM_) * cdiv(N, HBN);
+    // 256x128 tiles (8 waves, 25 % fewer L2->LDS bytes per flop) are kept as an option (S2VT_X3_WM=4); measured
+    // 5-10 % slower than 128x128 with two workgroups per CU on every shape of the path, so 128x128 is the default.
+    static int force_wm = -1;
+    if (force_wm < 0) { const char* e = getenv("S2VT_X3_WM"); force_wm = e ? atoi(e) : 2; }
+    const bool wm4 = (force_wm == 4);
+    const int tiles = cdiv(M, wm4 ? 256 : HBM_) * cdiv(N, HBN);
     int nsplit = 1;
     if (splitk_ws && tiles < 1024 && K >= 16 * BKc) {
         double best_eff = 0.0;
@@ -216,8 +261,13 @@ int gemm_bf16_nt(hipStream_t stream, int nplanes, int M, int N, int K, const uns
     if (nsplit > 1) nsplit = cdiv(K, p.ksplit);
     p.slabs = (nsplit > 1) ? splitk_ws : nullptr;
     const dim3 grid(cdiv(tiles, 8) * 8, nsplit);
-    if (nplanes == 3) hipLaunchKernelGGL((gemm_bf16_nt_kernel<3>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<1>), grid, dim3(256), 0, stream, p);
+    if (wm4) {
+        if (nplanes == 3) hipLaunchKernelGGL((gemm_bf16_nt_kernel<3, 4>), grid, dim3(512), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 4>), grid, dim3(512), 0, stream, p);
+    } else {
+        if (nplanes == 3) hipLaunchKernelGGL((gemm_bf16_nt_kernel<3, 2>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 2>), grid, dim3(256), 0, stream, p);
+    }
     S2VT_LAUNCH_CHECK("gemm_bf16_nt_kernel");
     if (nsplit > 1) return splitk_reduce(stream, splitk_ws, nsplit, M, N, C, ldc, cmap, bias, accumulate);
     return 0;

@@ -8,9 +8,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
-from s2vt_video_caption_amd import capi  # noqa: E402
+from s2vt_video_caption_amd import build, capi  # noqa: E402
 
 lib = capi.load()
+if os.environ.get("X3_DEFS"):       # experiment: a variant library built with extra -D defines
+    os.makedirs(os.path.join(ROOT, "gpurun_out", "variants"), exist_ok=True)
+    lib = ctypes.CDLL(build.build(defines=os.environ["X3_DEFS"].split(","),
+                                  out_path=os.path.join(ROOT, "gpurun_out", "variants", "libx3_%s.so" % os.environ["X3_DEFS"].replace("=", "").replace(",", "_"))))
 dev = "cuda:0"
 vp = ctypes.c_void_p
 i64 = ctypes.c_int64
