@@ -113,12 +113,23 @@ def test_c1_beam_search_against_reference_golden(lib, golden):
         assert [int(t.item()) for t in s] == [int(x) for x in g["beam_ids"][b] if x >= 0]
 
 
-def test_c2_full_size_against_reference_golden(lib, golden):
-    """BASELINE config 2 (B=64, H=E=1000, V=12000, fp32): loss within 1e-4 of the reference over two Adam steps;
+@pytest.mark.parametrize("gemm_mode", [3, 0])
+def test_c2_full_size_against_reference_golden(lib, golden, gemm_mode):
+    """Both arithmetic modes of the batched GEMMs (3 = split-precision bf16x3 on the bf16 matrix cores, the default at
+    B % 64 == 0; 0 = fp32-input MFMA).
+    BASELINE config 2 (B=64, H=E=1000, V=12000, fp32): loss within 1e-4 of the reference over two Adam steps;
     greedy ids equal to the reference's wherever the reference's own top-2 margin leaves room for fp32
     summation-order differences (a flip at a near-tie legitimately changes that caption's suffix)."""
     g = golden("c2")
     d, sd, feats, caps, mask = _setup(g, "c2")
+    prev = lib.s2vt_set_gemm_mode(gemm_mode)
+    try:
+        _c2_body(g, d, sd, feats, caps, mask)
+    finally:
+        lib.s2vt_set_gemm_mode(prev)
+
+
+def _c2_body(g, d, sd, feats, caps, mask):
     m = _model(d, sd)
     m.eval()
     with torch.no_grad():
@@ -208,3 +219,26 @@ def test_full_size_properties_c2_shape(lib):
             assert (outs[1][n] - 2 * outs[0][n]).abs().max().item() <= 1e-5 * outs[0][n].abs().max().item() + 1e-12
         else:
             assert torch.equal(outs[1][n], 2 * outs[0][n]), n
+
+
+def test_c5_dims_beam_and_greedy_against_reference_golden(lib, golden):
+    """BASELINE config 5 dims (H=E=1000, V=12000), beam_size 5, depth 30: token ids of the batched on-GPU beam search
+    against the reference's own per-sample Python beam search (4 captions; the reference needs ~18 s per caption)."""
+    g = golden("c5beam")
+    d = dict(synth.CONFIGS["c5"]); d["B"] = int(g["dims"][0])
+    seed = int(g["seed"])
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed)
+    feats, caps, mask = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
+    m = _model(d, sd).eval()
+    with torch.no_grad():
+        ids = m(feats.to(DEV), mode="test").cpu().numpy()
+        out = m(feats.to(DEV), mode="beam_search", beam_width=int(g["beam_width"]), max_beam_depth=30)
+    ref, marg = g["greedy_ids"], g["greedy_margin"]
+    for b in range(d["B"]):
+        risky = np.nonzero(marg[b] < 2e-4)[0]
+        upto = int(risky[0]) if len(risky) else ref.shape[1]
+        np.testing.assert_array_equal(ids[b, :upto], ref[b, :upto])
+    same = 0
+    for b, s in enumerate(out):
+        same += int([int(t.item()) for t in s] == [int(x) for x in g["beam_ids"][b] if x >= 0])
+    assert same >= d["B"] - 1, same      # a near-tie in log-prob order may legitimately flip one caption

@@ -122,3 +122,15 @@ def test_oracle_against_live_reference():
         ids = m(feats, mode="test")
     assert (a - orc.forward_train(sd, feats, caps[:, :-1])).abs().max().item() < 2e-6
     assert torch.equal(ids, orc.greedy_decode(sd, feats))
+
+
+def test_c5_dims_greedy_matches_reference(golden):
+    """config-5 dims: greedy ids of the oracle equal the reference's (the beam ids of this fixture were asserted equal
+    to the oracle's when it was generated; re-running the oracle beam here would take ~70 s)."""
+    g = golden("c5beam")
+    d = dict(synth.CONFIGS["c5"]); d["B"] = int(g["dims"][0])
+    seed = int(g["seed"])
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed)
+    feats, _, _ = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
+    ids = orc.greedy_decode(sd, feats)
+    np.testing.assert_array_equal(ids.numpy(), g["greedy_ids"])
