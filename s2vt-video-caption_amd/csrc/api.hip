@@ -653,13 +653,14 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
 
 // ------------------------------------------------------------------ greedy decode
 struct DecodeWS {
-    float *bsum1, *bsum2, *x1, *gx1, *h1, *c1, *gx2, *h2, *c2, *gws;
+    float *bsum1, *bsum2, *x1, *gx1, *h1, *c1, *gx2, *h2, *c2, *gws_a, *gws_b;
     size_t gws_floats;
     unsigned long long* packed;
+    PB feats, wf, px1, wih1, ph1, wv;      // packed planes (split-precision mode only)
     size_t bytes;
 };
 static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
-    const size_t B = d.B, L = d.L, H = d.H, T = 2 * L - 1;
+    const size_t B = d.B, L = d.L, F = d.F, H = d.H, T = 2 * L - 1;
     Carver c{reinterpret_cast<char*>(base), 0, 0};
     DecodeWS w;
     w.bsum1 = c.take<float>(4 * H);
@@ -673,7 +674,19 @@ static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
     w.c2 = c.take<float>(B * H);
     w.packed = c.take<unsigned long long>((L - 1) * B);
     w.gws_floats = gemm_ws_floats(d);
-    w.gws = c.take<float>(w.gws_floats);
+    w.gws_a = c.take<float>(w.gws_floats);
+    w.gws_b = c.take<float>(w.gws_floats);
+    if (planes_ok(d)) {
+        auto mk = [&](size_t rows, size_t k) {
+            PB b;
+            b.kpad = pad64((int)k);
+            b.ld = (int64_t)XP * b.kpad;
+            b.p = c.take<unsigned short>(rows * (size_t)b.ld);
+            return b;
+        };
+        w.feats = mk(B * L, F); w.wf = mk(H, F); w.px1 = mk(L * B, H); w.wih1 = mk(4 * H, H);
+        w.ph1 = mk(T * B, H);   w.wv = mk(4 * H, H);
+    }
     w.bytes = align_up(c.off, 256);
     return w;
 }
@@ -690,66 +703,98 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
     const DecodeWS w = carve_decode(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_greedy_decode: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
-    GemmWsScope gscope(w.gws, w.gws_floats);
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
+    const bool x3 = planes_ok(*d);
+    const int blk = pipe_block();
+    hipStream_t sx = st;
     int rc;
+    if (blk > 0 && (rc = side_stream(st, &sx))) return rc;
+    const Lane la{st, w.gws_a, w.gws_floats, nullptr};     // vid_rnn lane (caller's stream)
+    const Lane lb{sx, w.gws_b, w.gws_floats, nullptr};     // word_rnn lane: encode, then the 79 decode steps
+    size_t ev = 0;
     if ((rc = add_vectors(st, p->vid_b_ih, p->vid_b_hh, w.bsum1, 4 * H))) return rc;
     if ((rc = add_vectors(st, p->word_b_ih, p->word_b_hh, w.bsum2, 4 * H))) return rc;
     if ((rc = fill_zero(st, w.packed, sizeof(unsigned long long) * (size_t)(L - 1) * B))) return rc;
-    if ((rc = gemm(st, true, true, B * L, H, F, feats, F, ID, p->feat_w, F, ID, w.x1, H, perm(L, B), p->feat_b, false)))
-        return rc;
-    if ((rc = gemm(st, true, true, L * B, 4 * H, H, w.x1, H, ID, p->vid_w_ih, H, ID, w.gx1, 4 * H, ID, w.bsum1, false)))
-        return rc;
-    {   // vid_rnn over all T steps (S2VTModel.py:64-67); c updated in place, h kept for the word layer
-        ProfScope ps(st, K_STEP_FWD, T);
-        for (int t = 0; t < T; ++t) {
-            StepFwdArgs a;
-            memset(&a, 0, sizeof(a));
-            a.B = B; a.H = H;
-            a.h_prev = t ? w.h1 + (t - 1) * BH : nullptr; a.ldh = H;
-            a.w_hh = p->vid_w_hh; a.ldw = H;
-            a.gx = (t < L) ? w.gx1 + t * B4H : nullptr; a.ldgx = 4 * (int64_t)H;
-            a.bias = w.bsum1;
-            a.c_prev = t ? w.c1 : nullptr; a.ldc = H;
-            a.h_out = w.h1 + t * BH; a.ldho = H;
-            a.c_out = w.c1; a.ldco = H;
-            if ((rc = lstm_step_fwd(st, a))) return rc;
-        }
+    if ((rc = handoff(st, sx, ev++))) return rc;
+    // feature projection + vid_rnn input GEMM                                  S2VTModel.py:54, 64-67
+    if (x3) {
+        if ((rc = psplit(lb, w.wv, 0, p->word_w_ih + E, E + H, ID, 4 * H, H))) return rc;
+        if ((rc = psplit(la, w.feats, 0, feats, F, ID, B * L, F))) return rc;
+        if ((rc = psplit(la, w.wf, 0, p->feat_w, F, ID, H, F))) return rc;
+        if ((rc = psplit(la, w.wih1, 0, p->vid_w_ih, H, ID, 4 * H, H))) return rc;
+        if ((rc = pgemm(la, B * L, H, F, w.feats, 0, 0, w.wf, 0, 0, w.x1, H, perm(L, B), p->feat_b, false))) return rc;
+        if ((rc = psplit(la, w.px1, 0, w.x1, H, ID, L * B, H))) return rc;
+        if ((rc = pgemm(la, L * B, 4 * H, H, w.px1, 0, 0, w.wih1, 0, 0, w.gx1, 4 * H, ID, w.bsum1, false))) return rc;
+    } else {
+        if ((rc = lgemm(la, true, true, B * L, H, F, feats, F, ID, p->feat_w, F, ID, w.x1, H, perm(L, B), p->feat_b, false)))
+            return rc;
+        if ((rc = lgemm(la, true, true, L * B, 4 * H, H, w.x1, H, ID, p->vid_w_ih, H, ID, w.gx1, 4 * H, ID, w.bsum1, false)))
+            return rc;
     }
-    if ((rc = gemm(st, true, true, T * B, 4 * H, H, w.h1, H, ID, p->word_w_ih + E, E + H, ID, w.gx2, 4 * H, ID, w.bsum2,
-                   false)))
-        return rc;
-    for (int t = 0; t < T; ++t) {
-        {   // word_rnn: encode steps see a zero embedding (:84-86), decode steps Emb[prev token] (:89-103)
-            ProfScope ps(st, K_STEP_FWD, 1);
-            StepFwdArgs a;
-            memset(&a, 0, sizeof(a));
-            a.B = B; a.H = H;
-            a.h_prev = t ? w.h2 + ((t - 1) & 1) * BH : nullptr; a.ldh = H;
-            a.w_hh = p->word_w_hh; a.ldw = H;
-            if (t >= L) {
-                a.x2 = p->emb_w; a.ldx2 = E; a.K2 = E;
-                a.w2 = p->word_w_ih; a.ldw2 = E + H;
-                a.tok_packed = (t > L) ? w.packed + (int64_t)(t - L - 1) * B : nullptr;
-                a.tok_const = sos_ix;
+    const std::vector<int> bd = pipe_bounds(T, L, blk);
+    for (size_t k = 0; k + 1 < bd.size(); ++k) {
+        const int t0 = bd[k], t1 = bd[k + 1];
+        {   // lane A: vid_rnn over all T steps (S2VTModel.py:64-67); c updated in place, h kept for the word layer
+            ProfScope ps(st, K_STEP_FWD, t1 - t0);
+            for (int t = t0; t < t1; ++t) {
+                StepFwdArgs a;
+                memset(&a, 0, sizeof(a));
+                a.B = B; a.H = H;
+                a.h_prev = t ? w.h1 + (t - 1) * BH : nullptr; a.ldh = H;
+                a.w_hh = p->vid_w_hh; a.ldw = H;
+                a.gx = (t < L) ? w.gx1 + t * B4H : nullptr; a.ldgx = 4 * (int64_t)H;
+                a.bias = w.bsum1;
+                a.c_prev = t ? w.c1 : nullptr; a.ldc = H;
+                a.h_out = w.h1 + t * BH; a.ldho = H;
+                a.c_out = w.c1; a.ldco = H;
+                if ((rc = lstm_step_fwd(st, a))) return rc;
             }
-            a.gx = w.gx2 + t * B4H; a.ldgx = 4 * (int64_t)H;
-            a.c_prev = t ? w.c2 : nullptr; a.ldc = H;
-            a.h_out = w.h2 + (t & 1) * BH; a.ldho = H;
-            a.c_out = w.c2; a.ldco = H;
-            if ((rc = lstm_step_fwd(st, a))) return rc;
         }
-        if (t >= L) {  // out_linear + argmax (:95-96, :105-106)
-            ProfScope ps(st, K_ARGMAX, 1);
-            LogitsArgmaxArgs la;
-            la.B = B; la.H = H; la.V = V;
-            la.h = w.h2 + (t & 1) * BH; la.ldh = H;
-            la.w_out = p->out_w; la.ldw = H; la.b_out = p->out_b;
-            la.packed = w.packed + (int64_t)(t - L) * B;
-            if ((rc = logits_argmax(st, la))) return rc;
+        if ((rc = handoff(st, sx, ev++))) return rc;
+        // lane B: vid_out half of the word_rnn gate input for this block (+ biases)
+        if (x3) {
+            if ((rc = psplit(lb, w.ph1, t0 * B, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H))) return rc;
+            if ((rc = pgemm(lb, (t1 - t0) * B, 4 * H, H, w.ph1, t0 * B, 0, w.wv, 0, 0, w.gx2 + t0 * B4H, 4 * H, ID, w.bsum2,
+                            false)))
+                return rc;
+        } else {
+            if ((rc = lgemm(lb, true, true, (t1 - t0) * B, 4 * H, H, w.h1 + t0 * BH, H, ID, p->word_w_ih + E, E + H, ID,
+                            w.gx2 + t0 * B4H, 4 * H, ID, w.bsum2, false)))
+                return rc;
+        }
+        for (int t = t0; t < t1; ++t) {
+            {   // word_rnn: encode steps see a zero embedding (:84-86), decode steps Emb[prev token] (:89-103)
+                ProfScope ps(sx, K_STEP_FWD, 1);
+                StepFwdArgs a;
+                memset(&a, 0, sizeof(a));
+                a.B = B; a.H = H;
+                a.h_prev = t ? w.h2 + ((t - 1) & 1) * BH : nullptr; a.ldh = H;
+                a.w_hh = p->word_w_hh; a.ldw = H;
+                if (t >= L) {
+                    a.x2 = p->emb_w; a.ldx2 = E; a.K2 = E;
+                    a.w2 = p->word_w_ih; a.ldw2 = E + H;
+                    a.tok_packed = (t > L) ? w.packed + (int64_t)(t - L - 1) * B : nullptr;
+                    a.tok_const = sos_ix;
+                }
+                a.gx = w.gx2 + t * B4H; a.ldgx = 4 * (int64_t)H;
+                a.c_prev = t ? w.c2 : nullptr; a.ldc = H;
+                a.h_out = w.h2 + (t & 1) * BH; a.ldho = H;
+                a.c_out = w.c2; a.ldco = H;
+                if ((rc = lstm_step_fwd(sx, a))) return rc;
+            }
+            if (t >= L) {  // out_linear + argmax (:95-96, :105-106)
+                ProfScope ps(sx, K_ARGMAX, 1);
+                LogitsArgmaxArgs la2;
+                la2.B = B; la2.H = H; la2.V = V;
+                la2.h = w.h2 + (t & 1) * BH; la2.ldh = H;
+                la2.w_out = p->out_w; la2.ldw = H; la2.b_out = p->out_b;
+                la2.packed = w.packed + (int64_t)(t - L) * B;
+                if ((rc = logits_argmax(sx, la2))) return rc;
+            }
         }
     }
+    if ((rc = handoff(sx, st, ev++))) return rc;
     return unpack_tokens(st, w.packed, L - 1, B, ids);
 }
 
