@@ -104,6 +104,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="batch per GPU (BASELINE configs[1]: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decode-batch", type=int, default=None)
+    ap.add_argument("--gemm-mode", type=int, default=None, choices=[0, 1, 3],
+                    help="0 fp32-input MFMA, 3 split-precision bf16x3 (default, fp32-equivalent), 1 bf16 operands "
+                         "(BASELINE configs[2]: use with --batch 256)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -124,6 +127,9 @@ def main():
     import utils
     from s2vt_video_caption_amd import capi, dp, synth
     lib = capi.load()
+    if args.gemm_mode is not None:
+        lib.s2vt_set_gemm_mode(args.gemm_mode)
+    mode = lib.s2vt_set_gemm_mode(-1)
 
     L, F, H, E, V = 80, 4096, 1000, 1000, 12000
     B = args.batch
@@ -199,9 +205,11 @@ def main():
             return {k: (ms / nprof, n // nprof) for k, (ms, n) in r.items()}
 
         T = 2 * L - 1
-        x3 = (lib.s2vt_set_gemm_mode(-1) == 3) and (B % 64 == 0)
+        x3 = (mode == 3) and (B % 64 == 0)
+        bf = (mode == 1) and (B % 64 == 0)
+        esz = 2 if bf else 4
         gflop = gemm_flops_train(B, L, F, H, E, V) / 1e9
-        pair_bytes = step_bytes_fwd(B, H, H) + step_bytes_fwd(B, H, E + H)
+        pair_bytes = step_bytes_fwd(B, H, H, s=esz) + step_bytes_fwd(B, H, E + H, s=esz)
 
         # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh), committed
         # under profiles/ — counters cannot be collected from inside this process.  Only valid for the default workload.
@@ -222,7 +230,9 @@ def main():
             gemm_tf = gflop / gemm_ms                 # GFLOP / ms = TFLOP/s
             step_us = sf_ms * 1e3 / (2 * T)           # average launch of lstm_step_fwd_kernel (both layers)
             step_gbs = (pair_bytes / 2) / (step_us * 1e-6) / 1e9
-            if x3:   # each algorithmic fp32 product costs six bf16 MFMA products (three planes per operand)
+            if bf:
+                gk, gpeak, gnote = "gemm_bf16_nt_kernel<1>", MFMA_BF16_PEAK_TF, "bf16 operands, fp32 accumulate"
+            elif x3:   # each algorithmic fp32 product costs six bf16 MFMA products (three planes per operand)
                 gk, gpeak = "gemm_bf16_nt_kernel<3>", MFMA_BF16_PEAK_TF / 6.0
                 gnote = ("achieved = algorithmic (fp32-equivalent) FLOP/s; peak = bf16 dense MFMA peak / 6 plane products; "
                          "executed MFMA rate = 6 x achieved")
@@ -233,7 +243,7 @@ def main():
                   "traffic": traffic(gk), "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 3),
                   "algorithmic_bytes_or_flops_per_launch": round(gflop * 1e9 / max(gemm_n, 1)),
                   "algorithmic_gflop_per_step": round(gflop, 1), "timing": how, "note": gnote}
-            rs = {"kernel": "lstm_step_fwd_kernel", "bound": "hbm", "achieved": round(step_gbs, 1),
+            rs = {"kernel": "lstm_step_fwd_bf16_kernel" if bf else "lstm_step_fwd_kernel", "bound": "hbm", "achieved": round(step_gbs, 1),
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
                   "traffic": traffic("lstm_step_fwd_kernel"),
                   "avg_launch_us": round(step_us, 3), "launches_per_step": 2 * T,
@@ -249,7 +259,7 @@ def main():
         log("profiled steps done (pipeline block %d)" % prev_blk)
         roof_gemm, roof_step = rooflines(live, "live, layers pipelined on two streams (block %d)" % prev_blk)
         roof_gemm_alone, roof_step_alone = rooflines(alone, "pipeline off: every kernel alone on the GPU")
-        gname = "gemm_bf16_nt_kernel<3>" if x3 else "gemm_f32_kernel"
+        gname = "gemm_bf16_nt_kernel<1>" if bf else ("gemm_bf16_nt_kernel<3>" if x3 else "gemm_f32_kernel")
         fam = {gname: live["gemm"][0], "lstm_step_fwd_kernel": live["step_fwd"][0],
                "lstm_step_bwd_kernel": live["step_bwd"][0], "ce": live["ce"][0]}
         fam_alone = {gname: alone["gemm"][0], "lstm_step_fwd_kernel": alone["step_fwd"][0],
@@ -309,12 +319,17 @@ def main():
         out = {
             "metric": "training frames/sec (whole node)", "value": round(frames_per_s, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf else "f32",
+            "data": "synthetic",
             "arithmetic": ("fp32 storage and accumulation; batched GEMM products as 3 bf16 planes x 6 plane products on the bf16 "
                            "matrix cores (fp32-equivalent, ~2^-23 relative), recurrent GEMMs on the fp32-input MFMA"
-                           if x3 else "fp32 storage, fp32-input MFMA, fp32 accumulation"),
-            "config": {"workload": "BASELINE configs[1]: S2VT train step, B=%d per GPU x %d GPU, 80x4096 feats, "
-                                   "hidden=embed=1000, vocab=12000, fp32, Adam" % (B, world),
+                           if x3 else ("bf16 operands (weights, activations) on the bf16 matrix cores for batched and recurrent "
+                                       "GEMMs; fp32 accumulation, cell state, gate stash, gradients, master weights and Adam"
+                                       if bf else "fp32 storage, fp32-input MFMA, fp32 accumulation")),
+            "config": {"workload": ("BASELINE configs[2]: S2VT train step, B=%d per GPU x %d GPU, 80x4096 feats, hidden=embed=1000, "
+                                    "vocab=12000, bf16 operands / fp32 accumulate, Adam" % (B, world)) if bf else
+                                   ("BASELINE configs[1]: S2VT train step, B=%d per GPU x %d GPU, 80x4096 feats, "
+                                    "hidden=embed=1000, vocab=12000, fp32, Adam" % (B, world)),
                        "global_batch": B * world, "frames": L, "parallelism": "dp%d" % world},
             "final_loss": round(final_loss, 6), "host_enqueue_ms_per_step": round(host_ms, 3),
             "pipeline_streams_overlap": int(lib.s2vt_pipeline_overlaps()),

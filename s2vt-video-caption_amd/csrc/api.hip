@@ -308,27 +308,29 @@ static std::vector<int> pipe_bounds(int T, int L, int blk) {
 // rewritten ONCE per consumer orientation into packed planes by the memory-bound split kernels (split.hip),
 // which also perform every transpose / gather / batch-major<->time-major permutation, so the MFMA kernel only
 // sees k-contiguous operands.  The timestep kernels stay fp32 (they are latency/bandwidth bound, not MFMA bound).
-static int g_gemm_mode = -1;       // 0: fp32 MFMA GEMMs, 3: bf16 x 3 planes
+// 0: fp32-input MFMA GEMMs; 3: split precision, 3 bf16 planes (fp32-equivalent); 1: plain bf16 operands (config 3:
+// bf16 storage, fp32 accumulate) for the batched GEMMs AND the timestep kernels (lstm_bf16.hip)
+static int g_gemm_mode = -1;
+static int norm_mode(int m) { return (m == 3 || m == 1) ? m : 0; }
 static int gemm_mode() {
     if (g_gemm_mode < 0) {
         const char* e = getenv("S2VT_GEMM_MODE");
-        g_gemm_mode = e ? atoi(e) : 3;
-        if (g_gemm_mode != 3) g_gemm_mode = 0;
+        g_gemm_mode = norm_mode(e ? atoi(e) : 3);
     }
     return g_gemm_mode;
 }
-// plane mode needs every k-offset inside a packed operand to be a multiple of 64 (k = time*B + b): B % 64 == 0
-static bool planes_ok(const s2vt_dims& d) { return gemm_mode() == 3 && d.B % 64 == 0; }
+// plane modes need every k-offset inside a packed operand to be a multiple of 64 (k = time*B + b): B % 64 == 0
+static bool planes_ok(const s2vt_dims& d) { return gemm_mode() != 0 && d.B % 64 == 0; }
 
-constexpr int XP = 3;
+static int XP = 3;        // planes per operand of the running plane driver (3 or 1); set by the entry points
 static inline int pad64(int x) { return (x + 63) / 64 * 64; }
 struct PB { unsigned short* p; int64_t ld; int kpad; };       // packed planes of a k-major operand [rows][k]
 
 struct PlaneWS {
     // forward
-    PB feats, wf, x1, wih1, h1, we, wv, emb, h2dec, wo;
+    PB feats, wf, x1, wih1, h1, we, wv, emb, h2r, wo, whh1, whh2;
     // backward
-    PB dlog, woT, dlogT, h2decT, wvT, weT, wih1T, dg2, dg2T, h2T, h1T, embT, dg1, dg1T, x1T, dx1T, featsT;
+    PB dlog, woT, dlogT, h2decT, wvT, weT, wih1T, dg2, dg2T, h2T, h1T, embT, dg1, dg1T, x1T, dx1T, featsT, whh1T, whh2T;
     size_t bytes;
 };
 
@@ -345,11 +347,16 @@ static PlaneWS carve_planes(const s2vt_dims& d, void* base) {
     PlaneWS w;
     w.feats = mk(B * L, F);   w.wf = mk(H, F);       w.x1 = mk(L * B, H);    w.wih1 = mk(4 * H, H);
     w.h1 = mk(T * B, H);      w.we = mk(4 * H, E);   w.wv = mk(4 * H, H);    w.emb = mk(R, E);
-    w.h2dec = mk(R, H);       w.wo = mk(V, H);
+    w.h2r = mk(T * B, H);     w.wo = mk(V, H);
+    if (XP == 1) {            // bf16 mode: recurrent weights as bf16 rows (forward) and transposed rows (BPTT)
+        w.whh1 = mk(4 * H, H); w.whh2 = mk(4 * H, H); w.whh1T = mk(H, 4 * H); w.whh2T = mk(H, 4 * H);
+    } else {
+        w.whh1 = w.whh2 = w.whh1T = w.whh2T = PB{nullptr, 0, 0};
+    }
     w.dlog = mk(R, V);        w.woT = mk(H, V);      w.dlogT = mk(V, R);     w.h2decT = mk(H, R);
     w.wvT = mk(H, 4 * H);     w.weT = mk(E, 4 * H);  w.wih1T = mk(H, 4 * H); w.dg2 = mk(T * B, 4 * H);
     w.dg2T = mk(4 * H, T * B); w.h2T = mk(H, T * B); w.h1T = mk(H, T * B);   w.embT = mk(E, R);
-    w.dg1 = mk(L * B, 4 * H); w.dg1T = mk(4 * H, T * B); w.x1T = mk(H, L * B); w.dx1T = mk(H, L * B);
+    w.dg1 = mk(T * B, 4 * H); w.dg1T = mk(4 * H, T * B); w.x1T = mk(H, L * B); w.dx1T = mk(H, L * B);
     w.featsT = mk(F, L * B);
     w.bytes = align_up(c.off, 256);
     return w;
@@ -379,6 +386,57 @@ static int pgemm(const Lane& ln, int M, int N, int K, const PB& A, int a0, int k
                         B.p + (int64_t)b0 * B.ld + (int64_t)kb * XP, B.ld, C, ldc, cm, bias, acc, ln.gws, ln.gws_floats);
 }
 
+// bf16-operand layer forward over steps [t0, t1): hb = bf16 row images of h (time-major, ld = hb.ld), the k-major
+// plane the batched GEMMs read as well
+static int seq_fwd_bf16(hipStream_t st, int t0, int t1, int B, int H, float* gx_stash, int n_gx, const float* bias,
+                        const PB& wb, const PB& hb, float* h_all, float* c_all) {
+    if (t1 <= t0) return 0;
+    ProfScope ps(st, K_STEP_FWD, t1 - t0);
+    const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
+    for (int t = t0; t < t1; ++t) {
+        StepFwdBf16Args a;
+        memset(&a, 0, sizeof(a));
+        a.B = B; a.H = H; a.Kp = hb.kpad;
+        a.hb_prev = t ? hb.p + (int64_t)(t - 1) * B * hb.ld : nullptr; a.ldhb = hb.ld;
+        a.wb = wb.p; a.ldwb = wb.ld;
+        a.gx = (t < n_gx) ? gx_stash + t * B4H : nullptr; a.ldgx = 4 * (int64_t)H;
+        a.bias = bias;
+        a.c_prev = t ? c_all + (t - 1) * BH : nullptr; a.ldc = H;
+        a.h_out = h_all + t * BH; a.ldho = H;
+        a.hb_out = hb.p + (int64_t)t * B * hb.ld; a.ldhbo = hb.ld;
+        a.c_out = c_all + t * BH; a.ldco = H;
+        a.stash = gx_stash + t * B4H; a.ldst = 4 * (int64_t)H;
+        int rc = lstm_step_fwd_bf16(st, a);
+        if (rc) return rc;
+    }
+    return 0;
+}
+// bf16-operand BPTT over steps t1-1 .. t0: dgb = bf16 row images of dG (time-major), wt = W_hh^T bf16 rows
+static int seq_bwd_bf16(hipStream_t st, int T, int t0, int t1, int B, int H, const PB& wt, const float* dh_out,
+                        int dh_first, const float* c_all, float* stash_dg, const PB& dgb, float* dc) {
+    if (t1 <= t0) return 0;
+    ProfScope ps(st, K_STEP_BWD, t1 - t0);
+    const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
+    for (int t = t1 - 1; t >= t0; --t) {
+        StepBwdBf16Args a;
+        memset(&a, 0, sizeof(a));
+        a.B = B; a.H = H; a.Kp = dgb.kpad;
+        a.dgb_next = (t < T - 1) ? dgb.p + (int64_t)(t + 1) * B * dgb.ld : nullptr; a.lddgb = dgb.ld;
+        a.wtb = wt.p; a.ldwtb = wt.ld;
+        a.dh_out = (dh_out && t >= dh_first) ? dh_out + (int64_t)(t - dh_first) * BH : nullptr; a.lddho = H;
+        a.stash = stash_dg + t * B4H; a.ldst = 4 * (int64_t)H;
+        a.c = c_all + t * BH; a.ldc = H;
+        a.c_prev = t ? c_all + (t - 1) * BH : nullptr; a.ldcp = H;
+        a.dc = dc; a.lddc = H;
+        a.dc_is_zero = (t == T - 1) ? 1 : 0;
+        a.dg = stash_dg + t * B4H; a.lddg = 4 * (int64_t)H;
+        a.dgb = dgb.p + (int64_t)t * B * dgb.ld; a.lddgbo = dgb.ld;
+        int rc = lstm_step_bwd_bf16(st, a);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
                             int64_t targets_ld, float* logits, const TrainWS& w, const PlaneWS& q, hipStream_t st) {
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1, R = (L - 1) * B;
@@ -394,7 +452,14 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
     if ((rc = add_vectors(st, p->word_b_ih, p->word_b_hh, w.bsum2, 4 * H))) return rc;
     if ((rc = fill_zero(st, w.err, 4 * sizeof(int)))) return rc;
     if ((rc = targets_to_time_major(st, targets, B, L - 1, targets_ld, V, w.tok, w.err))) return rc;
+    const bool bf = (XP == 1);        // bf16 mode: bf16 timestep kernels write the h planes themselves
+    if (bf) {   // zero the k padding of the bf16 h row images (valid columns are written by the step kernels)
+        if ((rc = zero_pad_cols_u16(st, q.h1.p, (int64_t)T * B, q.h1.ld, H, q.h1.kpad))) return rc;
+        if ((rc = zero_pad_cols_u16(st, q.h2r.p, (int64_t)T * B, q.h2r.ld, H, q.h2r.kpad))) return rc;
+        if ((rc = pdual(la, p->vid_w_hh, H, ID, 4 * H, H, &q.whh1, 0, &q.whh1T, 0, nullptr))) return rc;
+    }
     if ((rc = handoff(st, sx, ev++))) return rc;
+    if (bf && (rc = pdual(lb, p->word_w_hh, H, ID, 4 * H, H, &q.whh2, 0, &q.whh2T, 0, nullptr))) return rc;
     // lane B: word_rnn / out_linear weights and the embedded caption words as planes; embedded-word half of gx2
     // (row planes for this forward, transposed planes for the coming backward: one read of each tensor)
     if ((rc = pdual(lb, p->word_w_ih, E + H, ID, 4 * H, E, &q.we, 0, &q.weT, 0, nullptr))) return rc;
@@ -412,20 +477,29 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
     const std::vector<int> bd = pipe_bounds(T, L, blk);
     for (size_t k = 0; k + 1 < bd.size(); ++k) {
         const int t0 = bd[k], t1 = bd[k + 1];
-        if ((rc = seq_fwd(st, t0, t1, B, H, w.s1, L, w.bsum1, p->vid_w_hh, w.h1, w.c1, true))) return rc;
+        if (bf) {
+            if ((rc = seq_fwd_bf16(st, t0, t1, B, H, w.s1, L, w.bsum1, q.whh1, q.h1, w.h1, w.c1))) return rc;
+        } else {
+            if ((rc = seq_fwd(st, t0, t1, B, H, w.s1, L, w.bsum1, p->vid_w_hh, w.h1, w.c1, true))) return rc;
+        }
         if ((rc = handoff(st, sx, ev++))) return rc;
         const bool cap = t0 >= L;
-        if ((rc = pdual(lb, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H, &q.h1, t0 * B, &q.h1T, t0 * B, nullptr))) return rc;
+        if ((rc = pdual(lb, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H, bf ? nullptr : &q.h1, t0 * B, &q.h1T, t0 * B, nullptr)))
+            return rc;
         if ((rc = pgemm(lb, (t1 - t0) * B, 4 * H, H, q.h1, t0 * B, 0, q.wv, 0, 0, w.s2 + t0 * B4H, 4 * H, ID,
                         cap ? nullptr : w.bsum2, cap)))
             return rc;
-        if ((rc = seq_fwd(sx, t0, t1, B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, true))) return rc;
+        if (bf) {
+            if ((rc = seq_fwd_bf16(sx, t0, t1, B, H, w.s2, T, w.bsum2, q.whh2, q.h2r, w.h2, w.c2))) return rc;
+        } else {
+            if ((rc = seq_fwd(sx, t0, t1, B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, true))) return rc;
+        }
         // h2 planes: transposed (k = time-major row) for dW_hh2; row planes of the decode steps for the logits GEMM
-        if ((rc = pdual(lb, w.h2 + t0 * BH, H, ID, (t1 - t0) * B, H, cap ? &q.h2dec : nullptr, cap ? (t0 - L) * B : 0,
-                        &q.h2T, t0 * B, nullptr)))
+        if ((rc = pdual(lb, w.h2 + t0 * BH, H, ID, (t1 - t0) * B, H, (cap && !bf) ? &q.h2r : nullptr, t0 * B, &q.h2T,
+                        t0 * B, nullptr)))
             return rc;
     }
-    if ((rc = pgemm(lb, R, V, H, q.h2dec, 0, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false))) return rc;
+    if ((rc = pgemm(lb, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false))) return rc;
     return handoff(sx, st, ev++);
 }
 
@@ -440,6 +514,11 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     const Lane la{st, w.gws_a, w.gws_floats, w.colsum_a};     // word_rnn lane
     const Lane lb{sx, w.gws_b, w.gws_floats, w.colsum_b};     // vid_rnn lane
     size_t ev = 0;
+    const bool bf = (XP == 1);
+    if (bf) {   // zero the k padding of the bf16 dG row images
+        if ((rc = zero_pad_cols_u16(st, q.dg2.p, (int64_t)T * B, q.dg2.ld, 4 * H, q.dg2.kpad))) return rc;
+        if ((rc = zero_pad_cols_u16(st, q.dg1.p, (int64_t)T * B, q.dg1.ld, 4 * H, q.dg1.kpad))) return rc;
+    }
     if ((rc = handoff(st, sx, ev++))) return rc;
     // lane A: dlogits planes in both orientations + its column sums (one read), gradient into the decode-step
     // hidden states (k = V), then word_rnn BPTT.  (W^T planes were written by the forward.)
@@ -455,17 +534,25 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     const std::vector<int> bd = pipe_bounds(T, L, blk);
     for (size_t k = bd.size() - 1; k >= 1; --k) {
         const int t0 = bd[k - 1], t1 = bd[k];
-        if ((rc = seq_bwd(st, T, t0, t1, B, H, w.wt2, w.dh2dec, L, w.c2, w.s2, w.dc2))) return rc;
+        if (bf) {
+            if ((rc = seq_bwd_bf16(st, T, t0, t1, B, H, q.whh2T, w.dh2dec, L, w.c2, w.s2, q.dg2, w.dc2))) return rc;
+        } else {
+            if ((rc = seq_bwd(st, T, t0, t1, B, H, w.wt2, w.dh2dec, L, w.c2, w.s2, w.dc2))) return rc;
+        }
         // dG2 of this block: row planes (dh1, d-embedding GEMMs), transposed planes (weight gradients) and the
         // bias-gradient partial sums, all from one read
-        if ((rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, &q.dg2, t0 * B, &q.dg2T, t0 * B,
+        if ((rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, bf ? nullptr : &q.dg2, t0 * B, &q.dg2T, t0 * B,
                         w.colsum_a + (int64_t)(t0 * B / 64) * 4 * H)))
             return rc;
         if ((rc = pgemm(la, (t1 - t0) * B, H, 4 * H, q.dg2, t0 * B, 0, q.wvT, 0, 0, w.dh1 + t0 * BH, H, ID, nullptr, false)))
             return rc;
         if ((rc = handoff(st, sx, ev++))) return rc;
-        if ((rc = seq_bwd(sx, T, t0, t1, B, H, w.wt1, w.dh1, 0, w.c1, w.s1, w.dc1))) return rc;
-        if ((rc = pdual(lb, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, (t0 < L) ? &q.dg1 : nullptr, t0 * B, &q.dg1T,
+        if (bf) {
+            if ((rc = seq_bwd_bf16(sx, T, t0, t1, B, H, q.whh1T, w.dh1, 0, w.c1, w.s1, q.dg1, w.dc1))) return rc;
+        } else {
+            if ((rc = seq_bwd(sx, T, t0, t1, B, H, w.wt1, w.dh1, 0, w.c1, w.s1, w.dc1))) return rc;
+        }
+        if ((rc = pdual(lb, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, (t0 < L && !bf) ? &q.dg1 : nullptr, t0 * B, &q.dg1T,
                         t0 * B, w.colsum_b + (int64_t)(t0 * B / 64) * 4 * H)))
             return rc;
     }
@@ -507,7 +594,10 @@ const char* s2vt_last_error(void) { return g_err; }
 size_t s2vt_train_workspace_bytes(const s2vt_dims* d) {
     if (!dims_ok(d)) return 0;
     size_t n = carve_train(*d, nullptr).bytes;
-    if (planes_ok(*d)) n += carve_planes(*d, nullptr).bytes;
+    if (planes_ok(*d)) {
+        XP = (gemm_mode() == 1) ? 1 : 3;
+        n += carve_planes(*d, nullptr).bytes;
+    }
     return n;
 }
 
@@ -518,6 +608,7 @@ int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* fe
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
     if (planes_ok(*d)) {
+        XP = (gemm_mode() == 1) ? 1 : 3;
         const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
         S2VT_REQUIRE(workspace_bytes >= w.bytes + q.bytes, "s2vt_train_forward: workspace %zu < %zu bytes",
                      workspace_bytes, w.bytes + q.bytes);
@@ -574,6 +665,7 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
     if (planes_ok(*d)) {
+        XP = (gemm_mode() == 1) ? 1 : 3;
         const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
         S2VT_REQUIRE(workspace_bytes >= w.bytes + q.bytes, "s2vt_train_backward: workspace %zu < %zu bytes",
                      workspace_bytes, w.bytes + q.bytes);
@@ -677,6 +769,7 @@ static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
     w.gws_a = c.take<float>(w.gws_floats);
     w.gws_b = c.take<float>(w.gws_floats);
     if (planes_ok(d)) {
+        XP = 3;     // greedy decode must stay fp32-equivalent (bit-exact ids): split precision in every plane mode
         auto mk = [&](size_t rows, size_t k) {
             PB b;
             b.kpad = pad64((int)k);
@@ -706,6 +799,7 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
     const bool x3 = planes_ok(*d);
+    if (x3) XP = 3;
     const int blk = pipe_block();
     hipStream_t sx = st;
     int rc;
@@ -930,7 +1024,7 @@ int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, con
 
 int s2vt_set_gemm_mode(int32_t mode) {
     const int prev = gemm_mode();
-    if (mode >= 0) g_gemm_mode = (mode == 3) ? 3 : 0;     // negative: query only
+    if (mode >= 0) g_gemm_mode = norm_mode(mode);         // negative: query only
     return prev;
 }
 

@@ -60,6 +60,36 @@ struct StepBwdArgs {
 };
 int lstm_step_bwd(hipStream_t stream, const StepBwdArgs& a);
 
+// ---- lstm_bf16.hip: bf16-operand timestep kernels (config 3)
+struct StepFwdBf16Args {
+    int B, H, Kp;                                   // Kp: k extent of the bf16 operands (H zero-padded to 64)
+    const unsigned short* hb_prev; int64_t ldhb;    // bf16 h_{t-1} rows (nullptr: h = 0)
+    const unsigned short* wb; int64_t ldwb;         // bf16 W_hh rows [4H][Kp]
+    const float* gx; int64_t ldgx;
+    const float* bias;
+    const float* c_prev; int64_t ldc;
+    float* h_out; int64_t ldho;                     // optional fp32 copy of h_t
+    unsigned short* hb_out; int64_t ldhbo;          // bf16 row image of h_t (next operand + GEMM plane)
+    float* c_out; int64_t ldco;
+    float* stash; int64_t ldst;
+};
+int lstm_step_fwd_bf16(hipStream_t stream, const StepFwdBf16Args& a);
+
+struct StepBwdBf16Args {
+    int B, H, Kp;                                   // Kp: 4H zero-padded to 64
+    const unsigned short* dgb_next; int64_t lddgb;  // bf16 dG_{t+1} rows (nullptr at the last step)
+    const unsigned short* wtb; int64_t ldwtb;       // bf16 W_hh^T rows [H][Kp]
+    const float* dh_out; int64_t lddho;
+    const float* stash; int64_t ldst;
+    const float* c; int64_t ldc;
+    const float* c_prev; int64_t ldcp;
+    float* dc; int64_t lddc;
+    int dc_is_zero;
+    float* dg; int64_t lddg;                        // fp32 dG_t (may alias stash)
+    unsigned short* dgb; int64_t lddgbo;            // bf16 row image of dG_t
+};
+int lstm_step_bwd_bf16(hipStream_t stream, const StepBwdBf16Args& a);
+
 struct LogitsArgmaxArgs {
     int B, H, V;
     const float* h; int64_t ldh;
@@ -81,6 +111,7 @@ int gather_rows_f32(hipStream_t s, const float* src, int64_t ld, const int32_t* 
 int embedding_scatter_add(hipStream_t s, const float* d_rows, int64_t rows, int E, const int32_t* tok, float* d_emb);
 int unpack_tokens(hipStream_t s, const unsigned long long* packed, int steps, int B, int64_t* out_ids);
 int fill_zero(hipStream_t s, void* p, size_t bytes);
+int zero_pad_cols_u16(hipStream_t s, unsigned short* p, int64_t rows, int64_t ld, int col0, int col1);
 
 // ---- ce.hip
 int mean_ce_fwd(hipStream_t s, const float* logits, int64_t rows, int V, const int64_t* target, int Lm1, int64_t ldt,

@@ -158,6 +158,21 @@ int unpack_tokens(hipStream_t s, const unsigned long long* packed, int steps, in
     return 0;
 }
 
+// p[r][col0:col1) = 0 for every row (zero padding of bf16 row images whose valid columns are written elsewhere)
+__global__ void zero_pad_cols_kernel(unsigned short* p, int64_t rows, int64_t ld, int col0, int ncols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ncols) return;
+    p[(i / ncols) * ld + col0 + (i % ncols)] = 0;
+}
+int zero_pad_cols_u16(hipStream_t s, unsigned short* p, int64_t rows, int64_t ld, int col0, int col1) {
+    const int ncols = col1 - col0;
+    if (rows <= 0 || ncols <= 0) return 0;
+    const int64_t n = rows * ncols;
+    hipLaunchKernelGGL(zero_pad_cols_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, rows, ld, col0, ncols);
+    S2VT_LAUNCH_CHECK("zero_pad_cols_kernel");
+    return 0;
+}
+
 int fill_zero(hipStream_t s, void* p, size_t bytes) {
     if (bytes == 0) return 0;
     S2VT_HIP(hipMemsetAsync(p, 0, bytes, s));

@@ -242,3 +242,40 @@ def test_c5_dims_beam_and_greedy_against_reference_golden(lib, golden):
     for b, s in enumerate(out):
         same += int([int(t.item()) for t in s] == [int(x) for x in g["beam_ids"][b] if x >= 0])
     assert same >= d["B"] - 1, same      # a near-tie in log-prob order may legitimately flip one caption
+
+
+def test_bf16_mode_config3_arithmetic(lib):
+    """BASELINE config 3 arithmetic (s2vt_set_gemm_mode(1)): bf16 operands for the batched GEMMs and the timestep
+    kernels, fp32 accumulation / cell state / gradients.  Token ids are not compared in bf16; the loss and
+    the gradients are compared with the fp32 oracle at bf16-level tolerances (8 mantissa bits: ~4e-3 relative per
+    operand, averaged down over K)."""
+    B, L, Fd, H, E, V, seed = 64, 6, 192, 128, 64, 500, 4
+    sd = synth.make_state_dict(V, Fd, H, E, seed=seed)
+    feats, caps, mask = synth.make_batch(B, L, Fd, V, seed=seed, min_words=1, max_words=3)
+    import S2VTModel, utils
+    om = orc.OracleModel(sd)
+    ologits = om(feats, caps[:, :-1])
+    oloss = orc.mask_criterion(ologits, caps, mask)
+    oloss.backward()
+    prev = lib.s2vt_set_gemm_mode(1)
+    try:
+        m = S2VTModel.S2VT(V, Fd, L, dim_hid=H, dim_embed=E)
+        m.load_state_dict(sd)
+        m.to(DEV)
+        logits = m(feats.to(DEV), targets=caps[:, :-1].to(DEV), mode="train")
+        loss = utils.MaskCriterion()(logits, caps.to(DEV), mask.to(DEV))
+        loss.backward()
+        with torch.no_grad():
+            ids_bf16_mode = m.eval()(feats.to(DEV), mode="test").cpu()
+    finally:
+        lib.s2vt_set_gemm_mode(prev)
+    scale = ologits.detach().abs().max().item()
+    assert (logits.detach().cpu() - ologits.detach()).abs().max().item() < 2e-2 * scale
+    assert abs(float(loss) - float(oloss)) < 5e-3
+    for (n, p), (k, q) in zip(m.named_parameters(), om.as_dict().items()):
+        rel = (p.grad.cpu() - q.grad).norm().item() / (q.grad.norm().item() + 1e-12)
+        assert rel < 3e-2, (n, rel)
+    # greedy decode keeps fp32-equivalent arithmetic in every mode
+    oids, marg = orc.greedy_decode(sd, feats, return_margins=True)
+    if marg.min().item() > 1e-4:
+        assert torch.equal(ids_bf16_mode, oids)
