@@ -20,10 +20,16 @@
 
 namespace s2vt {
 
-constexpr int KC = 64;       // k chunk per wave iteration
-constexpr int SLD = 68;      // LDS row stride in floats
+#ifndef S2VT_KC
+#define S2VT_KC 32
+#endif
+constexpr int KC = S2VT_KC;      // k chunk per wave iteration (64: 256-B row segments; 32: half the LDS, one line)
+constexpr int SLD = KC + 4;      // LDS row stride in floats (68 / 36: conflict-free ds_read_b128)
+constexpr int LPR = KC / 4;      // lanes per staged row (one float4 each)
+constexpr int RPL = 64 / LPR;    // rows covered by one wave-wide load
+constexpr int LPT = 16 / RPL;    // loads per lane per 16 rows of tile
 #ifndef S2VT_NWAVE_FWD
-#define S2VT_NWAVE_FWD 4
+#define S2VT_NWAVE_FWD 8
 #endif
 #ifndef S2VT_NWAVE_BWD
 #define S2VT_NWAVE_BWD 8
@@ -68,7 +74,7 @@ __device__ __forceinline__ f32x4 ld4(const float* base, const float* row, int c,
 // arow/brow: per-lane row pointers for rows (lane/16 + 4 i); sA/sB: wave-private LDS images.
 template <int MT, int NT, int NA, bool VEC, int NWAVE>
 __device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const float* abase, const float* bbase,
-                                             const float* const (&arow)[MT * 4], const float* const (&brow)[NT * 4],
+                                             const float* const (&arow)[MT * LPT], const float* const (&brow)[NT * LPT],
                                              int K, float* sA, float* sB, int wave, int lane) {
     // Wave w owns chunks w, w+NWAVE, ...; PF of them are in flight (registers) at any time.  Loads are issued
     // unconditionally (chunks past K read the zero block), so the body is straight-line code and the compiler's
@@ -76,16 +82,16 @@ __device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const flo
     const int nch = (K + KC - 1) / KC;
     const int per_wave = (nch + NWAVE - 1) / NWAVE;
     const int n_round = (per_wave + PF - 1) / PF;
-    const int lrow = lane >> 4, kq = (lane & 15) * 4;
+    const int lrow = lane / LPR, kq = (lane % LPR) * 4;
     const int fi = lane & 15, fq = lane >> 4;
-    f32x4 ra[PF][MT * 4], rb[PF][NT * 4];
+    f32x4 ra[PF][MT * LPT], rb[PF][NT * LPT];
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
         const int k0 = (wave + d * NWAVE) * KC + kq;
 #pragma unroll
-        for (int i = 0; i < MT * 4; ++i) ra[d][i] = ld4<VEC>(abase, arow[i], k0, K);
+        for (int i = 0; i < MT * LPT; ++i) ra[d][i] = ld4<VEC>(abase, arow[i], k0, K);
 #pragma unroll
-        for (int i = 0; i < NT * 4; ++i) rb[d][i] = ld4<VEC>(bbase, brow[i], k0, K);
+        for (int i = 0; i < NT * LPT; ++i) rb[d][i] = ld4<VEC>(bbase, brow[i], k0, K);
     }
 #if defined(S2VT_ABLATE) && S2VT_ABLATE == 3   // timing experiment: launch + epilogue only
     return;
@@ -95,17 +101,17 @@ __device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const flo
         for (int d = 0; d < PF; ++d) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-            for (int i = 0; i < MT * 4; ++i) *reinterpret_cast<f32x4*>(&sA[(lrow + 4 * i) * SLD + kq]) = ra[d][i];
+            for (int i = 0; i < MT * LPT; ++i) *reinterpret_cast<f32x4*>(&sA[(lrow + RPL * i) * SLD + kq]) = ra[d][i];
 #pragma unroll
-            for (int i = 0; i < NT * 4; ++i) *reinterpret_cast<f32x4*>(&sB[(lrow + 4 * i) * SLD + kq]) = rb[d][i];
+            for (int i = 0; i < NT * LPT; ++i) *reinterpret_cast<f32x4*>(&sB[(lrow + RPL * i) * SLD + kq]) = rb[d][i];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             {   // refill this stage with the chunk PF rounds ahead
                 const int k0 = (wave + ((r + 1) * PF + d) * NWAVE) * KC + kq;
 #pragma unroll
-                for (int i = 0; i < MT * 4; ++i) ra[d][i] = ld4<VEC>(abase, arow[i], k0, K);
+                for (int i = 0; i < MT * LPT; ++i) ra[d][i] = ld4<VEC>(abase, arow[i], k0, K);
 #pragma unroll
-                for (int i = 0; i < NT * 4; ++i) rb[d][i] = ld4<VEC>(bbase, brow[i], k0, K);
+                for (int i = 0; i < NT * LPT; ++i) rb[d][i] = ld4<VEC>(bbase, brow[i], k0, K);
             }
 #pragma unroll
             for (int s = 0; s < KC / 16; ++s) {
@@ -178,7 +184,8 @@ static inline bool vec_ok(const void* ptr, int64_t ld) {
 
 // ------------------------------------------------------------------------------ forward step
 template <int MT, int NT, bool VEC>
-__global__ __launch_bounds__(NW_FWD * 64) void lstm_step_fwd_kernel(StepFwdArgs p) {
+// two workgroups (one per pipeline lane) must fit a CU: with 8 waves each that is 4 waves per SIMD -> <= 128 VGPRs
+__global__ __launch_bounds__(NW_FWD * 64, NW_FWD / 2) void lstm_step_fwd_kernel(StepFwdArgs p) {
     constexpr int TM = 16 * MT, TN = 16 * NT, UN = TN / 4;
     constexpr int NWAVE = NW_FWD, NTHR = NWAVE * 64;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(NW_FWD * 64) void lstm_step_fwd_kernel(StepFwdArgs 
     int tx, ty;
     if (!xcd_tile((p.H + UN - 1) / UN, (p.B + TM - 1) / TM, tx, ty)) return;
     const int b0 = ty * TM, u0 = tx * UN;
-    const int lrow = lane >> 4;
+    const int lrow = lane / LPR;
 
     f32x4 acc[MT][NT][NA];
 #pragma unroll
@@ -218,26 +225,26 @@ __global__ __launch_bounds__(NW_FWD * 64) void lstm_step_fwd_kernel(StepFwdArgs 
     }
 
     if (p.h_prev) {
-        const float* arow[MT * 4];
-        const float* brow[NT * 4];
+        const float* arow[MT * LPT];
+        const float* brow[NT * LPT];
 #pragma unroll
-        for (int i = 0; i < MT * 4; ++i) {
-            const int b = b0 + lrow + 4 * i;
+        for (int i = 0; i < MT * LPT; ++i) {
+            const int b = b0 + lrow + RPL * i;
             arow[i] = (b < p.B) ? p.h_prev + (int64_t)b * p.ldh : nullptr;
         }
 #pragma unroll
-        for (int i = 0; i < NT * 4; ++i) {
-            const int r = lrow + 4 * i, g = r / UN, u = u0 + r % UN;
+        for (int i = 0; i < NT * LPT; ++i) {
+            const int r = lrow + RPL * i, g = r / UN, u = u0 + r % UN;
             brow[i] = (u < p.H) ? p.w_hh + ((int64_t)g * p.H + u) * p.ldw : nullptr;
         }
         wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.h_prev, p.w_hh, arow, brow, p.H, sA, sB, wave, lane);
     }
     if (p.x2) {
-        const float* arow[MT * 4];
-        const float* brow[NT * 4];
+        const float* arow[MT * LPT];
+        const float* brow[NT * LPT];
 #pragma unroll
-        for (int i = 0; i < MT * 4; ++i) {
-            const int b = b0 + lrow + 4 * i;
+        for (int i = 0; i < MT * LPT; ++i) {
+            const int b = b0 + lrow + RPL * i;
             if (b < p.B) {
                 int64_t tok;
                 if (p.tok_idx) tok = p.tok_idx[b];
@@ -249,8 +256,8 @@ __global__ __launch_bounds__(NW_FWD * 64) void lstm_step_fwd_kernel(StepFwdArgs 
             }
         }
 #pragma unroll
-        for (int i = 0; i < NT * 4; ++i) {
-            const int r = lrow + 4 * i, g = r / UN, u = u0 + r % UN;
+        for (int i = 0; i < NT * LPT; ++i) {
+            const int r = lrow + RPL * i, g = r / UN, u = u0 + r % UN;
             brow[i] = (u < p.H) ? p.w2 + ((int64_t)g * p.H + u) * p.ldw2 : nullptr;
         }
         wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.x2, p.w2, arow, brow, p.K2, sA, sB, wave, lane);
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(NW_BWD * 64) void lstm_step_bwd_kernel(StepBwdArgs 
     int tx, ty;
     if (!xcd_tile((p.H + TN - 1) / TN, (p.B + TM - 1) / TM, tx, ty)) return;
     const int b0 = ty * TM, n0 = tx * TN;
-    const int lrow = lane >> 4;
+    const int lrow = lane / LPR;
 
     f32x4 acc[MT][NT][NA];
 #pragma unroll
@@ -347,16 +354,16 @@ __global__ __launch_bounds__(NW_BWD * 64) void lstm_step_bwd_kernel(StepBwdArgs 
     }
 
     if (p.dg_next) {
-        const float* arow[MT * 4];
-        const float* brow[NT * 4];
+        const float* arow[MT * LPT];
+        const float* brow[NT * LPT];
 #pragma unroll
-        for (int i = 0; i < MT * 4; ++i) {
-            const int b = b0 + lrow + 4 * i;
+        for (int i = 0; i < MT * LPT; ++i) {
+            const int b = b0 + lrow + RPL * i;
             arow[i] = (b < p.B) ? p.dg_next + (int64_t)b * p.lddg : nullptr;
         }
 #pragma unroll
-        for (int i = 0; i < NT * 4; ++i) {
-            const int n = n0 + lrow + 4 * i;
+        for (int i = 0; i < NT * LPT; ++i) {
+            const int n = n0 + lrow + RPL * i;
             brow[i] = (n < p.H) ? p.w_hh_t + (int64_t)n * p.ldwt : nullptr;
         }
         wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.dg_next, p.w_hh_t, arow, brow, 4 * p.H, sA, sB, wave, lane);
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(NW_FWD * 64) void logits_argmax_kernel(LogitsArgmax
     int tx, ty;
     if (!xcd_tile((p.V + TN - 1) / TN, (p.B + TM - 1) / TM, tx, ty)) return;
     const int b0 = ty * TM, n0 = tx * TN;
-    const int lrow = lane >> 4;
+    const int lrow = lane / LPR;
 
     f32x4 acc[MT][NT][NA];
 #pragma unroll
@@ -420,16 +427,16 @@ __global__ __launch_bounds__(NW_FWD * 64) void logits_argmax_kernel(LogitsArgmax
 #pragma unroll
             for (int a = 0; a < NA; ++a) acc[mi][ni][a] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
-        const float* arow[MT * 4];
-        const float* brow[NT * 4];
+        const float* arow[MT * LPT];
+        const float* brow[NT * LPT];
 #pragma unroll
-        for (int i = 0; i < MT * 4; ++i) {
-            const int b = b0 + lrow + 4 * i;
+        for (int i = 0; i < MT * LPT; ++i) {
+            const int b = b0 + lrow + RPL * i;
             arow[i] = (b < p.B) ? p.h + (int64_t)b * p.ldh : nullptr;
         }
 #pragma unroll
-        for (int i = 0; i < NT * 4; ++i) {
-            const int n = n0 + lrow + 4 * i;
+        for (int i = 0; i < NT * LPT; ++i) {
+            const int n = n0 + lrow + RPL * i;
             brow[i] = (n < p.V) ? p.w_out + (int64_t)n * p.ldw : nullptr;
         }
         wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.h, p.w_out, arow, brow, p.H, sA, sB, wave, lane);

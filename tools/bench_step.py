@@ -12,14 +12,11 @@ import torch  # noqa: E402
 from s2vt_video_caption_amd import build  # noqa: E402
 
 VARIANTS = {
-    "w8_pf2": ["S2VT_NWAVE=8", "S2VT_PF=2"],
-    "w4_pf1": ["S2VT_NWAVE=4", "S2VT_PF=1"],
-    "w4_pf2": ["S2VT_NWAVE=4", "S2VT_PF=2"],
-    "w8_pf1": ["S2VT_NWAVE=8", "S2VT_PF=1"],
-    "w8_pf2_noload": ["S2VT_NWAVE=8", "S2VT_PF=2", "S2VT_ABLATE=1"],
-    "w8_pf2_nomfma": ["S2VT_NWAVE=8", "S2VT_PF=2", "S2VT_ABLATE=2"],
-    "w8_pf2_empty": ["S2VT_NWAVE=8", "S2VT_PF=2", "S2VT_ABLATE=3"],
-    "w4_pf2_empty": ["S2VT_NWAVE=4", "S2VT_PF=2", "S2VT_ABLATE=3"],
+    "f4b8_kc64": [],
+    "f8b8_kc32": ["S2VT_NWAVE_FWD=8", "S2VT_KC=32"],
+    "f4b8_kc32": ["S2VT_KC=32"],
+    "f8b8_kc32_pf1": ["S2VT_NWAVE_FWD=8", "S2VT_KC=32", "S2VT_PF=1"],
+    "f8b8_kc32_pf3": ["S2VT_NWAVE_FWD=8", "S2VT_KC=32", "S2VT_PF=3"],
 }
 if os.environ.get("VARIANTS"):
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["VARIANTS"].split(",")}
