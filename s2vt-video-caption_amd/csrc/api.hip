@@ -165,7 +165,7 @@ static int g_pipe_block = -1;      // timesteps per pipeline block; 0 = both lay
 static int pipe_block() {
     if (g_pipe_block < 0) {
         const char* e = getenv("S2VT_PIPE_BLOCK");
-        g_pipe_block = e ? atoi(e) : 16;
+        g_pipe_block = e ? atoi(e) : 32;
         if (g_pipe_block < 0) g_pipe_block = 0;
     }
     return g_pipe_block;
