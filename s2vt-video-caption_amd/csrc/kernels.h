@@ -44,6 +44,7 @@ struct StepFwdArgs {
     float* stash; int64_t ldst;              // [B,4H] activated gates i,f,g,o (train only)
 };
 int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a);
+int lstm_step_fwd2(hipStream_t stream, const StepFwdArgs& a, const StepFwdArgs* b);   // two independent steps, one launch
 
 struct StepBwdArgs {
     int B, H;
@@ -59,6 +60,7 @@ struct StepBwdArgs {
     float* dg; int64_t lddg_out;             // out: pre-activation gate grads [B,4H]
 };
 int lstm_step_bwd(hipStream_t stream, const StepBwdArgs& a);
+int lstm_step_bwd2(hipStream_t stream, const StepBwdArgs& a, const StepBwdArgs* b);
 
 // ---- lstm_bf16.hip: bf16-operand timestep kernels (config 3)
 struct StepFwdBf16Args {

@@ -169,8 +169,8 @@ __device__ __forceinline__ float read_sum(const float* red, int row, int col) {
 // one column tile read the same weight slice, so they are given ids that differ by a multiple of 8: the slice
 // is then fetched into ONE XCD's L2 (16 MB of W_hh / 8 XCDs = 2 MB per 4 MB L2) instead of NY of them.
 // Speed only: any placement is correct.  Grid = ceil(NX/8)*8*NY blocks; ids with x >= NX exit.
-__device__ __forceinline__ bool xcd_tile(int NX, int NY, int& x, int& y) {
-    const int id = blockIdx.x;
+__device__ __forceinline__ bool xcd_tile(int NX, int NY, int& x, int& y, int id = -1) {
+    if (id < 0) id = blockIdx.x;
     const int xcd = id & 7, j = id >> 3;
     x = (j / NY) * 8 + xcd;
     y = j % NY;
@@ -183,9 +183,21 @@ static inline bool vec_ok(const void* ptr, int64_t ld) {
 }
 
 // ------------------------------------------------------------------------------ forward step
+// (two workgroups must fit a CU: with 8 waves each that is 4 waves per SIMD -> <= 128 VGPRs, see launch bounds)
 template <int MT, int NT, bool VEC>
-// two workgroups (one per pipeline lane) must fit a CU: with 8 waves each that is 4 waves per SIMD -> <= 128 VGPRs
-__global__ __launch_bounds__(NW_FWD * 64, NW_FWD / 2) void lstm_step_fwd_kernel(StepFwdArgs p) {
+__device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid);
+
+// Up to TWO independent timesteps per launch (blocks [0, na): pa, blocks [na, ...): pb): the vid_rnn step of block
+// k+1 and the word_rnn step of block k of the layer pipeline share one dispatch (a dispatch costs ~4.5 us on this
+// system whatever it does) and are co-resident by construction (one workgroup of each per CU).
+template <int MT, int NT, bool VEC>
+__global__ __launch_bounds__(NW_FWD * 64, NW_FWD / 2) void lstm_step_fwd_kernel(StepFwdArgs pa, StepFwdArgs pb, int na) {
+    if ((int)blockIdx.x < na) lstm_step_fwd_body<MT, NT, VEC>(pa, blockIdx.x);
+    else lstm_step_fwd_body<MT, NT, VEC>(pb, blockIdx.x - na);
+}
+
+template <int MT, int NT, bool VEC>
+__device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid) {
     constexpr int TM = 16 * MT, TN = 16 * NT, UN = TN / 4;
     constexpr int NWAVE = NW_FWD, NTHR = NWAVE * 64;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
@@ -194,7 +206,7 @@ __global__ __launch_bounds__(NW_FWD * 64, NW_FWD / 2) void lstm_step_fwd_kernel(
     float* sA = smem + wave * (TM + TN) * SLD;
     float* sB = sA + TM * SLD;
     int tx, ty;
-    if (!xcd_tile((p.H + UN - 1) / UN, (p.B + TM - 1) / TM, tx, ty)) return;
+    if (!xcd_tile((p.H + UN - 1) / UN, (p.B + TM - 1) / TM, tx, ty, bid)) return;
     const int b0 = ty * TM, u0 = tx * UN;
     const int lrow = lane / LPR;
 
@@ -292,28 +304,48 @@ __global__ __launch_bounds__(NW_FWD * 64, NW_FWD / 2) void lstm_step_fwd_kernel(
     }
 }
 
-int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a) {
+static bool step_fwd_vec(const StepFwdArgs& a) {
+    // vector path: 16-B aligned rows whose length is a multiple of 4 floats, for every operand in use
+    return (!a.h_prev || (vec_ok(a.h_prev, a.ldh) && vec_ok(a.w_hh, a.ldw) && a.H % 4 == 0)) &&
+           (!a.x2 || (vec_ok(a.x2, a.ldx2) && vec_ok(a.w2, a.ldw2) && a.K2 % 4 == 0));
+}
+
+// b == nullptr: one timestep; otherwise two independent timesteps of the same (B, H) in one launch
+int lstm_step_fwd2(hipStream_t stream, const StepFwdArgs& a, const StepFwdArgs* b) {
     S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.h_out && a.c_out, "lstm_step_fwd: bad arguments");
     S2VT_REQUIRE(a.gx || a.bias, "lstm_step_fwd: need gx or bias");
-    // vector path: 16-B aligned rows whose length is a multiple of 4 floats, for every operand in use
-    const bool vec = (!a.h_prev || (vec_ok(a.h_prev, a.ldh) && vec_ok(a.w_hh, a.ldw) && a.H % 4 == 0)) &&
-                     (!a.x2 || (vec_ok(a.x2, a.ldx2) && vec_ok(a.w2, a.ldw2) && a.K2 % 4 == 0));
+    S2VT_REQUIRE(!b || (b->B == a.B && b->H == a.H && b->h_out && b->c_out && (b->gx || b->bias)),
+                 "lstm_step_fwd: paired steps must have the same batch and hidden size");
+    const bool vec = step_fwd_vec(a) && (!b || step_fwd_vec(*b));
+    const StepFwdArgs& bb = b ? *b : a;
     if (a.B <= 16) {
-        dim3 grid(xcd_grid(cdiv(a.H, 8), cdiv(a.B, 16)));
-        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, true>), grid, dim3(NW_FWD * 64), 0, stream, a);
-        else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, false>), grid, dim3(NW_FWD * 64), 0, stream, a);
+        const int na = xcd_grid(cdiv(a.H, 8), cdiv(a.B, 16));
+        dim3 grid(b ? 2 * na : na);
+        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, true>), grid, dim3(NW_FWD * 64), 0, stream, a, bb, na);
+        else hipLaunchKernelGGL((lstm_step_fwd_kernel<1, 2, false>), grid, dim3(NW_FWD * 64), 0, stream, a, bb, na);
     } else {
-        dim3 grid(xcd_grid(cdiv(a.H, 8), cdiv(a.B, 32)));
-        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, true>), grid, dim3(NW_FWD * 64), 0, stream, a);
-        else hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, false>), grid, dim3(NW_FWD * 64), 0, stream, a);
+        const int na = xcd_grid(cdiv(a.H, 8), cdiv(a.B, 32));
+        dim3 grid(b ? 2 * na : na);
+        if (vec) hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, true>), grid, dim3(NW_FWD * 64), 0, stream, a, bb, na);
+        else hipLaunchKernelGGL((lstm_step_fwd_kernel<2, 2, false>), grid, dim3(NW_FWD * 64), 0, stream, a, bb, na);
     }
     S2VT_LAUNCH_CHECK("lstm_step_fwd_kernel");
     return 0;
 }
+int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a) { return lstm_step_fwd2(stream, a, nullptr); }
 
 // ----------------------------------------------------------------------------- backward step
 template <int MT, int NT, bool VEC>
-__global__ __launch_bounds__(NW_BWD * 64) void lstm_step_bwd_kernel(StepBwdArgs p) {
+__device__ __forceinline__ void lstm_step_bwd_body(const StepBwdArgs& p, int bid);
+
+template <int MT, int NT, bool VEC>
+__global__ __launch_bounds__(NW_BWD * 64) void lstm_step_bwd_kernel(StepBwdArgs pa, StepBwdArgs pb, int na) {
+    if ((int)blockIdx.x < na) lstm_step_bwd_body<MT, NT, VEC>(pa, blockIdx.x);
+    else lstm_step_bwd_body<MT, NT, VEC>(pb, blockIdx.x - na);
+}
+
+template <int MT, int NT, bool VEC>
+__device__ __forceinline__ void lstm_step_bwd_body(const StepBwdArgs& p, int bid) {
     constexpr int TM = 16 * MT, TN = 16 * NT;
     constexpr int NWAVE = NW_BWD, NTHR = NWAVE * 64;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
@@ -322,7 +354,7 @@ __global__ __launch_bounds__(NW_BWD * 64) void lstm_step_bwd_kernel(StepBwdArgs 
     float* sA = smem + wave * (TM + TN) * SLD;
     float* sB = sA + TM * SLD;
     int tx, ty;
-    if (!xcd_tile((p.H + TN - 1) / TN, (p.B + TM - 1) / TM, tx, ty)) return;
+    if (!xcd_tile((p.H + TN - 1) / TN, (p.B + TM - 1) / TM, tx, ty, bid)) return;
     const int b0 = ty * TM, n0 = tx * TN;
     const int lrow = lane / LPR;
 
@@ -389,15 +421,21 @@ __global__ __launch_bounds__(NW_BWD * 64) void lstm_step_bwd_kernel(StepBwdArgs 
     }
 }
 
-int lstm_step_bwd(hipStream_t stream, const StepBwdArgs& a) {
+int lstm_step_bwd2(hipStream_t stream, const StepBwdArgs& a, const StepBwdArgs* b) {
     S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.stash && a.c && a.dc && a.dg, "lstm_step_bwd: bad arguments");
-    const bool vec = !a.dg_next || (vec_ok(a.dg_next, a.lddg) && vec_ok(a.w_hh_t, a.ldwt));
-    dim3 grid(xcd_grid(cdiv(a.H, 16), cdiv(a.B, 16)));
-    if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, true>), grid, dim3(NW_BWD * 64), 0, stream, a);
-    else hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, false>), grid, dim3(NW_BWD * 64), 0, stream, a);
+    S2VT_REQUIRE(!b || (b->B == a.B && b->H == a.H && b->stash && b->c && b->dc && b->dg),
+                 "lstm_step_bwd: paired steps must have the same batch and hidden size");
+    auto okv = [](const StepBwdArgs& x) { return !x.dg_next || (vec_ok(x.dg_next, x.lddg) && vec_ok(x.w_hh_t, x.ldwt)); };
+    const bool vec = okv(a) && (!b || okv(*b));
+    const StepBwdArgs& bb = b ? *b : a;
+    const int na = xcd_grid(cdiv(a.H, 16), cdiv(a.B, 16));
+    dim3 grid(b ? 2 * na : na);
+    if (vec) hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, true>), grid, dim3(NW_BWD * 64), 0, stream, a, bb, na);
+    else hipLaunchKernelGGL((lstm_step_bwd_kernel<1, 1, false>), grid, dim3(NW_BWD * 64), 0, stream, a, bb, na);
     S2VT_LAUNCH_CHECK("lstm_step_bwd_kernel");
     return 0;
 }
+int lstm_step_bwd(hipStream_t stream, const StepBwdArgs& a) { return lstm_step_bwd2(stream, a, nullptr); }
 
 // -------------------------------------------------------------------- decode: logits + argmax
 __device__ __forceinline__ uint32_t ordered_bits(float x) {
