@@ -1,0 +1,81 @@
+"""CPU: the drop-in `dataloader.VideoDataset` keeps the reference's item contract
+(dataloader.py:28-50) and its caption-sampling RNG stream.  The reference's own `__getitem__` cannot run on
+NumPy >= 1.24 (`np.random.choice` on a ragged list raises), so its rule is restated here on an object array."""
+import json
+import os
+
+import numpy as np
+import torch
+
+
+def _make(tmp_path, n=6, L=8, F=16):
+    rng = np.random.RandomState(0)
+    caps, ids = {}, []
+    os.makedirs(tmp_path / "feats")
+    for i in range(n):
+        vid = "vid%d" % i
+        ids.append(vid)
+        np.save(tmp_path / "feats" / (vid + ".npy"), rng.randn(L, F).astype(np.float32))
+        caps[vid] = [[3] + list(rng.randint(5, 20, size=rng.randint(1, 12))) + [4] for _ in range(rng.randint(2, 5))]
+        caps[vid] = [[int(x) for x in c] for c in caps[vid]]
+    data = {"word2ix": {str(i): i for i in range(20)}, "ix2word": {str(i): str(i) for i in range(20)},
+            "captions": caps, "splits": {"train": ids[:4], "valid": ids[4:5], "test": ids[5:]}}
+    with open(tmp_path / "captions.json", "w") as f:
+        json.dump(data, f)
+    return data
+
+
+def test_item_contract_and_sampling_stream(tmp_path):
+    import dataloader
+    data = _make(tmp_path)
+    ds = dataloader.VideoDataset(str(tmp_path / "captions.json"), str(tmp_path / "feats"), max_len=8, mode="train")
+    assert len(ds) == 4
+    np.random.seed(123)
+    items = [ds[i] for i in range(len(ds))]
+    # the reference's rule (dataloader.py:41) on an object array, same seed
+    np.random.seed(123)
+    for (feat, pad_label, vid, mask), path in zip(items, ds.feat_paths):
+        labels = data["captions"][vid]
+        obj = np.empty(len(labels), dtype=object)
+        for i, c in enumerate(labels):
+            obj[i] = c
+        label = np.random.choice(obj, 1)[0][:8]
+        assert vid == path.stem
+        assert feat.dtype == torch.float32 and tuple(feat.shape) == (8, 16)
+        assert torch.equal(feat, torch.from_numpy(np.load(str(path))))
+        assert pad_label.dtype == torch.int64 and pad_label.tolist() == list(label) + [0] * (8 - len(label))
+        assert mask.dtype == torch.float32 and mask.tolist() == [1.0] * len(label) + [0.0] * (8 - len(label))
+    # truncation of captions longer than max_len (dataloader.py:43-44)
+    assert all(int(m.sum()) <= 8 for _, _, _, m in items)
+
+
+def test_default_collate_and_feed_on_cpu(tmp_path):
+    import dataloader
+    _make(tmp_path)
+    ds = dataloader.VideoDataset(str(tmp_path / "captions.json"), str(tmp_path / "feats"), max_len=8, mode="train")
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False)
+    batches = list(dataloader.feed_batches(loader, dev=torch.device("cpu")))
+    assert len(batches) == 2
+    feats, targets, ids, masks = batches[0]
+    assert tuple(feats.shape) == (2, 8, 16) and tuple(targets.shape) == (2, 8) and tuple(masks.shape) == (2, 8)
+    assert len(ids) == 2
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_feed_batches_on_gpu_matches_host(tmp_path):
+    import dataloader
+    _make(tmp_path, n=9, L=8, F=16)
+    dev = torch.device("cuda", 0)
+    ds = dataloader.VideoDataset(str(tmp_path / "captions.json"), str(tmp_path / "feats"), max_len=8, mode="train")
+    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+    np.random.seed(7)
+    host = list(loader)
+    np.random.seed(7)
+    got = list(dataloader.feed_batches(loader, dev=dev, depth=2))
+    assert len(got) == len(host) == 4
+    for (f, t, ids, m), (hf, ht, hids, hm) in zip(got, host):
+        assert f.is_cuda and t.is_cuda and m.is_cuda
+        assert torch.equal(f.cpu(), hf) and torch.equal(t.cpu(), ht) and torch.equal(m.cpu(), hm) and ids == hids
