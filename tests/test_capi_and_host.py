@@ -102,3 +102,20 @@ def test_synth_recipe_is_deterministic_and_order_independent():
     assert torch.equal(f1, f2) and torch.equal(c1, c2) and torch.equal(m1, m2)
     assert (c1[:, 0] == 3).all() and ((c1 == 4).sum(1) == 1).all() and c1.max() < 50
     assert torch.equal(m1.sum(1), (c1 != 0).sum(1).float())
+
+
+def test_early_stopping_protocol(tmp_path):
+    """utils.EarlyStopping: the reference's protocol (utils.py:29-80) — patience counter, full-module checkpoint on
+    every improvement, val_loss_min bookkeeping."""
+    import utils
+    path = str(tmp_path / "stop.pth")
+    m = torch.nn.Linear(2, 2)
+    msgs = []
+    es = utils.EarlyStopping(patience=2, verbose=True, path=path, trace_func=msgs.append)
+    for v in (1.0, 0.9, 0.95):
+        es(v, m)
+    assert not es.early_stop and es.counter == 1 and abs(es.val_loss_min - 0.9) < 1e-12
+    es(0.96, m)
+    assert es.early_stop and es.counter == 2
+    assert isinstance(torch.load(path, weights_only=False), torch.nn.Linear)
+    assert any("Validation loss decreased" in s for s in msgs) and any("EarlyStopping counter: 2 out of 2" in s for s in msgs)

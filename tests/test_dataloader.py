@@ -79,3 +79,29 @@ def test_feed_batches_on_gpu_matches_host(tmp_path):
     for (f, t, ids, m), (hf, ht, hids, hm) in zip(got, host):
         assert f.is_cuda and t.is_cuda and m.is_cuda
         assert torch.equal(f.cpu(), hf) and torch.equal(t.cpu(), ht) and torch.equal(m.cpu(), hm) and ids == hids
+
+
+@pytest.mark.gpu
+def test_train_harness_end_to_end(tmp_path):
+    """train.py on a toy dataset: two epochs, best-loss and final full-module checkpoints that load back through the
+    drop-in class and decode (the reference's eval.py:41 protocol)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = _make(tmp_path, n=8, L=8, F=16)
+    data["word2ix"].update({"<pad>": 0, "<unk>": 1, "<sos>": 3, "<eos>": 4})
+    data["splits"] = {"train": ["vid%d" % i for i in range(6)], "valid": ["vid6"], "test": ["vid7"]}
+    json.dump(data, open(tmp_path / "captions.json", "w"))
+    ck = tmp_path / "ck"
+    r = subprocess.run([sys.executable, os.path.join(root, "train.py"), "--caption-file", str(tmp_path / "captions.json"),
+                        "--feats-path", str(tmp_path / "feats"), "--train-length", "8", "--dim-hidden", "32",
+                        "--dim-embed", "24", "--feat-dim", "16", "--batch-size", "3", "--epochs", "2", "--save-path",
+                        str(ck)], capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    files = sorted(os.listdir(ck))
+    assert any(f.endswith("stop.pth") for f in files) and any(f.endswith("final.pth") for f in files)
+    sys.path.insert(0, root)
+    import S2VTModel  # noqa: F401
+    m = torch.load(os.path.join(ck, [f for f in files if f.endswith("final.pth")][0]), weights_only=False).to("cuda:0")
+    ids = m.eval()(torch.randn(2, 8, 16, device="cuda:0"), mode="test")
+    assert tuple(ids.shape) == (2, 7)

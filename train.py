@@ -1,0 +1,117 @@
+"""Training harness for the MI355X S2VT path: the reference's loop (train.py:56-175) —
+Adam(lr) + ReduceLROnPlateau(patience) + EarlyStopping(patience) + full-module checkpoints every `save_freq` epochs, at
+the best validation loss and at the end — on top of the drop-in `S2VTModel.S2VT`, `utils.MaskCriterion`,
+`dataloader.VideoDataset` and, with more than one process, data parallelism over RCCL (`s2vt_video_caption_amd.dp`).
+
+  python train.py --caption-file data/captions.json --feats-path data/feats/vgg16_bn
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...
+
+Differences from the reference script: it trains `S2VT` (the reference's committed script instantiates the unrelated
+`Att_Baseline`, train.py:86), configuration comes from argparse with the reference's `Opt` defaults (train.py:20-48),
+TensorBoard logging is optional (tensorboardX is not a dependency), and `ReduceLROnPlateau` is built without the
+`verbose` argument that torch >= 2.6 removed.
+"""
+import argparse
+import os
+import time
+
+import torch
+import torch.distributed as dist
+from torch import optim
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--caption-file", default="./data/captions_server.json")
+    ap.add_argument("--feats-path", default="./data/feats/vgg16_bn")
+    ap.add_argument("--train-length", type=int, default=80)
+    ap.add_argument("--dim-hidden", type=int, default=512)
+    ap.add_argument("--dim-embed", type=int, default=512)
+    ap.add_argument("--feat-dim", type=int, default=4096)
+    ap.add_argument("--feat-dropout", type=float, default=0.0)
+    ap.add_argument("--batch-size", type=int, default=16, help="per process")
+    ap.add_argument("--epochs", type=int, default=300)
+    ap.add_argument("--save-freq", type=int, default=100)
+    ap.add_argument("--save-path", default="./checkpoint")
+    ap.add_argument("--early-stopping-patience", type=int, default=30)
+    ap.add_argument("--lr", type=float, default=1e-4)
+    ap.add_argument("--learning-rate-patience", type=int, default=20)
+    return ap.parse_args()
+
+
+def main():
+    opt = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import dataloader
+    from S2VTModel import S2VT
+    from utils import EarlyStopping, MaskCriterion
+    from s2vt_video_caption_amd import dp
+
+    start_time = time.strftime('%y_%m_%d_%H_%M_%S-', time.localtime())
+    os.makedirs(opt.save_path, exist_ok=True)
+    trainset = dataloader.VideoDataset(opt.caption_file, opt.feats_path, max_len=opt.train_length)
+    validset = dataloader.VideoDataset(opt.caption_file, opt.feats_path, max_len=opt.train_length, mode='valid')
+    sampler = torch.utils.data.distributed.DistributedSampler(trainset, shuffle=True, drop_last=True) if world > 1 else None
+    train_loader = torch.utils.data.DataLoader(trainset, batch_size=opt.batch_size, shuffle=sampler is None,
+                                               sampler=sampler, drop_last=world > 1)
+    valid_loader = torch.utils.data.DataLoader(validset, batch_size=opt.batch_size, shuffle=False)
+    word2ix = trainset.word2ix
+
+    torch.manual_seed(0)        # identical replicas
+    model = S2VT(len(word2ix), opt.feat_dim, length=opt.train_length, dim_hid=opt.dim_hidden, dim_embed=opt.dim_embed,
+                 feat_dropout=opt.feat_dropout, sos_ix=word2ix['<sos>'], eos_ix=word2ix['<eos>']).to(dev)
+    optimizer = optim.Adam(model.parameters(), lr=opt.lr)
+    lr_scheduler = optim.lr_scheduler.ReduceLROnPlateau(optimizer, patience=opt.learning_rate_patience)
+    early_stopping = EarlyStopping(patience=opt.early_stopping_patience, verbose=rank == 0,
+                                   path=os.path.join(opt.save_path, start_time + 'stop.pth'))
+    criterion = MaskCriterion()
+    reducer = dp.FlatGradAllReducer(model.parameters()) if world > 1 else None
+
+    for epoch in range(opt.epochs):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
+        running, count = 0.0, 0
+        for feats, targets, ids, masks in dataloader.feed_batches(train_loader, dev):
+            loss = dp.train_step(model, criterion, optimizer, feats, targets, masks, reducer)   # train.py:116-127
+            running += float(loss)
+            count += 1
+        train_loss = running / max(count, 1)
+        running, count = 0.0, 0
+        model.eval()
+        with torch.no_grad():
+            for feats, targets, ids, masks in dataloader.feed_batches(valid_loader, dev):
+                probs = model(feats, targets=targets[:, :-1], mode='train')                    # train.py:141-143
+                running += float(criterion(probs, targets, masks))
+                count += 1
+        valid_loss = running / max(count, 1)
+        if rank == 0:
+            print("epoch {} train loss:{} valid loss: {} lr: {}".format(epoch, train_loss, valid_loss,
+                                                                        optimizer.param_groups[0]['lr']))
+        lr_scheduler.step(valid_loss)
+        if rank == 0:
+            early_stopping(valid_loss, model)
+            if epoch % opt.save_freq == 0:
+                torch.save(model, os.path.join(opt.save_path, start_time + str(epoch) + '.pth'))
+        stop = torch.tensor([1 if (rank == 0 and early_stopping.early_stop) else 0], device=dev)
+        if world > 1:
+            dist.broadcast(stop, 0)
+        if int(stop):
+            if rank == 0:
+                print("Early stopping")
+            break
+    if rank == 0:
+        torch.save(model, os.path.join(opt.save_path, start_time + 'final.pth'))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
