@@ -119,3 +119,15 @@ def test_early_stopping_protocol(tmp_path):
     assert es.early_stop and es.counter == 2
     assert isinstance(torch.load(path, weights_only=False), torch.nn.Linear)
     assert any("Validation loss decreased" in s for s in msgs) and any("EarlyStopping counter: 2 out of 2" in s for s in msgs)
+
+
+def test_ids_to_caption_rules():
+    """eval.py:54-58 / :90-96: ids -> words, cut at the first <eos>; beam outputs drop their leading <sos>."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("s2vt_eval", os.path.join(ROOT, "eval.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    ix2word = {"0": "<pad>", "3": "<sos>", "4": "<eos>", "5": "a", "6": "cat"}
+    assert ev.ids_to_caption([5, 6, 4, 5, 5], ix2word) == "a cat"
+    assert ev.ids_to_caption([5, 6, 5], ix2word) == "a cat a"
+    assert ev.ids_to_caption([3, 5, 6, 4, 6], ix2word, drop_sos=True) == "a cat"
