@@ -1,5 +1,6 @@
 """CPU: the C-ABI library loads and exports every symbol include/s2vt_hip.h declares; host-side logic of
 the drop-in modules (no compute calls without a GPU)."""
+import numpy as np
 import ctypes
 import os
 import re
@@ -131,3 +132,33 @@ def test_ids_to_caption_rules():
     assert ev.ids_to_caption([5, 6, 4, 5, 5], ix2word) == "a cat"
     assert ev.ids_to_caption([5, 6, 5], ix2word) == "a cat a"
     assert ev.ids_to_caption([3, 5, 6, 4, 6], ix2word, drop_sos=True) == "a cat"
+
+
+@pytest.mark.parametrize("ties", [False, True])
+@pytest.mark.parametrize("V", [25, 3000])
+def test_beam_queues_match_reference_heap(ties, V):
+    """The vectorised per-depth candidate sets (beam.BeamQueues) pop, re-insert, stop and back-trace exactly like
+    the literal heap bookkeeping of S2VTModel.py:186-236 (beam.HeapQueues) - also when scores tie, where the pop
+    order depends on the heap's internal layout."""
+    from s2vt_video_caption_amd import beam
+
+    def run(Q, seed, B=9, bw=5, eos=2):
+        rng = np.random.default_rng(seed)
+        q = Q(B, bw, 1, eos)
+        d = 0
+        while d < 12 and not q.all_done():
+            d += 1
+            rb, rs, rt = q.pop()
+            ix = lp = None
+            if len(rb):
+                ix = np.sort(np.stack([rng.choice(V, 20, replace=False) for _ in rb]), axis=1).astype(np.int64)
+                lp = (-rng.integers(1, 6, size=(len(rb), 20)).astype(np.float32) if ties
+                      else -rng.random((len(rb), 20), dtype=np.float32) * 10)
+            q.push(ix, lp)
+        return q.finish(), list(rs), getattr(q, "tie_fallbacks", 0)
+
+    for seed in range(6):
+        a, rows_a, _ = run(beam.HeapQueues, seed)
+        b, rows_b, nf = run(beam.BeamQueues, seed)
+        assert a == b and rows_a == rows_b
+        assert (nf > 0) == ties

@@ -38,3 +38,14 @@ with torch.no_grad():
           (beam, B, tb * 1e3, B / tb, min(lens), max(lens)), flush=True)
     # beam width 1 degenerates to ... (the reference's quirky scoring is not greedy) - just check ids are in range
     assert all(0 <= int(t.item()) < d["V"] for s in out for t in s)
+    # the literal heap bookkeeping of the reference must give the same captions as the vectorised queues
+    from s2vt_video_caption_amd import beam as beam_mod
+    beam_mod.FAST_QUEUES = False
+    t0 = time.perf_counter()
+    out2 = m(feats, mode="beam_search", beam_width=beam, max_beam_depth=30)
+    torch.cuda.synchronize()
+    tb2 = time.perf_counter() - t0
+    same = all(len(a) == len(b) and all(int(x.reshape(-1)[0]) == int(y.reshape(-1)[0]) for x, y in zip(a, b))
+               for a, b in zip(out, out2))
+    print("heap-queue variant: %.1f ms/call; identical captions: %s" % (tb2 * 1e3, same), flush=True)
+    assert same
