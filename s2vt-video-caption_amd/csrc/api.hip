@@ -325,6 +325,10 @@ static bool planes_ok(const s2vt_dims& d) { return gemm_mode() != 0 && d.B % 64 
 static int XP = 3;        // planes per operand of the running plane driver (3 or 1); set by the entry points
 static inline int pad64(int x) { return (x + 63) / 64 * 64; }
 struct PB { unsigned short* p; int64_t ld; int kpad; };       // packed planes of a k-major operand [rows][k]
+// element offset of k index k0 (a multiple of 64) inside an operand: row layout (1 plane) k0; blocked 3-plane layout
+// (gemm_x3.hip) k0/16 records of 3072 elements
+static inline int64_t koff(int k0) { return XP == 3 ? (int64_t)k0 * 192 : (int64_t)k0 * XP; }
+static inline size_t rows64(size_t r) { return (r + 63) / 64 * 64; }
 
 struct PlaneWS {
     // forward
@@ -341,7 +345,7 @@ static PlaneWS carve_planes(const s2vt_dims& d, void* base) {
         PB b;
         b.kpad = pad64((int)k);
         b.ld = (int64_t)XP * b.kpad;
-        b.p = c.take<unsigned short>(rows * (size_t)b.ld);
+        b.p = c.take<unsigned short>(rows64(rows) * (size_t)b.ld);
         return b;
     };
     PlaneWS w;
@@ -368,22 +372,22 @@ static int psplit(const Lane& ln, const PB& dst, int r0, const float* in, int64_
 }
 // operand rows = input columns (all `cols` of them), k range [k0, k0+rows) <- planes of in[rows][cols]^T
 static int psplitT(const Lane& ln, const PB& dst, int k0, const float* in, int64_t ld, RowMap imap, int rows, int cols) {
-    return split_planes(ln.s, XP, true, in, ld, imap, rows, cols, dst.p + (int64_t)k0 * XP, dst.ld, pad64(rows), cols);
+    return split_planes(ln.s, XP, true, in, ld, imap, rows, cols, dst.p + koff(k0), dst.ld, pad64(rows), cols);
 }
 // one pass over in[rows][cols]: row planes into r (operand rows r0..), transposed planes into t (k range k0..),
 // 64-row partial column sums into colpart (each may be null)
 static int pdual(const Lane& ln, const float* in, int64_t ld, RowMap imap, int rows, int cols, const PB* r, int r0,
                  const PB* t, int k0, float* colpart) {
     return split_planes_dual(ln.s, XP, in, ld, imap, rows, cols, r ? r->p + (int64_t)r0 * r->ld : nullptr, r ? r->ld : 0,
-                             r ? r->kpad : 0, t ? t->p + (int64_t)k0 * XP : nullptr, t ? t->ld : 0, t ? pad64(rows) : 0,
+                             r ? r->kpad : 0, t ? t->p + koff(k0) : nullptr, t ? t->ld : 0, t ? pad64(rows) : 0,
                              colpart);
 }
 // C[M,N] (+)= A[rows a0.., k ka..ka+K) · B[rows b0.., k kb..kb+K)^T
 static int pgemm(const Lane& ln, int M, int N, int K, const PB& A, int a0, int ka, const PB& B, int b0, int kb, float* C,
                  int64_t ldc, RowMap cm, const float* bias, bool acc) {
     ProfScope ps(ln.s, K_GEMM, 1);
-    return gemm_bf16_nt(ln.s, XP, M, N, pad64(K), A.p + (int64_t)a0 * A.ld + (int64_t)ka * XP, A.ld,
-                        B.p + (int64_t)b0 * B.ld + (int64_t)kb * XP, B.ld, C, ldc, cm, bias, acc, ln.gws, ln.gws_floats);
+    return gemm_bf16_nt(ln.s, XP, M, N, pad64(K), A.p + (int64_t)a0 * A.ld + koff(ka), A.ld,
+                        B.p + (int64_t)b0 * B.ld + koff(kb), B.ld, C, ldc, cm, bias, acc, ln.gws, ln.gws_floats);
 }
 
 // bf16-operand layer forward over steps [t0, t1): hb = bf16 row images of h (time-major, ld = hb.ld), the k-major
@@ -894,7 +898,7 @@ static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
             PB b;
             b.kpad = pad64((int)k);
             b.ld = (int64_t)XP * b.kpad;
-            b.p = c.take<unsigned short>(rows * (size_t)b.ld);
+            b.p = c.take<unsigned short>(rows64(rows) * (size_t)b.ld);
             return b;
         };
         w.feats = mk(B * L, F); w.wf = mk(H, F); w.px1 = mk(L * B, H); w.wih1 = mk(4 * H, H);

@@ -229,6 +229,10 @@ int gemm_bf16_nt(hipStream_t stream, int nplanes, int M, int N, int K, const uns
                  bool accumulate, float* splitk_ws, size_t splitk_ws_floats) {
     if (M <= 0 || N <= 0) return 0;
     S2VT_REQUIRE(nplanes == 1 || nplanes == 3, "gemm_bf16_nt: planes must be 1 or 3");
+    static int x3_rows = -1;       // S2VT_X3_ROWS=1: the superseded row-layout 128x128 kernel (needs a matching split.hip)
+    if (x3_rows < 0) { const char* e = getenv("S2VT_X3_ROWS"); x3_rows = e ? atoi(e) : 0; }
+    if (nplanes == 3 && !x3_rows)
+        return gemm_x3(stream, M, N, K, A, lda, B, ldb, C, ldc, cmap, bias, accumulate, splitk_ws, splitk_ws_floats);
     const int BKc = (nplanes == 3) ? 32 : 64;
     S2VT_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= (int64_t)nplanes * K &&
                      ldb >= (int64_t)nplanes * K && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&

@@ -1,0 +1,228 @@
+// Split-precision (3 bf16 planes, 6 plane products = fp32-equivalent, see gemm_bf16.hip) GEMM for gfx950, built around
+// LDS-DMA: C[M,N] (+)= A[M,K] · B[N,K]^T (+ bias), operands in the BLOCKED plane layout written by split.hip.
+//
+// Blocked layout of an operand [rows][k] (ld = 3*kpad, kpad % 64 == 0, buffer holds cdiv(rows,64)*64 rows):
+//   element (r, k, plane pl) at  (r/64)*(64*ld) + (k/16)*3072 + (pl*2 + (k%16)/8)*512 + (r%64)*8 + k%8   [bf16 units]
+// i.e. for every 64-row block and every 16-wide k chunk a contiguous 6 KB record of six 1-KB "pieces"; piece
+// (pl, half) holds, for the 64 rows in order, the 16 bytes the 32x32x16 MFMA wants from lane (row, half).  One
+// global_load_lds_dwordx4 wave-instruction moves one piece (64 lanes x 16 B, contiguous in HBM and in LDS), so the
+// tile is staged without touching a VGPR, without ds_write instructions and without any address arithmetic beyond a
+// running pointer; fragment reads are 512-B contiguous per half-wave (conflict-free, no padding, no swizzle).
+//
+// Tile 256x256, k chunk 16 per stage (48 KB), 3-stage ring (144 KB of the 160-KB LDS, one workgroup per CU), 8 waves
+// as 2(M) x 4(N), wave tile 128x64 = 4x2 MFMA tiles -> 18 ds_read_b128 feed 48 MFMAs per stage (0.375 reads per MFMA;
+// the 128x128 / 64x64-per-wave form needs 0.5 and its LDS pipe was the limiter).  Stage s+2 is requested right
+// after the barrier that opens stage s and stays in flight across the next barrier (counted vmcnt, raw s_barrier).
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace s2vt {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int XT = 256;                    // tile rows = tile cols
+constexpr int X_REC = 6144;                // bytes of one (64-row block, k16 chunk) record: 6 pieces x 1 KB
+constexpr int X_STAGE = 8 * X_REC;         // 4 A records + 4 B records
+constexpr int X_NS = 3;                    // ring depth
+
+struct GemmX3Args {
+    int M, N, K;                              // K = padded k extent of this call (multiple of 64)
+    const unsigned short* A; int64_t lda;     // blocked planes; row-block stride = 64 * lda elements
+    const unsigned short* B; int64_t ldb;
+    float* C; int64_t ldc; RowMap cmap;
+    const float* bias;
+    int accumulate;
+    int ksplit;
+    float* slabs;
+};
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[X_NS * X_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int ntn = (p.N + XT - 1) / XT, ntm = (p.M + XT - 1) / XT;
+    const int nwg = ntm * ntn, cpx = (nwg + 7) >> 3;
+    const int t = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= cpx || t >= nwg) return;
+    constexpr int GM = 4;
+    const int gsz = GM * ntn, grp = t / gsz, first_m = grp * GM;
+    const int gm = (ntm - first_m < GM) ? (ntm - first_m) : GM;
+    const int tm = first_m + (t % gsz) % gm, tn = (t % gsz) / gm;
+    const int m0 = tm * XT, n0 = tn * XT;
+    const int kbeg = blockIdx.y * p.ksplit;
+    const int kend = (kbeg + p.ksplit < p.K) ? kbeg + p.ksplit : p.K;
+    const int nk = (kend - kbeg) >> 4;                 // k16 stages
+
+    // loader role: waves 0-3 stream the four A row-blocks of the tile, waves 4-7 the four B row-blocks; a row-block
+    // past the operand's last one is clamped onto it (its outputs are never stored)
+    const unsigned char* src;
+    {
+        const bool isA = wave < 4;
+        const int nrb = ((isA ? p.M : p.N) + 63) >> 6;
+        int rb = ((isA ? m0 : n0) >> 6) + (wave & 3);
+        rb = rb < nrb ? rb : nrb - 1;
+        const unsigned short* base = isA ? p.A : p.B;
+        const int64_t ld = isA ? p.lda : p.ldb;
+        src = reinterpret_cast<const unsigned char*>(base + (int64_t)rb * 64 * ld) + (int64_t)(kbeg >> 4) * X_REC + lane * 16;
+    }
+    unsigned char* const ldst = smem + wave * X_REC;   // + stage * X_STAGE + piece * 1024 (+ lane * 16 by the DMA)
+    auto request = [&](int s) {                        // stage s of this tile's k range -> ring slot s % 3
+        const unsigned char* g = src + (int64_t)s * X_REC;
+        unsigned char* l = ldst + (s % X_NS) * X_STAGE;
+#if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE == 1     // timing experiment: no global traffic (results are garbage)
+        if (p.K > 0) return;
+#endif
+#pragma unroll
+        for (int j = 0; j < 6; ++j) glds16(g + j * 1024, l + j * 1024);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // fragment addresses inside a stage: A record (wm*2 + mi/2), row (mi&1)*32 + li; B record 4 + wn, row ni*32 + li
+    const int a_off = (wm * 2) * X_REC + lh * 1024 + li * 16;
+    const int b_off = (4 + wn) * X_REC + lh * 1024 + li * 16;
+
+#ifndef S2VT_X3_SPREAD
+#define S2VT_X3_SPREAD 1      // 1: one DMA request after each of the six MFMA groups; 0: all six right after the barrier
+#endif
+    // One k16 stage.  MORE (compile time): stage s+2 exists and is requested during this stage.
+    auto stage = [&](int s, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        // stage s has landed for this wave once at most the 6 requests of stage s+1 are outstanding; the barrier makes
+        // that true for every wave's pieces and also says everyone is done reading slot (s+2)%3 (= stage s-1)
+        if (MORE || s + 1 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const unsigned char* g2 = src + (int64_t)(s + 2) * X_REC;
+        unsigned char* l2 = ldst + ((s + 2) % X_NS) * X_STAGE;
+        if (MORE && !S2VT_X3_SPREAD) request(s + 2);
+        const unsigned char* st = smem + (s % X_NS) * X_STAGE;
+        bf16x8 a[3][4], b[3][2];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+                a[pl][mi] = *reinterpret_cast<const bf16x8*>(st + a_off + (mi >> 1) * X_REC + pl * 2048 + (mi & 1) * 512);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                b[pl][ni] = *reinterpret_cast<const bf16x8*>(st + b_off + pl * 2048 + ni * 512);
+        }
+#if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE == 2     // timing experiment: operands staged and read, no MFMA
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(a[pl][mi]));
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) asm volatile("" ::"v"(b[pl][ni]));
+        }
+        if (MORE && S2VT_X3_SPREAD) request(s + 2);
+        if (p.K > 0) return;
+#endif
+        // six plane products, smallest terms first; product-major order keeps 8 independent MFMAs between two
+        // updates of the same accumulator.  The DMA requests of stage s+2 are spread over the MFMA groups: issuing
+        // one costs the wave ~100 cycles, which a running MFMA group hides
+#define X3_PROD(PA, PB)                                                                                          \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)            \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][mi], b[PB][ni], acc[mi][ni], 0, 0, 0);
+#if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE == 1     // timing experiment: no global traffic (results are garbage)
+#define X3_REQ(J)
+#else
+#define X3_REQ(J) if (MORE && S2VT_X3_SPREAD) glds16(g2 + (J) * 1024, l2 + (J) * 1024);
+#endif
+        X3_PROD(1, 1) X3_REQ(0) X3_PROD(0, 2) X3_REQ(1) X3_PROD(2, 0) X3_REQ(2) X3_PROD(0, 1) X3_REQ(3) X3_PROD(1, 0) X3_REQ(4)
+        X3_PROD(0, 0)
+        X3_REQ(5)
+#undef X3_REQ
+#undef X3_PROD
+    };
+    request(0);
+    if (nk > 1) request(1);
+    int s = 0;
+    for (; s + 2 < nk; ++s) stage(s, std::true_type{});
+    for (; s < nk; ++s) stage(s, std::false_type{});
+
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (m >= p.M) continue;
+            if (p.slabs) {
+                float* srow = p.slabs + ((int64_t)blockIdx.y * p.M + m) * p.N;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int n = n0 + wn * 64 + ni * 32 + li;
+                    if (n < p.N) srow[n] = acc[mi][ni][r];
+                }
+                continue;
+            }
+            float* crow = p.C + (int64_t)map_row(p.cmap, m) * p.ldc;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int n = n0 + wn * 64 + ni * 32 + li;
+                if (n >= p.N) continue;
+                float v = acc[mi][ni][r];
+                if (p.bias) v += p.bias[n];
+                if (p.accumulate) v += crow[n];
+                crow[n] = v;
+            }
+        }
+    }
+}
+
+int splitk_reduce(hipStream_t stream, const float* slabs, int nsplit, int M, int N, float* C, int64_t ldc, RowMap cmap,
+                  const float* bias, bool accumulate);
+
+// A, B: blocked 3-plane operands (see the header of this file); K = their common padded k extent for this call.
+int gemm_x3(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
+            int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
+            size_t splitk_ws_floats) {
+    if (M <= 0 || N <= 0) return 0;
+    S2VT_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= 3 * (int64_t)K && ldb >= 3 * (int64_t)K &&
+                     (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0,
+                 "gemm_x3: K must be the zero-padded multiple of 64 of the blocked plane layout, operands 16-B aligned");
+    GemmX3Args p;
+    p.M = M; p.N = N; p.K = K;
+    p.A = A; p.lda = lda;
+    p.B = B; p.ldb = ldb;
+    p.C = C; p.ldc = ldc; p.cmap = cmap; p.bias = bias; p.accumulate = accumulate ? 1 : 0;
+    const int tiles = cdiv(M, XT) * cdiv(N, XT);
+    // one workgroup per CU: split K until the grid is a whole number of 256-CU rounds (>= 90 % full) or K runs out
+    int nsplit = 1;
+    if (splitk_ws && K >= 512) {
+        double best_eff = 0.0;
+        for (int n = 1; n <= 16; ++n) {
+            if (n > 1 && (K / n < 256 || (size_t)n * M * N > splitk_ws_floats)) break;
+            const int total = tiles * n;
+            const double eff = (total / 256.0) / (double)((total + 255) / 256);
+            if (eff > best_eff + 0.03) { best_eff = eff; nsplit = n; }
+            if (eff >= 0.9) break;
+        }
+    }
+    p.ksplit = (nsplit > 1) ? cdiv(cdiv(K, nsplit), 64) * 64 : K;
+    if (nsplit > 1) nsplit = cdiv(K, p.ksplit);
+    p.slabs = (nsplit > 1) ? splitk_ws : nullptr;
+    const dim3 grid(cdiv(tiles, 8) * 8, nsplit);
+    hipLaunchKernelGGL(gemm_x3_kernel, grid, dim3(512), 0, stream, p);
+    S2VT_LAUNCH_CHECK("gemm_x3_kernel");
+    if (nsplit > 1) return splitk_reduce(stream, splitk_ws, nsplit, M, N, C, ldc, cmap, bias, accumulate);
+    return 0;
+}
+
+}  // namespace s2vt

@@ -26,8 +26,16 @@ __device__ __forceinline__ void split3(float x, unsigned short (&o)[3]) {
     }
 }
 
-// Packed plane layout (see gemm_bf16.hip): element (r, k, pl) at r*ldo + (k/32)*(32*NP) + pl*32 + k%32, ldo = NP*kpad.
+// Plane layouts.  1 plane (bf16 mode, gemm_bf16.hip / lstm_bf16.hip): plain k-major rows, element (r, k) at r*ldo + k.
+// 3 planes (split precision, gemm_x3.hip): BLOCKED - per 64-row block and 16-wide k chunk one 6-KB record of six
+// 1-KB pieces (plane, k half), each piece = 64 rows x 8 consecutive k:
+//   (r/64)*(64*ldo) + (k/16)*3072 + (pl*2 + (k%16)/8)*512 + (r%64)*8 + k%8,   ldo = 3*kpad.
+// S2VT_X3_ROWS (build define) restores the superseded row layout r*ldo + (k/32)*96 + pl*32 + k%32.
 __device__ __forceinline__ int64_t packed_off(int64_t r, int k, int pl, int64_t ldo, int np) {
+#ifndef S2VT_X3_ROWS
+    if (np == 3)
+        return (r >> 6) * (64 * ldo) + (int64_t)(k >> 4) * 3072 + (pl * 2 + ((k >> 3) & 1)) * 512 + (r & 63) * 8 + (k & 7);
+#endif
     return r * ldo + (int64_t)(k >> 5) * (32 * np) + pl * 32 + (k & 31);
 }
 
@@ -131,7 +139,8 @@ __global__ __launch_bounds__(256) void split_dual_kernel(const float* in, int64_
         colpart[(int64_t)blockIdx.y * cols + c0 + threadIdx.x] = sum;
     }
     for (int s = threadIdx.x; s < 64 * 8; s += 256) {
-        const int a = s >> 3, bq = (s & 7) * 8;       // a: line index, bq: start of an 8-element run
+        // a: line index, bq: start of an 8-element run.  Blocked layout: a wave writes one 1-KB piece (64 lines x 16 B)
+        const int a = (NP == 3) ? (s & 63) : (s >> 3), bq = (NP == 3) ? (s >> 6) * 8 : (s & 7) * 8;
         if (out_r) {                                   // operand row = input row r0+a, k = input cols c0+bq..+7
             const int r = r0 + a, c = c0 + bq;
             if (r < rows && c < kpad_r) {
@@ -206,6 +215,11 @@ int split_planes(hipStream_t s, int nplanes, bool transpose, const float* in, in
                      (reinterpret_cast<uintptr_t>(out) & 15) == 0,
                  "split_planes: kpad must be a multiple of 64, ldo >= nplanes*kpad, output 16-B aligned");
     if (rows <= 0 || cols <= 0) return 0;
+    if (nplanes == 3) {     // blocked layout: the tiled kernel writes whole 1-KB pieces in either orientation
+        S2VT_REQUIRE(kpad >= (transpose ? rows : cols) && out_rows_pad >= (transpose ? cols : rows), "split_planes: output too small");
+        return transpose ? split_planes_dual(s, 3, in, ld, imap, rows, cols, nullptr, 0, 0, out, ldo, kpad, nullptr)
+                         : split_planes_dual(s, 3, in, ld, imap, rows, cols, out, ldo, kpad, nullptr, 0, 0, nullptr);
+    }
     if (!transpose) {
         S2VT_REQUIRE(kpad >= cols && out_rows_pad >= rows, "split_planes: output too small");
         const int64_t nq = (int64_t)out_rows_pad * (kpad / 8);

@@ -26,7 +26,7 @@ for name, defs in VARIANTS.items():
     h = torch.empty(T * B, H, device=dev); c = torch.empty(T * B, H, device=dev)
     M, N, K = 10176, 4000, 3072
     a = torch.randn(M, K, device=dev); b = torch.randn(N, K, device=dev)
-    pa = torch.empty(M, 3 * K, dtype=torch.int16, device=dev); pb = torch.empty(N, 3 * K, dtype=torch.int16, device=dev)
+    pa = torch.empty((M + 63) // 64 * 64, 3 * K, dtype=torch.int16, device=dev); pb = torch.empty((N + 63) // 64 * 64, 3 * K, dtype=torch.int16, device=dev)
     cc = torch.empty(M, N, device=dev)
     s0, s1 = torch.cuda.Stream(), torch.cuda.Stream(priority=-1)
     st0 = vp(torch.cuda.current_stream().cuda_stream)

@@ -15,7 +15,7 @@ for tag in ("fetch", "write", "l2"):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
             fam = None
-            for key in ("gemm_bf16_nt_kernel<3>", "gemm_f32_kernel", "lstm_step_fwd_kernel", "lstm_step_bwd_kernel",
+            for key in ("gemm_x3_kernel", "gemm_f32_kernel", "lstm_step_fwd_kernel", "lstm_step_bwd_kernel",
                         "split_dual_kernel", "logits_argmax_kernel", "ce_row_kernel", "ce_bwd_kernel"):
                 if key in n:
                     fam = key

@@ -9,7 +9,7 @@ M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (5056, 12000
 vp, i64 = ctypes.c_void_p, ctypes.c_int64
 dev = "cuda:0"
 a = torch.randn(M, K, device=dev); b = torch.randn(N, K, device=dev) * 0.05
-pa = torch.empty(M, 3 * K, dtype=torch.int16, device=dev); pb = torch.empty(N, 3 * K, dtype=torch.int16, device=dev)
+pa = torch.empty((M + 63) // 64 * 64, 3 * K, dtype=torch.int16, device=dev); pb = torch.empty((N + 63) // 64 * 64, 3 * K, dtype=torch.int16, device=dev)
 c = torch.empty(M, N, device=dev)
 st = vp(torch.cuda.current_stream().cuda_stream)
 lib.s2vt_split_planes(3, 0, vp(a.data_ptr()), i64(K), M, K, vp(pa.data_ptr()), i64(3 * K), K, M, st)
