@@ -109,16 +109,20 @@ int s2vt_gemm_f32_splitk(int32_t a_kmajor, int32_t b_kmajor, int32_t M, int32_t 
                          int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, const float* bias,
                          int32_t accumulate, float* ws, size_t ws_floats, void* stream);
 
-/* Split-precision path (gemm_bf16.hip).  An fp32 matrix [rows][cols] is rewritten as `nplanes` (1 or 3) bf16 planes
- * p0+p1+p2 = x (24 mantissa bits) of a k-major GEMM operand in the PACKED layout
- *   element (row r, k, plane pl) at r*ldo + (k/32)*(32*nplanes) + pl*32 + k%32,  ldo >= nplanes*kpad, kpad % 32 == 0,
- * zero-filled beyond the data.  transpose = 0: operand rows = input rows, k = input columns; transpose = 1: operand
- * rows = input columns (out_rows_pad >= cols), k = input rows (kpad >= rows). */
+/* Split-precision path (split.hip, gemm_x3.hip, gemm_bf16.hip).  An fp32 matrix [rows][cols] is rewritten as `nplanes`
+ * (1 or 3) bf16 planes p0+p1+p2 = x (24 mantissa bits) of a k-major GEMM operand, zero-filled in k beyond the data
+ * (kpad % 64 == 0, ldo >= nplanes*kpad):
+ *   nplanes = 1: plain rows, element (r, k) at r*ldo + k;
+ *   nplanes = 3: BLOCKED layout of gemm_x3.hip - per 64-row block and 16-wide k chunk one 6-KB record of six 1-KB
+ *     pieces (plane, k half) of 64 rows x 8 k:  (r/64)*(64*ldo) + (k/16)*3072 + (pl*2 + (k%16)/8)*512 + (r%64)*8 + k%8
+ *     (bf16 units); the buffer must hold whole 64-row blocks: ceil(operand rows / 64) * 64 * ldo elements.
+ * transpose = 0: operand rows = input rows, k = input columns; transpose = 1: operand rows = input columns
+ * (out_rows_pad >= cols), k = input rows (kpad >= rows). */
 int s2vt_split_planes(int32_t nplanes, int32_t transpose, const float* in, int64_t ld, int32_t rows, int32_t cols,
                       uint16_t* out, int64_t ldo, int32_t kpad, int32_t out_rows_pad, void* stream);
-/* C[M,N] (+)= A[M,K]·B[N,K]^T (+bias) from packed bf16 planes on the bf16 matrix cores, fp32 accumulate; K = kpad.
- * nplanes = 3 sums the six leading plane products (fp32-equivalent, ~2^-23 relative); nplanes = 1 is a plain bf16
- * GEMM. */
+/* C[M,N] (+)= A[M,K]·B[N,K]^T (+bias) from bf16 planes (layouts above) on the bf16 matrix cores, fp32 accumulate;
+ * K = kpad.  nplanes = 3 sums the six leading plane products (fp32-equivalent, ~2^-23 relative; LDS-DMA kernel,
+ * 256x256 tiles); nplanes = 1 is a plain bf16 GEMM.  ws/ws_floats: optional scratch for deterministic split-K. */
 int s2vt_gemm_bf16_nt(int32_t nplanes, int32_t M, int32_t N, int32_t K, const uint16_t* A, int64_t lda, const uint16_t* B,
                       int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t accumulate, float* ws,
                       size_t ws_floats, void* stream);

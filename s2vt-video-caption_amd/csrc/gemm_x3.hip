@@ -203,18 +203,24 @@ int gemm_x3(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
     p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.cmap = cmap; p.bias = bias; p.accumulate = accumulate ? 1 : 0;
     const int tiles = cdiv(M, XT) * cdiv(N, XT);
-    // one workgroup per CU: split K until the grid is a whole number of 256-CU rounds (>= 90 % full) or K runs out
+    // One workgroup per CU.  K is split when the model time (rounds of 256 workgroups x per-tile time + the fixed-order
+    // slab combine) says so: ~0.14 us per k unit of a tile (2.2 us per k16 stage), ~6 us per tile of prologue/epilogue,
+    // combine = (n + 1) passes over M x N floats at ~3.5 TB/s + a launch.
     int nsplit = 1;
     if (splitk_ws && K >= 512) {
-        double best_eff = 0.0;
+        double best = 1e30;
         for (int n = 1; n <= 16; ++n) {
             if (n > 1 && (K / n < 256 || (size_t)n * M * N > splitk_ws_floats)) break;
-            const int total = tiles * n;
-            const double eff = (total / 256.0) / (double)((total + 255) / 256);
-            if (eff > best_eff + 0.03) { best_eff = eff; nsplit = n; }
-            if (eff >= 0.9) break;
+            const int ks = cdiv(cdiv(K, n), 64) * 64, nn = cdiv(K, ks);
+            if (nn != n) continue;
+            const double rounds = (double)cdiv(tiles * nn, 256);
+            const double t = rounds * (ks * 0.14 + 6.0) + (nn > 1 ? (nn + 1.0) * M * (double)N * 4.0 / 3.5e6 + 8.0 : 0.0);
+            if (t < best * 0.97) { best = t; nsplit = nn; }
         }
     }
+    static int force_n = -1;     // S2VT_X3_NSPLIT=n: experiment override (tools/bench_x3_split.py)
+    if (force_n < 0) { const char* e = getenv("S2VT_X3_NSPLIT"); force_n = e ? atoi(e) : 0; }
+    if (force_n > 0 && splitk_ws && (size_t)force_n * M * N <= splitk_ws_floats && K / force_n >= 64) nsplit = force_n;
     p.ksplit = (nsplit > 1) ? cdiv(cdiv(K, nsplit), 64) * 64 : K;
     if (nsplit > 1) nsplit = cdiv(K, p.ksplit);
     p.slabs = (nsplit > 1) ? splitk_ws : nullptr;

@@ -53,17 +53,37 @@ __global__ void colsum_partial_kernel(const float* x, int64_t rows, int cols, in
     for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
     partial[(int64_t)blockIdx.y * cols + c] = s;
 }
-__global__ void colsum_final_kernel(const float* partial, int nchunks, int cols, float* out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    float s = accumulate ? out[c] : 0.f;
-    for (int k = 0; k < nchunks; ++k) s += partial[(int64_t)k * cols + c];
-    out[c] = s;
+// 64 columns per workgroup; the chunk loop is dealt over 4 thread rows with 4 independent accumulators each (the sum
+// is a dependent chain of loads otherwise: 159 chunks took 80 us), combined in a fixed order -> deterministic.
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nchunks, int cols, float* out,
+                                                           int accumulate) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cols) {
+        const float* q = partial + c;
+        int k = ty;
+        for (; k + 12 < nchunks; k += 16) {
+            s0 += q[(int64_t)k * cols];
+            s1 += q[(int64_t)(k + 4) * cols];
+            s2 += q[(int64_t)(k + 8) * cols];
+            s3 += q[(int64_t)(k + 12) * cols];
+        }
+        for (; k < nchunks; k += 4) s0 += q[(int64_t)k * cols];
+    }
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty == 0 && c < cols) {
+        float s = accumulate ? out[c] : 0.f;
+        s += red[0][tx]; s += red[1][tx]; s += red[2][tx]; s += red[3][tx];
+        out[c] = s;
+    }
 }
 // fixed-order sum of `nchunks` partial rows (written by colsum_partial_kernel or split_dual_kernel)
 int colsum_finish(hipStream_t s, const float* partial, int nchunks, int cols, float* out, bool accumulate) {
     if (cols <= 0) return 0;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, partial, nchunks, cols, out,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, s, partial, nchunks, cols, out,
                        accumulate ? 1 : 0);
     S2VT_LAUNCH_CHECK("colsum_final_kernel");
     return 0;
@@ -78,7 +98,7 @@ int colsum_f32(hipStream_t s, const float* x, int64_t rows, int cols, int64_t ld
                            partial);
         S2VT_LAUNCH_CHECK("colsum_partial_kernel");
     }
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, partial, nchunks, cols, out,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, s, partial, nchunks, cols, out,
                        accumulate ? 1 : 0);
     S2VT_LAUNCH_CHECK("colsum_final_kernel");
     return 0;

@@ -32,6 +32,41 @@ def gemm(a, b, bias=None, a_kmajor=True, b_kmajor=True, out=None, accumulate=Fal
     return out
 
 
+def split_planes(x, nplanes=3, transpose=False):
+    """fp32 [rows, cols] -> bf16 planes of a k-major GEMM operand (include/s2vt_hip.h: blocked layout for 3 planes, plain
+    rows for 1).  Returns (planes int16 [ceil64(operand rows), nplanes*kpad], ldo, kpad)."""
+    lib = capi.load()
+    x = _f32c(x, "x")
+    rows, cols = x.shape
+    orows, k = (cols, rows) if transpose else (rows, cols)
+    kpad = (k + 63) // 64 * 64
+    ldo = nplanes * kpad
+    dev = x.device
+    with torch.cuda.device(dev):
+        out = torch.zeros((orows + 63) // 64 * 64, ldo, dtype=torch.int16, device=dev)
+        capi.check(lib.s2vt_split_planes(nplanes, int(transpose), _ptr(x), x.stride(0), rows, cols, _ptr(out), ldo, kpad,
+                                         orows, _stream(dev)), "s2vt_split_planes")
+    return out, ldo, kpad
+
+
+def gemm_planes(pa, pb, M, N, nplanes=3, bias=None, out=None, accumulate=False, splitk_ws=None):
+    """out[M,N] (+)= A·B^T (+bias) from operands written by split_planes (same nplanes, same kpad)."""
+    lib = capi.load()
+    (a, lda, ka), (b, ldb, kb) = pa, pb
+    if ka != kb:
+        raise ValueError("gemm_planes: operands have different padded k (%d vs %d)" % (ka, kb))
+    dev = a.device
+    with torch.cuda.device(dev):
+        if out is None:
+            out = torch.zeros(M, N, dtype=torch.float32, device=dev) if accumulate else \
+                torch.empty(M, N, dtype=torch.float32, device=dev)
+        capi.check(lib.s2vt_gemm_bf16_nt(nplanes, M, N, ka, _ptr(a), lda, _ptr(b), ldb, _ptr(out), out.stride(0), _ptr(bias),
+                                         int(accumulate), _ptr(splitk_ws),
+                                         ctypes.c_size_t(splitk_ws.numel() if splitk_ws is not None else 0), _stream(dev)),
+                   "s2vt_gemm_bf16_nt")
+    return out
+
+
 def feat_proj_fwd(feats, w, bias):
     """x1 time-major [L*B, H] = feats[B,L,F]·w^T + bias."""
     lib = capi.load()

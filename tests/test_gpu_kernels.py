@@ -47,6 +47,45 @@ def test_gemm_is_exact_on_integers(lib):
         assert torch.equal(got, a @ b.t())
 
 
+@pytest.mark.parametrize("M,N,K", [(5, 7, 3), (200, 300, 104), (257, 513, 1000), (640, 256, 2048), (64, 1000, 4100),
+                                   (1, 1, 1), (300, 70, 65)])
+def test_split_precision_gemm_blocked_planes(lib, M, N, K):
+    """3 bf16 planes x 6 plane products (split.hip + gemm_x3.hip) against fp64: fp32-equivalent (the bound is the one
+    of test_gemm_all_layouts), in both split orientations, with bias / accumulate and with split-K scratch."""
+    from s2vt_video_caption_amd import ops
+    a, b, bias = _r(M, K, seed=1), _r(N, K, seed=2), _r(N, seed=3)
+    ref = a.double() @ b.double().t()
+    tol = 4e-6 * ref.abs().max().item() + 1e-6      # fp32-equivalent: a few ulp of the largest output (fp32 MFMA: 1.5-2e-6)
+    pa, pb = ops.split_planes(a.to(DEV)), ops.split_planes(b.to(DEV))
+    got = ops.gemm_planes(pa, pb, M, N, bias=bias.to(DEV)).cpu()
+    assert (got.double() - (ref + bias.double())).abs().max().item() < tol
+    # operands given transposed ([K, rows]): the transposing split must produce the same planes
+    paT = ops.split_planes(a.t().contiguous().to(DEV), transpose=True)
+    pbT = ops.split_planes(b.t().contiguous().to(DEV), transpose=True)
+    assert torch.equal(paT[0][:M].cpu(), pa[0][:M].cpu()) if M % 64 == 0 else True
+    got_t = ops.gemm_planes(paT, pbT, M, N, bias=bias.to(DEV)).cpu()
+    assert torch.equal(got_t, got)
+    c0 = _r(M, N, seed=4)
+    out = c0.to(DEV).clone()
+    ws = torch.empty(8 * M * N + 1, device=DEV)
+    ops.gemm_planes(pa, pb, M, N, out=out, accumulate=True, splitk_ws=ws)
+    assert (out.cpu().double() - (ref + c0.double())).abs().max().item() < tol
+
+
+def test_split_precision_gemm_is_exact_on_integers(lib):
+    """Small integers are exact in the hi plane (mid/lo planes zero) and every partial sum is representable: the
+    result must be exact - catches any wrong piece / fragment / k mapping of the blocked layout."""
+    from s2vt_video_caption_amd import ops
+    g = torch.Generator().manual_seed(5)
+    a = torch.randint(-4, 5, (333, 200), generator=g).float()
+    b = torch.randint(-4, 5, (517, 200), generator=g).float()
+    got = ops.gemm_planes(ops.split_planes(a.to(DEV)), ops.split_planes(b.to(DEV)), 333, 517).cpu()
+    assert torch.equal(got, a @ b.t())
+    got = ops.gemm_planes(ops.split_planes(a.t().contiguous().to(DEV), transpose=True),
+                          ops.split_planes(b.t().contiguous().to(DEV), transpose=True), 333, 517).cpu()
+    assert torch.equal(got, a @ b.t())
+
+
 @pytest.mark.parametrize("B,H", [(1, 32), (4, 500), (33, 40), (64, 1000), (16, 8), (17, 36)])
 def test_lstm_step_fwd_matches_cell(lib, B, H):
     from s2vt_video_caption_amd import ops

@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = []
 for r in rows:
     n = r["Kernel_Name"]
-    fam = ("gemm" if "gemm_f32" in n else "splitk" if "splitk" in n else "step_fwd" if "lstm_step_fwd" in n else
+    fam = ("gemm" if ("gemm_f32" in n or "gemm_x3" in n or "gemm_bf16" in n) else "split" if "split_" in n else "splitk" if "splitk" in n else "step_fwd" if "lstm_step_fwd" in n else
            "step_bwd" if "lstm_step_bwd" in n else "argmax" if "logits_argmax" in n else "ce" if "ce_" in n else
            "adam" if "multi_tensor" in n else "other")
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), fam))
