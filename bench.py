@@ -231,7 +231,7 @@ def main():
             step_us = sf_ms * 1e3 / (2 * T)           # average launch of lstm_step_fwd_kernel (both layers)
             step_gbs = (pair_bytes / 2) / (step_us * 1e-6) / 1e9
             if bf:
-                gk, gpeak, gnote = "gemm_bf16_nt_kernel<1>", MFMA_BF16_PEAK_TF, "bf16 operands, fp32 accumulate"
+                gk, gpeak, gnote = "gemm_b1_kernel", MFMA_BF16_PEAK_TF, "bf16 operands, fp32 accumulate"
             elif x3:   # each algorithmic fp32 product costs six bf16 MFMA products (three planes per operand)
                 gk, gpeak = "gemm_x3_kernel", MFMA_BF16_PEAK_TF / 6.0
                 gnote = ("achieved = algorithmic (fp32-equivalent) FLOP/s; peak = bf16 dense MFMA peak / 6 plane products; "
@@ -259,7 +259,7 @@ def main():
         log("profiled steps done (pipeline block %d)" % prev_blk)
         roof_gemm, roof_step = rooflines(live, "live, layers pipelined on two streams (block %d)" % prev_blk)
         roof_gemm_alone, roof_step_alone = rooflines(alone, "pipeline off: every kernel alone on the GPU")
-        gname = "gemm_bf16_nt_kernel<1>" if bf else ("gemm_x3_kernel" if x3 else "gemm_f32_kernel")
+        gname = "gemm_b1_kernel" if bf else ("gemm_x3_kernel" if x3 else "gemm_f32_kernel")
         fam = {gname: live["gemm"][0], "lstm_step_fwd_kernel": live["step_fwd"][0],
                "lstm_step_bwd_kernel": live["step_bwd"][0], "ce": live["ce"][0]}
         fam_alone = {gname: alone["gemm"][0], "lstm_step_fwd_kernel": alone["step_fwd"][0],

@@ -233,6 +233,10 @@ int gemm_bf16_nt(hipStream_t stream, int nplanes, int M, int N, int K, const uns
     if (x3_rows < 0) { const char* e = getenv("S2VT_X3_ROWS"); x3_rows = e ? atoi(e) : 0; }
     if (nplanes == 3 && !x3_rows)
         return gemm_x3(stream, M, N, K, A, lda, B, ldb, C, ldc, cmap, bias, accumulate, splitk_ws, splitk_ws_floats);
+    static int b1_old = -1;        // S2VT_B1_OLD=1: the superseded register-staged 128x128 kernel below
+    if (b1_old < 0) { const char* e = getenv("S2VT_B1_OLD"); b1_old = e ? atoi(e) : 0; }
+    if (nplanes == 1 && !b1_old)
+        return gemm_b1(stream, M, N, K, A, lda, B, ldb, C, ldc, cmap, bias, accumulate, splitk_ws, splitk_ws_floats);
     const int BKc = (nplanes == 3) ? 32 : 64;
     S2VT_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= (int64_t)nplanes * K &&
                      ldb >= (int64_t)nplanes * K && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
