@@ -74,7 +74,7 @@ class S2VT(nn.Module):
         if mode == 'train':
             if targets is None:
                 raise ValueError("mode='train' needs targets")
-            return _F.train_forward(feats, targets, params)
+            return _F.train_forward(feats, targets, params, grad_sink=_F.grad_sink_for(self))
         elif mode == 'test':
             return _F.greedy_decode(feats, params, self.sos_ix)
         return None                                        # the reference falls through for unknown modes

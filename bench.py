@@ -142,7 +142,7 @@ def main():
         opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
     except Exception:
         opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    reducer = dp.FlatGradAllReducer(model.parameters()) if use_pg else None
+    reducer = dp.FlatGradAllReducer(model.parameters()).attach(model) if use_pg else None
 
     # this rank's shard of the synthetic global batch (seeded recipe); resident in HBM
     feats, caps, mask = synth.make_batch(B, L, F, V, seed=1234 + rank)

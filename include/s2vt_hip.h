@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define S2VT_ABI_VERSION 1
+#define S2VT_ABI_VERSION 2
 
 typedef struct s2vt_dims {
     int32_t B, L, F, H, E, V;
@@ -71,6 +71,14 @@ size_t s2vt_train_workspace_bytes(const s2vt_dims* d);
  *   logits  [B, L-1, V] out.  The workspace then holds what s2vt_train_backward needs. */
 int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
                        int64_t targets_ld, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Data-parallel overlap (no reference counterpart: the reference is single-device).  After s2vt_train_backward has
+ * RETURNED (all of its work is enqueued), make `stream` wait until a group of that call's parameter gradients is
+ * final, so that their all-reduce can run under the rest of the backward:
+ *   group 0 = out_linear (weight, bias): final ~1 ms into the backward;
+ *   group 1 = word_rnn (4 tensors) + embedding: final before the vid_rnn / feat_linear weight-gradient GEMMs.
+ * The remaining gradients (vid_rnn, feat_linear) are final when the backward's own stream is. */
+int s2vt_backward_wait_grads(int32_t group, void* stream);
 
 /* Autograd of the above (loss.backward(), train.py:124) given dlogits [B, L-1, V] (contiguous).
  * dfeats [B, L, F] may be NULL (nothing reads it in the reference: SURVEY.md §3.1 note). */

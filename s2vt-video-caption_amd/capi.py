@@ -33,6 +33,8 @@ class Grads(ctypes.Structure):
 
 
 # name -> (restype, argtypes): every symbol include/s2vt_hip.h declares
+ABI_VERSION = 2          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
+
 SIGNATURES = {
     "s2vt_abi_version": (c_int32, []),
     "s2vt_last_error": (c_char_p, []),
@@ -41,6 +43,7 @@ SIGNATURES = {
                                      c_size_t, c_void_p]),
     "s2vt_train_backward": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_void_p, POINTER(Grads), c_void_p,
                                       c_void_p, c_size_t, c_void_p]),
+    "s2vt_backward_wait_grads": (c_int32, [c_int32, c_void_p]),
     "s2vt_decode_workspace_bytes": (c_size_t, [POINTER(Dims)]),
     "s2vt_greedy_decode": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_int32, c_void_p, c_void_p, c_size_t,
                                      c_void_p]),
@@ -102,8 +105,8 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the library lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.s2vt_abi_version() != 1:
-        raise S2VTHipError("libs2vt_hip.so ABI %d != 1" % lib.s2vt_abi_version())
+    if lib.s2vt_abi_version() != ABI_VERSION:
+        raise S2VTHipError("libs2vt_hip.so ABI %d != %d" % (lib.s2vt_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

@@ -322,6 +322,17 @@ static int gemm_mode() {
 // plane modes need every k-offset inside a packed operand to be a multiple of 64 (k = time*B + b): B % 64 == 0
 static bool planes_ok(const s2vt_dims& d) { return gemm_mode() != 0 && d.B % 64 == 0; }
 
+// "Gradient group is final" events of the last s2vt_train_backward on this thread's device (data-parallel overlap):
+// group 0 = out_linear (weight, bias), group 1 = word_rnn (4 tensors) + embedding; the rest is final with the call's stream.
+static hipEvent_t g_grad_ev[2] = {nullptr, nullptr};
+static bool g_grad_ev_set[2] = {false, false};
+static int grads_ready(int group, hipStream_t s) {
+    if (!g_grad_ev[group]) S2VT_HIP(hipEventCreateWithFlags(&g_grad_ev[group], hipEventDisableTiming));
+    S2VT_HIP(hipEventRecord(g_grad_ev[group], s));
+    g_grad_ev_set[group] = true;
+    return 0;
+}
+
 static int XP = 3;        // planes per operand of the running plane driver (3 or 1); set by the entry points
 static inline int pad64(int x) { return (x + 63) / 64 * 64; }
 struct PB { unsigned short* p; int64_t ld; int kpad; };       // packed planes of a k-major operand [rows][k]
@@ -619,6 +630,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = psplitT(lb, q.h2decT, 0, w.h2 + L * BH, H, perm(L - 1, B), R, H))) return rc;
     if ((rc = pgemm(lb, V, H, R, q.dlogT, 0, 0, q.h2decT, 0, 0, g->out_w, H, ID, nullptr, false))) return rc;
     if ((rc = colsum_finish(sx, w.colsum_c, cdiv(R, 64), V, g->out_b, false))) return rc;
+    if ((rc = grads_ready(0, sx))) return rc;
     if (!paired && (rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     const std::vector<int> bd = pipe_bounds(T, L, blk);
     if (paired) {
@@ -689,6 +701,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = pgemm(la, R, E, 4 * H, q.dg2, L * B, 0, q.weT, 0, 0, w.de, E, ID, nullptr, false))) return rc;
     if ((rc = fill_zero(st, g->emb_w, sizeof(float) * (size_t)V * E))) return rc;
     if ((rc = embedding_scatter_add(st, w.de, R, E, w.tok, g->emb_w))) return rc;
+    if ((rc = grads_ready(1, st))) return rc;
     // lane B: vid_rnn and feat_linear parameter gradients
     if ((rc = pgemm(lb, 4 * H, H, (T - 1) * B, q.dg1T, 0, B, q.h1T, 0, 0, g->vid_w_hh, H, ID, nullptr, false))) return rc;
     if ((rc = pgemm(lb, 4 * H, H, L * B, q.dg1T, 0, 0, q.x1T, 0, 0, g->vid_w_ih, H, ID, nullptr, false))) return rc;
@@ -815,6 +828,7 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
                     false)))
         return rc;
     if ((rc = colsum_f32(sx, dlogits, R, V, V, lb.colsum, g->out_b, false))) return rc;
+    if ((rc = grads_ready(0, sx))) return rc;
     if ((rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     const std::vector<int> bd = pipe_bounds(T, L, blk);
     for (size_t k = bd.size() - 1; k >= 1; --k) {
@@ -847,6 +861,7 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
         return rc;
     if ((rc = fill_zero(st, g->emb_w, sizeof(float) * (size_t)V * E))) return rc;
     if ((rc = embedding_scatter_add(st, w.de, R, E, w.tok, g->emb_w))) return rc;
+    if ((rc = grads_ready(1, st))) return rc;
     // lane B: vid_rnn and feat_linear parameter gradients                           (autograd of :67, :54)
     if ((rc = lgemm(lb, false, false, 4 * H, H, (T - 1) * B, w.s1 + B4H, 4 * H, ID, w.h1, H, ID, g->vid_w_hh, H, ID,
                     nullptr, false)))
@@ -906,6 +921,13 @@ static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
     }
     w.bytes = align_up(c.off, 256);
     return w;
+}
+
+int s2vt_backward_wait_grads(int32_t group, void* stream) {
+    S2VT_REQUIRE(group == 0 || group == 1, "s2vt_backward_wait_grads: group must be 0 (out_linear) or 1 (word_rnn + embedding)");
+    S2VT_REQUIRE(g_grad_ev_set[group], "s2vt_backward_wait_grads: no s2vt_train_backward has run yet");
+    S2VT_HIP(hipStreamWaitEvent((hipStream_t)stream, g_grad_ev[group], 0));
+    return 0;
 }
 
 size_t s2vt_decode_workspace_bytes(const s2vt_dims* d) {

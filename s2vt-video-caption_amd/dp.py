@@ -61,18 +61,71 @@ class FlatGradAllReducer:
         if start < n:
             self.buckets.append((start, n))
 
+        self.model = None
+        self.groups = None
+        self.comm_stream = None
+
+    def attach(self, model):
+        """Overlap mode for the HIP S2VT replica `model` (whose 13 parameters are exactly self.params):
+        * the backward WRITES its gradients straight into the flat buffer (no autograd accumulation pass, no zeroing);
+        * the all-reduce is issued per gradient group as soon as the library says the group is final
+          (s2vt_backward_wait_grads): out_linear ~1 ms into the backward, word_rnn + embedding before the
+          vid_rnn / feat_linear weight-gradient GEMMs, the rest at the end - on a side stream, under the backward."""
+        from . import functional
+        hip = model._hip_params()
+        by_id = {id(p): i for i, p in enumerate(self.params)}
+        if len(hip) != len(self.params) or any(id(p) not in by_id for p in hip):
+            raise ValueError("attach(model): the reducer must have been built from exactly this model's parameters")
+        functional.set_grad_sink(model, [self.params[by_id[id(p)]].grad for p in hip])
+        self.model = model
+        names = {id(p): n for n, p in model.named_parameters()}
+        group_of = lambda n: 0 if n.startswith("out_linear") else 1 if n.startswith(("word_rnn", "embedding")) else 2
+        groups = {0: [], 1: [], 2: []}
+        for p, (lo, hi) in zip(self.params, self.slices):
+            g = groups[group_of(names[id(p)])]
+            if g and g[-1][1] == lo:
+                g[-1] = (g[-1][0], hi)          # merge neighbours into one contiguous range
+            else:
+                g.append((lo, hi))
+        self.groups = groups
+        if self.flat.is_cuda:
+            self.comm_stream = torch.cuda.Stream(device=self.flat.device)
+        return self
+
     def zero_grad(self):
-        self.flat.zero_()
+        if self.model is None:                  # attached: the backward overwrites every gradient
+            self.flat.zero_()
 
     def all_reduce(self):
         """Average gradients over ranks (sum all-reduce, then * 1/W). No-op for a single process."""
         if self.world == 1 and not dist.is_initialized():
             return
+        if self.model is not None and self.flat.is_cuda:
+            return self._all_reduce_overlapped()
         works = [dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                  for (lo, hi) in reversed(self.buckets)]
         for w in works:
             w.wait()
         self.flat.mul_(1.0 / self.world)
+
+    def _all_reduce_overlapped(self):
+        """Called right after loss.backward() returned, i.e. with the whole backward ENQUEUED but mostly not executed."""
+        from . import capi
+        lib = capi.load()
+        main = torch.cuda.current_stream(self.flat.device)
+        cs = self.comm_stream
+        scale = 1.0 / self.world
+        with torch.cuda.stream(cs):
+            for g in (0, 1):
+                capi.check(lib.s2vt_backward_wait_grads(g, capi.c_void_p(cs.cuda_stream)), "s2vt_backward_wait_grads")
+                for lo, hi in self.groups[g]:
+                    dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                    self.flat[lo:hi].mul_(scale)
+            cs.wait_stream(main)                 # the remaining gradients are final with the backward's stream
+            for lo, hi in self.groups[2]:
+                dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+                self.flat[lo:hi].mul_(scale)
+        main.wait_stream(cs)
 
 
 def train_step(model, criterion, optimizer, feats, caps, mask, reducer=None):

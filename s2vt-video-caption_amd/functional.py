@@ -6,6 +6,7 @@ Mirrors the reference's operator surface for this path: `train_forward` is what
 (utils.py:11,22).  Everything here requires HIP tensors; CPU tensors raise.
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -52,7 +53,7 @@ def _dims(feats, params):
 
 class _TrainForward(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, targets, *params):
+    def forward(ctx, feats, targets, grad_sink, *params):
         lib = capi.load()
         feats = _f32c(feats, "feats")
         params = tuple(_f32c(p, "parameter") for p in params)
@@ -74,7 +75,7 @@ class _TrainForward(torch.autograd.Function):
                                               targets.stride(0), _ptr(logits), _ptr(ws), nbytes, _stream(dev)),
                        "s2vt_train_forward")
         ctx.save_for_backward(feats, *params)
-        ctx.ws, ctx.d, ctx.used = ws, d, False
+        ctx.ws, ctx.d, ctx.used, ctx.grad_sink = ws, d, False, grad_sink
         return logits
 
     @staticmethod
@@ -89,7 +90,16 @@ class _TrainForward(torch.autograd.Function):
         dev = feats.device
         dlogits = _f32c(dlogits, "dlogits")
         with torch.cuda.device(dev):
-            grads = [torch.empty_like(p) for p in params]
+            sink = ctx.grad_sink
+            if sink is not None:
+                # data-parallel mode (dp.FlatGradAllReducer.attach): the 13 gradients are WRITTEN (not accumulated)
+                # straight into the views of the flat all-reduce buffer; autograd gets None and leaves .grad alone
+                if len(sink) != len(params) or any(g.shape != p.shape or g.dtype != torch.float32 or not g.is_contiguous()
+                                                   or g.device != p.device for g, p in zip(sink, params)):
+                    raise capi.S2VTHipError("gradient sink does not match the 13 S2VT parameters")
+                grads = list(sink)
+            else:
+                grads = [torch.empty_like(p) for p in params]
             dfeats = torch.empty_like(feats) if ctx.needs_input_grad[0] else None
             ps = _params_struct(capi.Params, params)
             gs = _params_struct(capi.Grads, grads)
@@ -97,12 +107,31 @@ class _TrainForward(torch.autograd.Function):
                                                ctypes.byref(gs), _ptr(dfeats), _ptr(ws), ws.numel(), _stream(dev)),
                        "s2vt_train_backward")
         ctx.ws = None
-        return (dfeats, None) + tuple(grads)
+        if sink is not None:
+            return (dfeats, None, None) + (None,) * len(params)
+        return (dfeats, None, None) + tuple(grads)
 
 
-def train_forward(feats, targets, params):
-    """logits [B, L-1, V] of S2VT.forward(mode='train'); `params` in capi.PARAM_KEYS order."""
-    return _TrainForward.apply(feats, targets, *params)
+# model -> 13 gradient tensors (capi.PARAM_KEYS order) the backward writes into; kept OUT of the module's __dict__ so
+# that torch.save(model) checkpoints stay exactly the reference's layout
+_GRAD_SINKS = weakref.WeakKeyDictionary()
+
+
+def set_grad_sink(model, tensors):
+    if tensors is None:
+        _GRAD_SINKS.pop(model, None)
+    else:
+        _GRAD_SINKS[model] = tuple(tensors)
+
+
+def grad_sink_for(model):
+    return _GRAD_SINKS.get(model)
+
+
+def train_forward(feats, targets, params, grad_sink=None):
+    """logits [B, L-1, V] of S2VT.forward(mode='train'); `params` in capi.PARAM_KEYS order.  `grad_sink`: optional 13
+    tensors (same order) the backward writes the parameter gradients into instead of returning them to autograd."""
+    return _TrainForward.apply(feats, targets, grad_sink, *params)
 
 
 @torch.no_grad()

@@ -279,3 +279,44 @@ def test_bf16_mode_config3_arithmetic(lib):
     oids, marg = orc.greedy_decode(sd, feats, return_margins=True)
     if marg.min().item() > 1e-4:
         assert torch.equal(ids_bf16_mode, oids)
+
+
+@pytest.mark.parametrize("cfg,B", [("tiny", 3), ("c2", 64)])
+def test_dp_overlapped_allreduce_single_rank_rccl(lib, cfg, B):
+    """dp.FlatGradAllReducer.attach(): the backward writes its gradients straight into the flat buffer and the
+    all-reduce of each gradient group is issued on a side stream behind s2vt_backward_wait_grads.  With one rank
+    (RCCL world_size 1: sum == identity) two steps must leave exactly the parameters of the plain single-GPU loop;
+    the c2 case (B=64) goes through the split-precision / two-lane driver, tiny through the fp32-MFMA one."""
+    import socket
+    import torch.distributed as dist
+    import utils
+    from s2vt_video_caption_amd import dp
+    d = dict(synth.CONFIGS[cfg]); d["B"] = B
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=3)
+    feats, caps, mask = (t.to(DEV) for t in synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=77))
+    crit = utils.MaskCriterion()
+
+    def run(use_reducer):
+        m = _model(d, sd)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+        red = dp.FlatGradAllReducer(m.parameters()).attach(m) if use_reducer else None
+        losses = [float(dp.train_step(m, crit, opt, feats, caps, mask, red)) for _ in range(2)]
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+
+    ref_losses, ref_sd = run(False)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device(DEV))
+    try:
+        losses, got = run(True)
+    finally:
+        dist.destroy_process_group()
+    # The embedding gradient is a scatter-add with fp32 atomics (order-dependent rounding), so two runs of the SAME loop
+    # already differ in the last ulp; Adam then moves a parameter by <= lr whatever the gradient's size.  Bar: the loss
+    # trajectory to 1e-6 relative and all but a 1e-5 fraction of every tensor's elements within 1e-6.
+    for a, b in zip(losses, ref_losses):
+        assert abs(a - b) <= 1e-6 * abs(b), (losses, ref_losses)
+    for k in ref_sd:
+        diff = (got[k] - ref_sd[k]).abs()
+        assert (diff > 1e-6).float().mean().item() < 1e-5, (k, diff.max().item())

@@ -73,7 +73,7 @@ def main():
     early_stopping = EarlyStopping(patience=opt.early_stopping_patience, verbose=rank == 0,
                                    path=os.path.join(opt.save_path, start_time + 'stop.pth'))
     criterion = MaskCriterion()
-    reducer = dp.FlatGradAllReducer(model.parameters()) if world > 1 else None
+    reducer = dp.FlatGradAllReducer(model.parameters()).attach(model) if world > 1 else None
 
     for epoch in range(opt.epochs):
         if sampler is not None:
