@@ -28,48 +28,57 @@ __device__ __forceinline__ unsigned short f2bf(float x) {
 
 // acc[mi][ni] += A[32*MT rows, 0:K) · B[32*NT rows, 0:K)^T over this wave's chunks (K multiple of 64, zero padded).
 // arow/brow: per-lane row pointers for rows (lane/8 + 8 i); each lane moves the 16-B piece (lane % 8) of its rows.
-template <int MT, int NT>
+// PF chunks of the wave are in flight at any time (PF register sets, loops fully unrolled so they are statically
+// indexed).  Measured at B=256: PF = 3 in the BPTT step (K = 4H, 16 rounds per wave) is 24 % SLOWER than PF = 1 - the
+// step is bound by its L2->CU traffic (256 workgroups x 516 KB = 132 MB per launch at 32x32 tiles), not by the round
+// trips; larger tiles (fewer bytes) are the lever there, deeper prefetch only adds contention.
+template <int MT, int NT, int PF>
 __device__ __forceinline__ void wave_gemm_bf16(f32x16 (&acc)[MT][NT], const unsigned short* const (&arow)[MT * 4],
                                                const unsigned short* const (&brow)[NT * 4], int K, unsigned char* sA,
                                                unsigned char* sB, int wave, int lane) {
     const int nch = K / BKC;
     const int per_wave = (nch + BNW - 1) / BNW;
+    const int n_round = (per_wave + PF - 1) / PF;
     const int lrow = lane >> 3, piece = lane & 7;
     const int fr = lane & 31, fh = lane >> 5;
     const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero4);
-    u32x4 ra[MT * 4], rb[NT * 4];
-    auto load = [&](int c) {
+    u32x4 ra[PF][MT * 4], rb[PF][NT * 4];
+    auto load = [&](int c, u32x4 (&qa)[MT * 4], u32x4 (&qb)[NT * 4]) {      // past-the-end chunks read the zero block
         const bool in = c < nch;
         const int k0 = c * BKC + piece * 8;
 #pragma unroll
-        for (int i = 0; i < MT * 4; ++i) ra[i] = *reinterpret_cast<const u32x4*>((in && arow[i]) ? arow[i] + k0 : zero);
+        for (int i = 0; i < MT * 4; ++i) qa[i] = *reinterpret_cast<const u32x4*>((in && arow[i]) ? arow[i] + k0 : zero);
 #pragma unroll
-        for (int i = 0; i < NT * 4; ++i) rb[i] = *reinterpret_cast<const u32x4*>((in && brow[i]) ? brow[i] + k0 : zero);
+        for (int i = 0; i < NT * 4; ++i) qb[i] = *reinterpret_cast<const u32x4*>((in && brow[i]) ? brow[i] + k0 : zero);
     };
-    load(wave);
-    for (int r = 0; r < per_wave; ++r) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int i = 0; i < MT * 4; ++i) *reinterpret_cast<u32x4*>(sA + (lrow + 8 * i) * BROWB + piece * 16) = ra[i];
+    for (int d = 0; d < PF; ++d) load(wave + d * BNW, ra[d], rb[d]);
+    for (int r = 0; r < n_round; ++r) {
 #pragma unroll
-        for (int i = 0; i < NT * 4; ++i) *reinterpret_cast<u32x4*>(sB + (lrow + 8 * i) * BROWB + piece * 16) = rb[i];
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        load(wave + (r + 1) * BNW);             // past-the-end chunks read the zero block
+        for (int d = 0; d < PF; ++d) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-        for (int s = 0; s < BKC / 16; ++s) {
-            bf16x8 a[MT], b[NT];
+            for (int i = 0; i < MT * 4; ++i) *reinterpret_cast<u32x4*>(sA + (lrow + 8 * i) * BROWB + piece * 16) = ra[d][i];
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
-                a[mi] = *reinterpret_cast<const bf16x8*>(sA + (mi * 32 + fr) * BROWB + s * 32 + fh * 16);
+            for (int i = 0; i < NT * 4; ++i) *reinterpret_cast<u32x4*>(sB + (lrow + 8 * i) * BROWB + piece * 16) = rb[d][i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            load(wave + ((r + 1) * PF + d) * BNW, ra[d], rb[d]);       // refill this set
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-                b[ni] = *reinterpret_cast<const bf16x8*>(sB + (ni * 32 + fr) * BROWB + s * 32 + fh * 16);
+            for (int s = 0; s < BKC / 16; ++s) {
+                bf16x8 a[MT], b[NT];
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi)
+                for (int mi = 0; mi < MT; ++mi)
+                    a[mi] = *reinterpret_cast<const bf16x8*>(sA + (mi * 32 + fr) * BROWB + s * 32 + fh * 16);
 #pragma unroll
                 for (int ni = 0; ni < NT; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                    b[ni] = *reinterpret_cast<const bf16x8*>(sB + (ni * 32 + fr) * BROWB + s * 32 + fh * 16);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
         }
     }
 }
@@ -158,7 +167,7 @@ __global__ __launch_bounds__(BNT) void lstm_step_fwd_bf16_kernel(StepFwdBf16Args
             const int r = lrow + 8 * i, g = r / UN, u = u0 + r % UN;
             brow[i] = (u < p.H) ? p.wb + ((int64_t)g * p.H + u) * p.ldwb : nullptr;
         }
-        wave_gemm_bf16<MT, NT>(acc, arow, brow, p.Kp, sA, sB, wave, lane);
+        wave_gemm_bf16<MT, NT, (MT * NT >= 4) ? 1 : 2>(acc, arow, brow, p.Kp, sA, sB, wave, lane);
     }
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(BNT) void lstm_step_bwd_bf16_kernel(StepBwdBf16Args
             const int n = n0 + lrow + 8 * i;
             brow[i] = (n < p.H) ? p.wtb + (int64_t)n * p.ldwtb : nullptr;
         }
-        wave_gemm_bf16<MT, NT>(acc, arow, brow, p.Kp, sA, sB, wave, lane);
+        wave_gemm_bf16<MT, NT, 1>(acc, arow, brow, p.Kp, sA, sB, wave, lane);
     }
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);
