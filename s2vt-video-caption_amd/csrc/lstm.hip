@@ -223,8 +223,13 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
     const int lrow = lane / LPR;
 #ifdef S2VT_STAMPS
     int stamp_slot = -1;
-    if (bid == 8 && tid == 0) { stamp_slot = (int)atomicAdd(&g_stamp_n, 1u); if (stamp_slot >= 8192) stamp_slot = -1; }
-    STAMP(0);
+    if (bid == 8 && tid == 0) {      // entry time is taken BEFORE the slot atomic (its round trip is ~1-2 us)
+        const unsigned long long t_entry = wall_clock64();
+        stamp_slot = (int)atomicAdd(&g_stamp_n, 1u);
+        if (stamp_slot >= 8192) stamp_slot = -1;
+        if (stamp_slot >= 0) g_stamps[stamp_slot][0] = t_entry;
+        if (stamp_slot >= 0) g_stamps[stamp_slot][7] = wall_clock64();     // after the atomic returned
+    }
 #else
     constexpr int stamp_slot = -1;
 #endif

@@ -43,6 +43,7 @@ for it in range(3):
 s = out[:n].astype(np.int64)
 s = s[np.argsort(s[:, 0])]
 print("B=%d: %d stamped launches, %.2f us per launch by events" % (B, n, e0.elapsed_time(e1) * 1e3 / T))
+print("  (stamping atomic returned at %.2f us after entry: that much of the next line is the instrumentation)" % ((s[1:-1, 7] - s[1:-1, 0]) * 0.01).mean())
 names = ["entry", "loads issued", "first chunk staged", "K loop done", "all waves done (barrier)", "partials reduced (barrier)",
          "outputs stored+drained"]
 rel = (s[1:-1, :7] - s[1:-1, :1]) * 0.01     # us since entry (skip first launch: no recurrent term)
