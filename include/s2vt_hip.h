@@ -72,6 +72,20 @@ size_t s2vt_train_workspace_bytes(const s2vt_dims* d);
 int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
                        int64_t targets_ld, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 
+/* One depth of the batched beam search (beam.py; S2VTModel.py:205-223 for every expandable node of every sample at once):
+ *   1. one zero-input vid_rnn step for the whole batch: (vid_h_in, vid_c_in) [B,H] -> (vid_h_out, vid_c_out);
+ *   2. for the R expandable rows r (sample row_b[r], parent state row row_state[r] of the previous depth's table,
+ *      last token tok[r]): word_rnn step on [Emb[tok] | vid_h_out[row_b]] from (word_h_in, word_c_in)[row_state] ->
+ *      the new state table (word_h_out, word_c_out) [R,H];
+ *   3. out_linear, log_softmax and the 20 most probable tokens of every row in ASCENDING token order (the order the
+ *      reference pushes them): top_ix [R,20] int32, top_lp [R,20] fp32 log-probs.
+ * d->B = batch size; R may be 0 (only the vid step runs).  Workspace: s2vt_beam_workspace_bytes(d, max R). */
+size_t s2vt_beam_workspace_bytes(const s2vt_dims* d, int32_t max_rows);
+int s2vt_beam_step(const s2vt_dims* d, const s2vt_params* p, int32_t R, const int32_t* row_b, const int32_t* row_state,
+                   const int32_t* tok, const float* vid_h_in, const float* vid_c_in, float* vid_h_out, float* vid_c_out,
+                   const float* word_h_in, const float* word_c_in, float* word_h_out, float* word_c_out, int32_t* top_ix,
+                   float* top_lp, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Data-parallel overlap (no reference counterpart: the reference is single-device).  After s2vt_train_backward has
  * RETURNED (all of its work is enqueued), make `stream` wait until a group of that call's parameter gradients is
  * final, so that their all-reduce can run under the rest of the backward:

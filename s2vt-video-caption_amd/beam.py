@@ -71,39 +71,55 @@ def beam_search(model, feats, params, beam_width=3, max_depth=30):
     vid_h, vid_c = h1_all[(L - 1) * B:], c1_all[(L - 1) * B:]
     word_h, word_c = h2_all[(L - 1) * B:].clone(), c2_all[(L - 1) * B:].clone()
 
-    # ---- per-sample queues (host): see BeamQueues
-    states = (word_h, word_c)
+    # ---- per-sample queues (host, BeamQueues) + one library call per depth (s2vt_beam_step): vid step for the batch,
+    # word step / out_linear / log_softmax / top-20 for all expandable (sample, beam slot) rows
+    import ctypes
+    from . import capi
+    from .functional import _ptr, _stream, _dims, _params_struct
+    lib = capi.load()
     queues = (BeamQueues if FAST_QUEUES else HeapQueues)(B, beam_width, sos, eos)
-    depth = 0
-    while depth < max_depth and not queues.all_done():
-        depth += 1
-        rows_b, rows_state, rows_tok = queues.pop()
-        # one zero-input vid step for the whole batch (:208-210)
-        vid_h, vid_c = ops.lstm_step_fwd(None, bsum1, w_hh1, vid_h.contiguous(), vid_c.contiguous())
-        top_ix = top_lp = None
-        if len(rows_b):
-            bidx = torch.as_tensor(np.asarray(rows_b, dtype=np.int64), device=dev)
-            tok = torch.as_tensor(np.asarray(rows_tok, dtype=np.int64), device=dev)
-            ridx = torch.as_tensor(np.asarray(rows_state, dtype=np.int64), device=dev)
-            # every expandable node of this depth was created at the previous depth -> one state table
-            sh, sc = states
-            ph, pc = sh[ridx], sc[ridx]
-            gx = _gemm_strided(vid_h[bidx].contiguous(), w_v, bsum2)             # vid_out half + biases
-            gx = _gemm_strided(emb[tok].contiguous(), w_e, None, out=gx, accumulate=True)   # embedded word half
-            wh, wc = ops.lstm_step_fwd(gx, None, w_hh2, ph.contiguous(), pc.contiguous())   # (:211-212)
-            logits = ops.gemm(wh, w_o, bias=b_o)                                # (:213)
-            logp = torch.log_softmax(logits, dim=1)                             # (:214)
-            top = logp.topk(FANOUT, dim=1).indices.sort(dim=1).values          # ascending token order (:216-219)
-            both = torch.cat([logp.gather(1, top), top.to(torch.float32)], dim=1).cpu().numpy()   # one D2H copy
-            top_lp = np.ascontiguousarray(both[:, :FANOUT])
-            top_ix = both[:, FANOUT:].astype(np.int64)                          # exact: V < 2**24
-            states = (wh, wc)
-        queues.push(top_ix, top_lp)
-    sentences = []
-    for seq in queues.finish():
-        out = [torch.tensor([[seq[0]]], dtype=torch.long, device=dev)]
-        out += [torch.tensor(i, device=dev) for i in seq[1:]]
-        sentences.append(out)
+    max_rows = max(B * beam_width, B)
+    pcs = tuple(p.contiguous() for p in (w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, w_f, b_f, w_o, b_o, emb))
+    d = _dims(feats, pcs)
+    ps = _params_struct(capi.Params, pcs)
+    with torch.cuda.device(dev):
+        nbytes = lib.s2vt_beam_workspace_bytes(ctypes.byref(d), max_rows)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        vid = [(vid_h.contiguous(), vid_c.contiguous()), (torch.empty(B, H, device=dev), torch.empty(B, H, device=dev))]
+        tab = [(torch.empty(max_rows, H, device=dev), torch.empty(max_rows, H, device=dev)) for _ in range(2)]
+        tab[0][0][:B].copy_(word_h)
+        tab[0][1][:B].copy_(word_c)
+        rows_dev = torch.empty(3, max_rows, dtype=torch.int32, device=dev)
+        top_dev = torch.empty(2, max_rows, FANOUT, dtype=torch.int32, device=dev)      # [0] ids, [1] fp32 log-prob bits
+        depth = 0
+        while depth < max_depth and not queues.all_done():
+            depth += 1
+            rows_b, rows_state, rows_tok = queues.pop()
+            R = len(rows_b)
+            if R:
+                rows_dev[:, :R].copy_(torch.from_numpy(np.stack([np.asarray(rows_b), np.asarray(rows_state),
+                                                                  np.asarray(rows_tok)]).astype(np.int32)))
+            (vh_in, vc_in), (vh_out, vc_out) = vid[(depth - 1) & 1], vid[depth & 1]
+            (wh_in, wc_in), (wh_out, wc_out) = tab[(depth - 1) & 1], tab[depth & 1]
+            capi.check(lib.s2vt_beam_step(ctypes.byref(d), ctypes.byref(ps), R, _ptr(rows_dev[0]), _ptr(rows_dev[1]),
+                                          _ptr(rows_dev[2]), _ptr(vh_in), _ptr(vc_in), _ptr(vh_out), _ptr(vc_out),
+                                          _ptr(wh_in), _ptr(wc_in), _ptr(wh_out), _ptr(wc_out), _ptr(top_dev[0]),
+                                          _ptr(top_dev[1]), _ptr(ws), nbytes, _stream(dev)), "s2vt_beam_step")
+            top_ix = top_lp = None
+            if R:
+                both = top_dev[:, :R].cpu().numpy()                                     # one D2H copy per depth
+                top_ix = both[0].astype(np.int64)
+                top_lp = both[1].view(np.float32)
+            queues.push(top_ix, top_lp)
+    # list[list[Tensor]] like the reference (first element the [[<sos>]] tensor, then 0-dim ids): one H2D copy for all
+    # sequences, the elements are views of it
+    seqs = queues.finish()
+    flat = torch.as_tensor(np.concatenate([np.asarray(q, dtype=np.int64) for q in seqs]), device=dev)
+    sentences, o = [], 0
+    for q in seqs:
+        t = flat[o:o + len(q)]
+        o += len(q)
+        sentences.append([t[:1].view(1, 1)] + list(t[1:].unbind(0)))
     return sentences
 
 
@@ -195,122 +211,154 @@ def _heap_order(keys, m):
 
 
 class BeamQueues(object):
-    """Same bookkeeping as HeapQueues with the per-depth candidate sets held as numpy arrays.
+    """Same bookkeeping as HeapQueues, vectorised over samples AND candidates (numpy).
 
-    Because the queue is emptied after every pop phase (:194), a sample's heap at depth d is just "the
-    candidates pushed at depth d-1, in push order"; popping beam_width entries is a partial sort by key.
-    Distinct keys sort the same way in any heap, so the fast path is one stable argsort per sample; when two
-    of the beam_width+1 smallest keys are EQUAL the pop order depends on the heap's internal layout, and the
-    sample falls back to replaying the pushes into a real heap (_heap_order).  Nodes are materialised only
-    when popped (<= beam_width per sample and depth instead of 20 x beam_width).
+    Because the queue is emptied after every pop phase (:194), a sample's heap at depth d is just "the candidates
+    pushed at depth d-1, in push order"; popping beam_width entries is a partial sort by key.  Distinct keys sort the
+    same way in any heap, so the fast path is one stable argsort over a [B, beam_width*20] key matrix; when two of a
+    sample's beam_width+1 smallest keys are EQUAL the pop order depends on the heap's internal layout, and that sample
+    falls back to replaying its pushes into a real heap (_heap_order).  Nodes are materialised only when popped
+    (<= beam_width per sample and depth instead of 20 x beam_width).
     """
 
     def __init__(self, B, beam_width, sos, eos):
         self.B, self.bw, self.eos = B, beam_width, eos
-        # node table: token and parent of every popped node (back-trace), plus the root per sample
-        self.tok = [sos] * B
-        self.prev = [-1] * B
-        # candidates per sample, in push order.  A candidate is (key, token, parent node, length, state row,
-        # node id or -1 when not materialised yet).
-        self.c_key = [np.array([-0.0], dtype=np.float64) for _ in range(B)]
-        self.c_tok = [np.array([sos]) for _ in range(B)]
-        self.c_par = [np.array([-1]) for _ in range(B)]
-        self.c_len = [np.array([1]) for _ in range(B)]
-        self.c_row = [np.array([b]) for b in range(B)]
-        self.c_nid = [np.array([b]) for b in range(B)]
-        self.done = [False] * B
-        self.beams = [None] * B
+        self.NC = max(beam_width * FANOUT, 1)
+        # node table (back-trace): token and parent of every popped node; the B roots come first
+        self.tok_tab = [np.full(B, sos, dtype=np.int64)]
+        self.prev_tab = [np.full(B, -1, dtype=np.int64)]
+        self.n_nodes = B
+        NC = self.NC
+        # candidates of every sample in push order, padded to NC: key (+inf pad), token, parent node, length, state row,
+        # node id (-1: not materialised yet)
+        self.key = np.full((B, NC), np.inf)
+        self.tok = np.zeros((B, NC), dtype=np.int64)
+        self.par = np.full((B, NC), -1, dtype=np.int64)
+        self.len = np.ones((B, NC), dtype=np.int64)
+        self.row = np.zeros((B, NC), dtype=np.int64)
+        self.nid = np.full((B, NC), -1, dtype=np.int64)
+        self.n = np.ones(B, dtype=np.int64)
+        self.key[:, 0] = -0.0
+        self.tok[:, 0] = sos
+        self.row[:, 0] = np.arange(B)
+        self.nid[:, 0] = np.arange(B)
+        self.done = np.zeros(B, dtype=bool)
         self.tie_fallbacks = 0
+        # score divisor len**0.7 exactly as the reference evaluates it: Python float pow, then fp32 (S2VTModel.py:262-266)
+        self.pow07 = np.array([np.float32(pow(float(l), 0.7)) if l > 0 else np.float32(1) for l in range(4096)],
+                              dtype=np.float32)
 
     def all_done(self):
-        return all(self.done)
+        return bool(self.done.all())
 
-    def _order(self, keys, m):
-        n = len(keys)
-        if n == 1:
-            return [0]
-        idx = np.argsort(keys, kind="stable")[:m + 1]
-        ks = keys[idx]
-        if np.any(ks[1:] == ks[:-1]):
+    def _tab(self):
+        if len(self.tok_tab) > 1:
+            self.tok_tab = [np.concatenate(self.tok_tab)]
+            self.prev_tab = [np.concatenate(self.prev_tab)]
+        return self.tok_tab[0], self.prev_tab[0]
+
+    def _pop_order(self, m_want):
+        """[B, m_want] candidate indices in pop order (entries j >= min(m_want, n_b) are meaningless)."""
+        B = self.B
+        k = min(m_want + 1, self.NC)
+        order = np.argsort(self.key, axis=1, kind="stable")[:, :k]
+        ks = np.take_along_axis(self.key, order, axis=1)
+        # a tie matters only among the first min(m_want, n) + 1 VALID candidates
+        pos = np.arange(1, k)[None, :]
+        tie = ((ks[:, 1:] == ks[:, :-1]) & (pos < self.n[:, None]) & (pos <= m_want)).any(axis=1) & ~self.done
+        order = order[:, :m_want] if order.shape[1] >= m_want else np.pad(order, ((0, 0), (0, m_want - order.shape[1])))
+        for b in np.nonzero(tie)[0]:
             self.tie_fallbacks += 1
-            return _heap_order(keys.tolist(), m)
-        return idx[:m].tolist()
+            nb = int(self.n[b])
+            o = _heap_order(self.key[b, :nb].tolist(), min(m_want, nb))
+            order[b, :len(o)] = o
+        return order
 
     def pop(self):
-        rows_b, rows_state, rows_tok = [], [], []
-        self.beams = [None] * self.B
-        for b in range(self.B):
-            if self.done[b]:
-                continue
-            keys = self.c_key[b]
-            order = self._order(keys, min(self.bw, len(keys)))
-            toks, pars, lens, rows, nids = self.c_tok[b], self.c_par[b], self.c_len[b], self.c_row[b], self.c_nid[b]
-            beam = []
-            for i in order:
-                nid = int(nids[i])
-                t = int(toks[i])
-                if nid < 0:
-                    nid = len(self.tok)
-                    self.tok.append(t)
-                    self.prev.append(int(pars[i]))
-                fin = (t == self.eos and self.prev[nid] >= 0)
-                beam.append((keys[i], nid, int(lens[i]), fin))
-                if not fin:
-                    rows_b.append(b)
-                    rows_state.append(int(rows[i]))
-                    rows_tok.append(t)
-            self.beams[b] = beam
-        return rows_b, rows_state, rows_tok
+        B, bw = self.B, self.bw
+        act = ~self.done
+        order = self._pop_order(bw)                                         # [B, bw]
+        valid = (np.arange(bw)[None, :] < np.minimum(self.n, bw)[:, None]) & act[:, None]
+        g = lambda arr: np.take_along_axis(arr, order, axis=1)
+        key, tok, par, ln, row, nid = g(self.key), g(self.tok), g(self.par), g(self.len), g(self.row), g(self.nid)
+        # materialise the popped candidates that are not nodes yet, in (sample, beam slot) order
+        new = valid & (nid < 0)
+        nnew = int(new.sum())
+        if nnew:
+            nid = nid.copy()
+            nid[new] = self.n_nodes + np.arange(nnew)
+            self.tok_tab.append(tok[new])
+            self.prev_tab.append(par[new])
+            self.n_nodes += nnew
+        tok_tab, prev_tab = self._tab()
+        prev = np.where(valid, prev_tab[np.where(valid, nid, 0)], -1)
+        fin = valid & (tok == self.eos) & (prev >= 0)
+        exp = valid & ~fin
+        self.beam = (key, nid, ln, fin, exp, valid)
+        bidx = np.broadcast_to(np.arange(B)[:, None], (B, bw))
+        return bidx[exp], row[exp], tok[exp]
 
     def push(self, top_ix, top_lp):
-        r = 0
-        F = FANOUT
-        for b in range(self.B):
-            beam = self.beams[b]
-            if beam is None:
-                continue
-            n = sum(1 if fin else F for _, _, _, fin in beam)
-            key = np.empty(n, dtype=np.float64)
-            tok = np.empty(n, dtype=np.int64)
-            par = np.empty(n, dtype=np.int64)
-            ln = np.empty(n, dtype=np.int64)
-            row = np.empty(n, dtype=np.int64)
-            nid = np.empty(n, dtype=np.int64)
-            o = 0
-            for k, node, leng, fin in beam:
-                if fin:                                                        # re-inserted unchanged (:200-202)
-                    key[o], tok[o], par[o], ln[o], row[o], nid[o] = k, self.eos, self.prev[node], leng, -1, node
-                    o += 1
-                    continue
-                # score = fp32 log-prob / python float len**0.7, evaluated in fp32 like the reference's
-                # 0-dim tensor / float division (S2VTModel.py:262-266); key = -score
-                sc = top_lp[r] / np.float32(pow(float(leng + 1), 0.7))
-                key[o:o + F] = -sc.astype(np.float64)
-                tok[o:o + F] = top_ix[r]
-                par[o:o + F] = node
-                ln[o:o + F] = leng + 1
-                row[o:o + F] = r
-                nid[o:o + F] = -1
-                o += F
-                r += 1
-            self.c_key[b], self.c_tok[b], self.c_par[b], self.c_len[b], self.c_row[b], self.c_nid[b] = \
-                key, tok, par, ln, row, nid
-            if n <= self.bw:                                                   # (:227-228)
-                self.done[b] = True
+        B, bw, NC, F = self.B, self.bw, self.NC, FANOUT
+        key, nid, ln, fin, exp, valid = self.beam
+        _, prev_tab = self._tab()
+        size = np.where(exp, F, 0) + fin.astype(np.int64)                   # candidates each beam entry pushes
+        off = np.cumsum(size, axis=1) - size                                # their first slot, in beam order
+        n_new = size.sum(axis=1)
+        act = valid.any(axis=1)
+        nk = np.full((B, NC), np.inf)
+        nt = np.zeros((B, NC), dtype=np.int64)
+        npar = np.full((B, NC), -1, dtype=np.int64)
+        nl = np.ones((B, NC), dtype=np.int64)
+        nrow = np.zeros((B, NC), dtype=np.int64)
+        nnid = np.full((B, NC), -1, dtype=np.int64)
+        bidx = np.broadcast_to(np.arange(B)[:, None], (B, bw))
+        if fin.any():                                                       # finished entries re-inserted unchanged (:200-202)
+            fb, fo = bidx[fin], off[fin]
+            nk[fb, fo] = key[fin]
+            nt[fb, fo] = self.eos
+            npar[fb, fo] = prev_tab[nid[fin]]
+            nl[fb, fo] = ln[fin]
+            nrow[fb, fo] = -1
+            nnid[fb, fo] = nid[fin]
+        if exp.any():                                                       # 20 children per expanded entry (:216-223)
+            eb, eo, el, en = bidx[exp], off[exp], ln[exp] + 1, nid[exp]
+            R = len(eb)
+            cols = eo[:, None] + np.arange(F)[None, :]
+            rows = eb[:, None]
+            # score = fp32 log-prob / fp32(len**0.7); key = -score
+            sc = np.asarray(top_lp, dtype=np.float32)[:R] / self.pow07[el][:, None]
+            nk[rows, cols] = -sc.astype(np.float64)
+            nt[rows, cols] = np.asarray(top_ix)[:R]
+            npar[rows, cols] = en[:, None]
+            nl[rows, cols] = el[:, None]
+            nrow[rows, cols] = np.arange(R)[:, None]
+        for dst, src in ((self.key, nk), (self.tok, nt), (self.par, npar), (self.len, nl), (self.row, nrow), (self.nid, nnid)):
+            dst[act] = src[act]
+        self.n[act] = n_new[act]
+        self.done |= act & (n_new <= bw)                                    # (:227-228)
 
     def finish(self):
+        tok_tab, prev_tab = self._tab()
+        first = self._pop_order_final()
         out = []
         for b in range(self.B):
-            keys = self.c_key[b]
-            i = self._order(keys, 1)[0]                                        # (:231)
-            seq = [int(self.c_tok[b][i])]
-            node = int(self.c_nid[b][i])
-            node = int(self.c_par[b][i]) if node < 0 else self.prev[node]
-            while node >= 0:                                                   # (:234-236)
-                seq.append(self.tok[node])
-                node = self.prev[node]
+            i = int(first[b])                                               # (:231)
+            seq = [int(self.tok[b, i])]
+            node = int(self.nid[b, i])
+            node = int(self.par[b, i]) if node < 0 else int(prev_tab[node])
+            while node >= 0:                                                # (:234-236)
+                seq.append(int(tok_tab[node]))
+                node = int(prev_tab[node])
             out.append(seq[::-1])
         return out
+
+    def _pop_order_final(self):
+        saved, self.done = self.done, np.zeros(self.B, dtype=bool)          # frozen samples still pop their best entry
+        try:
+            return self._pop_order(1)[:, 0]
+        finally:
+            self.done = saved
 
 
 def _gemm_strided(a, w, bias, out=None, accumulate=False):

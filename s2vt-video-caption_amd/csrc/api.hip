@@ -923,6 +923,79 @@ static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
     return w;
 }
 
+// ---------------------------------------------------------------------------------- batched beam-search depth
+struct BeamWS {
+    float *bsum1, *bsum2, *ph, *pc, *gx, *logits, *gws;
+    size_t gws_floats, bytes;
+};
+static BeamWS carve_beam(const s2vt_dims& d, int max_rows, void* base) {
+    const size_t H = d.H, V = d.V, R = (size_t)max_rows;
+    Carver c{reinterpret_cast<char*>(base), 0, 0};
+    BeamWS w;
+    w.bsum1 = c.take<float>(4 * H);
+    w.bsum2 = c.take<float>(4 * H);
+    w.ph = c.take<float>(R * H);
+    w.pc = c.take<float>(R * H);
+    w.gx = c.take<float>(R * 4 * H);
+    w.logits = c.take<float>(R * V);
+    w.gws_floats = 4 * R * (V > 4 * H ? V : 4 * H);
+    w.gws = c.take<float>(w.gws_floats);
+    w.bytes = align_up(c.off, 256);
+    return w;
+}
+
+size_t s2vt_beam_workspace_bytes(const s2vt_dims* d, int32_t max_rows) {
+    if (!d || max_rows <= 0) return 0;
+    return carve_beam(*d, max_rows, nullptr).bytes;
+}
+
+int s2vt_beam_step(const s2vt_dims* d, const s2vt_params* p, int32_t R, const int32_t* row_b, const int32_t* row_state,
+                   const int32_t* tok, const float* vid_h_in, const float* vid_c_in, float* vid_h_out, float* vid_c_out,
+                   const float* word_h_in, const float* word_c_in, float* word_h_out, float* word_c_out, int32_t* top_ix,
+                   float* top_lp, void* workspace, size_t workspace_bytes, void* stream) {
+    S2VT_REQUIRE(d && p && vid_h_in && vid_c_in && vid_h_out && vid_c_out && workspace, "s2vt_beam_step: null argument");
+    S2VT_REQUIRE(R >= 0 && (R == 0 || (row_b && row_state && tok && word_h_in && word_c_in && word_h_out && word_c_out &&
+                                        top_ix && top_lp)),
+                 "s2vt_beam_step: null row argument");
+    const int B = d->B, H = d->H, E = d->E, V = d->V;
+    S2VT_REQUIRE(workspace_bytes >= carve_beam(*d, R > 0 ? R : 1, nullptr).bytes, "s2vt_beam_step: workspace too small");
+    const BeamWS w = carve_beam(*d, R > 0 ? R : 1, workspace);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = add_vectors(st, p->vid_b_ih, p->vid_b_hh, w.bsum1, 4 * H))) return rc;
+    if ((rc = add_vectors(st, p->word_b_ih, p->word_b_hh, w.bsum2, 4 * H))) return rc;
+    {   // one zero-input vid_rnn step for the whole batch (S2VTModel.py:208-210)
+        StepFwdArgs a = {};
+        a.B = B; a.H = H;
+        a.h_prev = vid_h_in; a.ldh = H; a.w_hh = p->vid_w_hh; a.ldw = H;
+        a.bias = w.bsum1;
+        a.c_prev = vid_c_in; a.ldc = H;
+        a.h_out = vid_h_out; a.ldho = H; a.c_out = vid_c_out; a.ldco = H;
+        if ((rc = lstm_step_fwd(st, a))) return rc;
+    }
+    if (R == 0) return 0;
+    const Lane ln{st, w.gws, w.gws_floats, nullptr};
+    // parents' word_rnn states, the vid_out half of the gate input (A rows gathered by sample), then the word step
+    // with the embedding rows gathered inside the kernel's second K segment (:211-212)
+    if ((rc = gather_rows_f32(st, word_h_in, H, row_state, R, H, w.ph))) return rc;
+    if ((rc = gather_rows_f32(st, word_c_in, H, row_state, R, H, w.pc))) return rc;
+    if ((rc = lgemm(ln, true, true, R, 4 * H, H, vid_h_out, H, gather(row_b), p->word_w_ih + E, E + H, ID, w.gx, 4 * H, ID,
+                    w.bsum2, false)))
+        return rc;
+    {
+        StepFwdArgs a = {};
+        a.B = R; a.H = H;
+        a.h_prev = w.ph; a.ldh = H; a.w_hh = p->word_w_hh; a.ldw = H;
+        a.x2 = p->emb_w; a.ldx2 = E; a.K2 = E; a.w2 = p->word_w_ih; a.ldw2 = E + H; a.tok_idx = tok;
+        a.gx = w.gx; a.ldgx = 4 * H;
+        a.c_prev = w.pc; a.ldc = H;
+        a.h_out = word_h_out; a.ldho = H; a.c_out = word_c_out; a.ldco = H;
+        if ((rc = lstm_step_fwd(st, a))) return rc;
+    }
+    if ((rc = lgemm(ln, true, true, R, V, H, word_h_out, H, ID, p->out_w, H, ID, w.logits, V, ID, p->out_b, false))) return rc;   // (:213)
+    return top20_logprob(st, w.logits, V, R, V, top_ix, top_lp);                                                                   // (:214-219)
+}
+
 int s2vt_backward_wait_grads(int32_t group, void* stream) {
     S2VT_REQUIRE(group == 0 || group == 1, "s2vt_backward_wait_grads: group must be 0 (out_linear) or 1 (word_rnn + embedding)");
     S2VT_REQUIRE(g_grad_ev_set[group], "s2vt_backward_wait_grads: no s2vt_train_backward has run yet");

@@ -129,4 +129,92 @@ int mean_ce_bwd(hipStream_t s, const float* logits, int64_t rows, int V, const i
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------- beam-search fan-out
+// Per logits row: log_softmax (S2VTModel.py:214) and the 20 most probable tokens with their log-probs, returned in
+// ASCENDING token order - the order in which the reference pushes them (it scans the vocabulary and keeps the ids that
+// are in topk(20), S2VTModel.py:216-219).  One workgroup per row: the row is staged in LDS, reduced to max and
+// sum-exp, then the largest remaining element is extracted 20 times (ties -> the lower token id).
+constexpr int TOPK_N = 20;
+__global__ __launch_bounds__(256) void top20_logprob_kernel(const float* logits, int64_t ld, int V, int32_t* top_ix,
+                                                            float* top_lp) {
+    extern __shared__ float row[];                  // V floats, then reduction scratch
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    __shared__ float sel_v[TOPK_N];
+    __shared__ int sel_i[TOPK_N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = logits + (int64_t)blockIdx.x * ld;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 256) {
+        const float v = src[i];
+        row[i] = v;
+        mx = fmaxf(mx, v);
+    }
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red_v[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_v[0], red_v[1]), fmaxf(red_v[2], red_v[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int i = tid; i < V; i += 256) sum += expf(row[i] - mx);
+    for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red_v[wave] = sum;
+    __syncthreads();
+    const float lse = mx + logf((red_v[0] + red_v[1]) + (red_v[2] + red_v[3]));
+    __syncthreads();
+    // every thread keeps the best of its own elements; only the owner of an extracted element rescans
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+    auto rescan = [&]() {
+        bv = -INFINITY; bi = 0x7fffffff;
+        for (int i = tid; i < V; i += 256) {
+            const float v = row[i];
+            if (v > bv) { bv = v; bi = i; }          // ascending i: the first (lowest id) of equal values is kept
+        }
+    };
+    rescan();
+    for (int k = 0; k < TOPK_N; ++k) {
+        float v = bv;
+        int ix = bi;
+        for (int o = 32; o; o >>= 1) {
+            const float ov = __shfl_xor(v, o);
+            const int oi = __shfl_xor(ix, o);
+            if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+        }
+        if (lane == 0) { red_v[wave] = v; red_i[wave] = ix; }
+        __syncthreads();
+        v = red_v[0]; ix = red_i[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (red_v[w] > v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
+        if (tid == 0) { sel_v[k] = v; sel_i[k] = ix; }
+        if ((ix & 255) == tid && ix < V) {           // owner: remove it and find the next best of its elements
+            row[ix] = -INFINITY;
+            rescan();
+        }
+        __syncthreads();
+    }
+    if (tid < TOPK_N) {                              // rank by token id (ids are distinct)
+        const int my = sel_i[tid];
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < TOPK_N; ++j) rank += (sel_i[j] < my);
+        top_ix[(int64_t)blockIdx.x * TOPK_N + rank] = my;
+        top_lp[(int64_t)blockIdx.x * TOPK_N + rank] = sel_v[tid] - lse;
+    }
+}
+
+int top20_logprob(hipStream_t s, const float* logits, int64_t ld, int64_t rows, int V, int32_t* top_ix, float* top_lp) {
+    if (rows <= 0) return 0;
+    S2VT_REQUIRE(V >= TOPK_N && (size_t)V * sizeof(float) <= 150 * 1024, "top20_logprob: 20 <= vocab_size <= 38400");
+    if ((size_t)V * sizeof(float) > 48 * 1024)
+        S2VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(top20_logprob_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)V * sizeof(float))));
+    hipLaunchKernelGGL(top20_logprob_kernel, dim3((unsigned)rows), dim3(256), (size_t)V * sizeof(float), s, logits, ld, V,
+                       top_ix, top_lp);
+    S2VT_LAUNCH_CHECK("top20_logprob_kernel");
+    return 0;
+}
+
 }  // namespace s2vt

@@ -117,6 +117,8 @@ int colsum_f32(hipStream_t s, const float* x, int64_t rows, int cols, int64_t ld
 size_t colsum_partial_floats(int64_t rows, int cols);
 int targets_to_time_major(hipStream_t s, const int64_t* targets, int B, int Lm1, int64_t ld, int V, int32_t* out,
                           int* err_flag);
+// beam-search fan-out (ce.hip): log_softmax + the 20 most probable tokens per row in ascending token order
+int top20_logprob(hipStream_t s, const float* logits, int64_t ld, int64_t rows, int V, int32_t* top_ix, float* top_lp);
 int gather_rows_f32(hipStream_t s, const float* src, int64_t ld, const int32_t* idx, int64_t rows, int cols, float* out);
 int embedding_scatter_add(hipStream_t s, const float* d_rows, int64_t rows, int E, const int32_t* tok, float* d_emb);
 int unpack_tokens(hipStream_t s, const unsigned long long* packed, int steps, int B, int64_t* out_ids);

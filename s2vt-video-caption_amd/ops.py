@@ -174,3 +174,28 @@ def decode_step_argmax(h, w_out, b_out):
         capi.check(lib.s2vt_decode_step_argmax(B, H, V, _ptr(h), _ptr(w_out), _ptr(b_out), _ptr(packed), _stream(dev)),
                    "s2vt_decode_step_argmax")
         return 0xFFFFFFFF - (packed & 0xFFFFFFFF)
+
+
+def beam_step(params, dims, row_b, row_state, tok, vid_h, vid_c, word_h, word_c):
+    """One s2vt_beam_step call (include/s2vt_hip.h).  params: 13 tensors in capi.PARAM_KEYS order; dims = (B,L,F,H,E,V);
+    row_b / row_state / tok: int32 [R].  Returns (vid_h', vid_c', word_h' [R,H], word_c' [R,H], top_ix [R,20] int32,
+    top_lp [R,20] fp32)."""
+    from .functional import _params_struct
+    lib = capi.load()
+    d = capi.Dims(*dims)
+    B, H = dims[0], dims[3]
+    R = int(row_b.numel())
+    dev = vid_h.device
+    with torch.cuda.device(dev):
+        nbytes = lib.s2vt_beam_workspace_bytes(ctypes.byref(d), max(R, 1))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        vh, vc = torch.empty(B, H, device=dev), torch.empty(B, H, device=dev)
+        wh, wc = torch.empty(max(R, 1), H, device=dev), torch.empty(max(R, 1), H, device=dev)
+        tix = torch.empty(max(R, 1), 20, dtype=torch.int32, device=dev)
+        tlp = torch.empty(max(R, 1), 20, dtype=torch.float32, device=dev)
+        ps = _params_struct(capi.Params, tuple(_f32c(p, "parameter") for p in params))
+        capi.check(lib.s2vt_beam_step(ctypes.byref(d), ctypes.byref(ps), R, _ptr(row_b), _ptr(row_state), _ptr(tok),
+                                      _ptr(_f32c(vid_h, "vid_h")), _ptr(_f32c(vid_c, "vid_c")), _ptr(vh), _ptr(vc),
+                                      _ptr(_f32c(word_h, "word_h")), _ptr(_f32c(word_c, "word_c")), _ptr(wh), _ptr(wc),
+                                      _ptr(tix), _ptr(tlp), _ptr(ws), nbytes, _stream(dev)), "s2vt_beam_step")
+    return vh, vc, wh[:R], wc[:R], tix[:R], tlp[:R]

@@ -216,3 +216,33 @@ def test_feat_proj_fwd_bwd(lib):
     assert (dw.cpu() - torch.einsum("blh,blf->hf", dx_bm, feats)).abs().max().item() < 2e-5
     assert (db.cpu() - dx1.sum(0)).abs().max().item() < 1e-5
     assert (dfe.cpu() - dx_bm @ w).abs().max().item() < 1e-5
+
+
+def test_beam_step_matches_cell_and_topk(lib):
+    """s2vt_beam_step (vid step, gathered word step with in-kernel embedding rows, out_linear, log_softmax + top-20 in
+    ascending token order) against the oracle's cell and torch's log_softmax/topk on the CPU."""
+    from s2vt_video_caption_amd import ops, synth, capi
+    B, L, F, H, E, V = 5, 8, 64, 40, 24, 300
+    sd = synth.make_state_dict(V, F, H, E, seed=9)
+    params = [sd[k] for k in capi.PARAM_KEYS]
+    g = torch.Generator().manual_seed(3)
+    R = 11
+    row_b = torch.randint(0, B, (R,), generator=g, dtype=torch.int32)
+    row_state = torch.randint(0, 7, (R,), generator=g, dtype=torch.int32)
+    tok = torch.randint(0, V, (R,), generator=g, dtype=torch.int32)
+    vid_h, vid_c = _r(B, H, seed=1, scale=0.5), _r(B, H, seed=2, scale=0.5)
+    word_h, word_c = _r(7, H, seed=3, scale=0.5), _r(7, H, seed=4, scale=0.5)
+    out = ops.beam_step([p.to(DEV) for p in params], (B, L, F, H, E, V), row_b.to(DEV), row_state.to(DEV), tok.to(DEV),
+                        vid_h.to(DEV), vid_c.to(DEV), word_h.to(DEV), word_c.to(DEV))
+    vh, vc, wh, wc, tix, tlp = [t.cpu() for t in out]
+    # CPU restatement (S2VTModel.py:208-219)
+    w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, w_f, b_f, w_o, b_o, emb = params
+    rvh, rvc = orc.lstm_cell(torch.zeros(B, H), vid_h, vid_c, w_ih1, w_hh1, b_ih1, b_hh1)
+    x = torch.cat([emb[tok.long()], rvh[row_b.long()]], dim=1)
+    rwh, rwc = orc.lstm_cell(x, word_h[row_state.long()], word_c[row_state.long()], w_ih2, w_hh2, b_ih2, b_hh2)
+    logp = torch.log_softmax(rwh @ w_o.t() + b_o, dim=1)
+    rix = logp.topk(20, dim=1).indices.sort(dim=1).values
+    assert (vh - rvh).abs().max() < 2e-6 and (vc - rvc).abs().max() < 2e-6
+    assert (wh - rwh).abs().max() < 2e-6 and (wc - rwc).abs().max() < 2e-6
+    assert torch.equal(tix.long(), rix)
+    assert (tlp - logp.gather(1, rix)).abs().max() < 5e-6

@@ -27,7 +27,7 @@ with torch.no_grad():
     torch.cuda.synchronize()
     tg = (time.perf_counter() - t0) / 3
     print("greedy B=%d: %.2f ms/call, %.0f captions/s" % (B, tg * 1e3, B / tg), flush=True)
-    m(feats[:8], mode="beam_search", beam_width=beam, max_beam_depth=30)
+    m(feats, mode="beam_search", beam_width=beam, max_beam_depth=30)   # warm-up at the timed size (allocator, code objects)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = m(feats, mode="beam_search", beam_width=beam, max_beam_depth=30)
