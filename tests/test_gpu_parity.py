@@ -153,8 +153,10 @@ def _c2_body(g, d, sd, feats, caps, mask):
 
 def test_against_oracle_on_fresh_seeds(lib):
     """Ragged / edge shapes the fixtures do not cover: B=1, B not a multiple of the tile, H not a multiple of
-    8 or 4-aligned E, V not 4-aligned."""
-    for (B, L, Fd, H, E, V, seed) in [(1, 4, 20, 12, 8, 23, 1), (19, 6, 33, 36, 20, 57, 2), (33, 3, 64, 40, 44, 30, 3)]:
+    8 or 4-aligned E, V not 4-aligned; the B=64 / B=128 cases take the split-precision, two-lane drivers (blocked plane
+    layout with partial 64-row blocks, k padding, clamped 256x256 tiles)."""
+    for (B, L, Fd, H, E, V, seed) in [(1, 4, 20, 12, 8, 23, 1), (19, 6, 33, 36, 20, 57, 2), (33, 3, 64, 40, 44, 30, 3),
+                                      (64, 5, 70, 44, 28, 61, 4), (128, 4, 36, 100, 52, 333, 5)]:
         sd = synth.make_state_dict(V, Fd, H, E, seed=seed)
         feats, caps, mask = synth.make_batch(B, L, Fd, V, seed=seed, min_words=1, max_words=2)
         import S2VTModel, utils
