@@ -99,6 +99,7 @@ struct TrainWS {
     float *wt1, *wt2, *dh1, *dh2dec, *dx1, *de, *dc1, *dc2, *colsum_a, *colsum_b, *colsum_c, *gws_a, *gws_b;
     size_t gws_floats;
     int32_t* tok;
+    int* embws;              // embedding_grad scratch (heavy-token list)
     int* err;
     size_t bytes;
 };
@@ -121,6 +122,7 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     w.h2 = c.take<float>(T * B * H);
     w.c2 = c.take<float>(T * B * H);
     w.tok = c.take<int32_t>((L - 1) * B);
+    w.embws = c.take<int>(embedding_grad_ws_ints((int64_t)(L - 1) * B));
     w.err = c.take<int>(4);
     // backward-only scratch (two of everything that the two concurrently running layers touch)
     w.wt1 = c.take<float>(H * 4 * H);
@@ -699,8 +701,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = colsum_finish(st, w.colsum_a, T * B / 64, 4 * H, g->word_b_ih, false))) return rc;
     S2VT_HIP(hipMemcpyAsync(g->word_b_hh, g->word_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
     if ((rc = pgemm(la, R, E, 4 * H, q.dg2, L * B, 0, q.weT, 0, 0, w.de, E, ID, nullptr, false))) return rc;
-    if ((rc = fill_zero(st, g->emb_w, sizeof(float) * (size_t)V * E))) return rc;
-    if ((rc = embedding_scatter_add(st, w.de, R, E, w.tok, g->emb_w))) return rc;
+    if ((rc = embedding_grad(st, w.de, R, E, w.tok, V, g->emb_w, w.embws))) return rc;
     if ((rc = grads_ready(1, st))) return rc;
     // lane B: vid_rnn and feat_linear parameter gradients
     if ((rc = pgemm(lb, 4 * H, H, (T - 1) * B, q.dg1T, 0, B, q.h1T, 0, 0, g->vid_w_hh, H, ID, nullptr, false))) return rc;
@@ -859,8 +860,7 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
     if ((rc = lgemm(la, true, false, R, E, 4 * H, w.s2 + (int64_t)L * B4H, 4 * H, ID, p->word_w_ih, E + H, ID, w.de, E, ID,
                     nullptr, false)))
         return rc;
-    if ((rc = fill_zero(st, g->emb_w, sizeof(float) * (size_t)V * E))) return rc;
-    if ((rc = embedding_scatter_add(st, w.de, R, E, w.tok, g->emb_w))) return rc;
+    if ((rc = embedding_grad(st, w.de, R, E, w.tok, V, g->emb_w, w.embws))) return rc;
     if ((rc = grads_ready(1, st))) return rc;
     // lane B: vid_rnn and feat_linear parameter gradients                           (autograd of :67, :54)
     if ((rc = lgemm(lb, false, false, 4 * H, H, (T - 1) * B, w.s1 + B4H, 4 * H, ID, w.h1, H, ID, g->vid_w_hh, H, ID,

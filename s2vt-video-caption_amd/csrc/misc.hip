@@ -126,19 +126,95 @@ int targets_to_time_major(hipStream_t s, const int64_t* targets, int B, int Lm1,
     return 0;
 }
 
-// d_emb[tok[r], :] += d_rows[r, :]  (one wave-wide run of fp32 atomics per 256 B of a row; rows with
-// the same token collide, which is what makes this an atomic scatter).
-__global__ void emb_scatter_kernel(const float* d_rows, int64_t rows, int E, const int32_t* tok, float* d_emb) {
-    const int64_t r = blockIdx.y;
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= rows || c >= E) return;
-    atomicAdd(&d_emb[(int64_t)tok[r] * E + c], d_rows[r * E + c]);
+// Embedding gradient (autograd of S2VTModel.py:71): d_emb[v, :] = sum over the rows r with tok[r] == v of d_rows[r, :],
+// in a FIXED order - no atomics, so the whole training step is bitwise reproducible.
+//   emb_grad_kernel: one workgroup per vocabulary row v.  It scans the token list (order-preserving compaction by wave
+//     ballots); a row with <= EG_CAP matches is summed in ascending r (unused tokens are written as zeros: no separate
+//     fill); a row with more (<pad>, <eos>, frequent words: thousands of matches) is only put on the `heavy` list.
+//   emb_grad_heavy_kernel: one workgroup per (heavy token, 16 columns): 16 row-lanes sum contiguous slices of the
+//     ordered match list, the 16 partials are added in lane order.
+constexpr int EG_CAP = 64;
+__device__ __forceinline__ int eg_compact(bool hit, int r, int* list, int n_list, int* wave_cnt, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = n_list;
+    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    if (hit && list) list[off + __popcll(m & ((1ull << lane) - 1ull))] = r;
+    const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+    __syncthreads();
+    return n_list + total;
 }
-int embedding_scatter_add(hipStream_t s, const float* d_rows, int64_t rows, int E, const int32_t* tok, float* d_emb) {
-    if (rows <= 0 || E <= 0) return 0;
-    hipLaunchKernelGGL(emb_scatter_kernel, dim3(cdiv(E, 256), (unsigned)rows), dim3(256), 0, s, d_rows, rows, E, tok,
-                       d_emb);
-    S2VT_LAUNCH_CHECK("emb_scatter_kernel");
+__global__ __launch_bounds__(256) void emb_grad_kernel(const float* d_rows, int rows, int E, const int32_t* tok, float* d_emb,
+                                                       int* heavy, int* n_heavy) {
+    __shared__ int list[EG_CAP + 256];
+    __shared__ int wave_cnt[4];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    int n = 0;                                                // uniform: matches found so far
+    for (int base = 0; base < rows && n <= EG_CAP; base += 256) {
+        const int r = base + tid;
+        n = eg_compact((r < rows) && (tok[r] == v), r, list, n, wave_cnt, tid);
+    }
+    if (n > EG_CAP) {
+        if (tid == 0) heavy[atomicAdd(n_heavy, 1)] = v;       // list order does not matter
+        return;
+    }
+    float* out = d_emb + (int64_t)v * E;
+    for (int c = tid; c < E; c += 256) {
+        float sum = 0.f;
+        for (int i = 0; i < n; ++i) sum += d_rows[(int64_t)list[i] * E + c];
+        out[c] = sum;
+    }
+}
+constexpr int EG_HLIST = 8192;      // matches of a heavy token handled per pass
+__global__ __launch_bounds__(256) void emb_grad_heavy_kernel(const float* d_rows, int rows, int E, const int32_t* tok,
+                                                             float* d_emb, const int* heavy, const int* n_heavy) {
+    __shared__ int list[EG_HLIST + 256];
+    __shared__ int wave_cnt[4];
+    __shared__ float part[16][17];
+    if ((int)blockIdx.y >= *n_heavy) return;
+    const int v = heavy[blockIdx.y], tid = threadIdx.x;
+    const int rl = tid >> 4, c = blockIdx.x * 16 + (tid & 15);
+    float total = 0.f;
+    int base = 0;
+    while (base < rows) {
+        int n = 0;
+        for (; base < rows && n <= EG_HLIST; base += 256) {       // list holds EG_HLIST + 256
+            const int r = base + tid;
+            n = eg_compact((r < rows) && (tok[r] == v), r, list, n, wave_cnt, tid);
+        }
+        // row-lane rl sums the slice [rl*per, (rl+1)*per) of this pass's ordered matches
+        const int per = (n + 15) / 16, i0 = rl * per, i1 = (i0 + per < n) ? i0 + per : n;
+        float sum = 0.f;
+        if (c < E) {
+#pragma unroll 8
+            for (int i = i0; i < i1; ++i) sum += d_rows[(int64_t)list[i] * E + c];
+        }
+        part[rl][tid & 15] = sum;
+        __syncthreads();
+        if (rl == 0) {
+            float s = part[0][tid & 15];
+#pragma unroll
+            for (int k = 1; k < 16; ++k) s += part[k][tid & 15];
+            total += s;
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && c < E) d_emb[(int64_t)v * E + c] = total;
+}
+size_t embedding_grad_ws_ints(int64_t rows) { return (size_t)(rows / EG_CAP + 2) + 1; }
+// ws: embedding_grad_ws_ints(rows) ints of scratch (heavy-token list + its counter)
+int embedding_grad(hipStream_t s, const float* d_rows, int64_t rows, int E, const int32_t* tok, int V, float* d_emb, int* ws) {
+    if (V <= 0 || E <= 0) return 0;
+    const int max_heavy = (int)(rows / EG_CAP + 2);           // each heavy token owns > EG_CAP of the `rows` rows
+    int* n_heavy = ws + max_heavy;
+    S2VT_HIP(hipMemsetAsync(n_heavy, 0, sizeof(int), s));
+    hipLaunchKernelGGL(emb_grad_kernel, dim3((unsigned)V), dim3(256), 0, s, d_rows, (int)rows, E, tok, d_emb, ws, n_heavy);
+    S2VT_LAUNCH_CHECK("emb_grad_kernel");
+    hipLaunchKernelGGL(emb_grad_heavy_kernel, dim3(cdiv(E, 16), max_heavy), dim3(256), 0, s, d_rows, (int)rows, E, tok, d_emb,
+                       ws, n_heavy);
+    S2VT_LAUNCH_CHECK("emb_grad_heavy_kernel");
     return 0;
 }
 
