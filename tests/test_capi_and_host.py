@@ -162,3 +162,10 @@ def test_beam_queues_match_reference_heap(ties, V):
         b, rows_b, nf = run(beam.BeamQueues, seed)
         assert a == b and rows_a == rows_b
         assert (nf > 0) == ties
+
+
+def test_graft_entry_build_runs():
+    """the driver's build check: compile (or find up to date) every HIP source, load the library, import the drop-ins"""
+    import importlib
+    ge = importlib.import_module("__graft_entry__")
+    ge.build()
