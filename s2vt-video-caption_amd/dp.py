@@ -64,6 +64,7 @@ class FlatGradAllReducer:
         self.model = None
         self.groups = None
         self.comm_stream = None
+        self._avg_ok = True
 
     def attach(self, model):
         """Overlap mode for the HIP S2VT replica `model` (whose 13 parameters are exactly self.params):
@@ -114,17 +115,26 @@ class FlatGradAllReducer:
         lib = capi.load()
         main = torch.cuda.current_stream(self.flat.device)
         cs = self.comm_stream
-        scale = 1.0 / self.world
+
+        def reduce(lo, hi):
+            t = self.flat[lo:hi]
+            if self._avg_ok:            # RCCL averages in the collective: no separate 1/W pass over the buffer
+                try:
+                    dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+                    return
+                except (RuntimeError, ValueError):
+                    self._avg_ok = False
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            t.mul_(1.0 / self.world)
+
         with torch.cuda.stream(cs):
             for g in (0, 1):
                 capi.check(lib.s2vt_backward_wait_grads(g, capi.c_void_p(cs.cuda_stream)), "s2vt_backward_wait_grads")
                 for lo, hi in self.groups[g]:
-                    dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
-                    self.flat[lo:hi].mul_(scale)
+                    reduce(lo, hi)
             cs.wait_stream(main)                 # the remaining gradients are final with the backward's stream
             for lo, hi in self.groups[2]:
-                dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
-                self.flat[lo:hi].mul_(scale)
+                reduce(lo, hi)
         main.wait_stream(cs)
 
 
