@@ -169,3 +169,27 @@ def test_graft_entry_build_runs():
     import importlib
     ge = importlib.import_module("__graft_entry__")
     ge.build()
+
+
+def test_dp_reducer_attach_groups_cover_the_flat_buffer():
+    """FlatGradAllReducer.attach(): the three gradient groups (out_linear | word_rnn + embedding | vid_rnn + feat_linear)
+    are disjoint ranges covering the whole flat buffer, and the backward's gradient sink is the 13 flat views in the
+    library's parameter order (host logic only: no GPU call)."""
+    import S2VTModel
+    from s2vt_video_caption_amd import dp, functional, capi
+    m = S2VTModel.S2VT(50, 64, 8, dim_hid=32, dim_embed=24)
+    red = dp.FlatGradAllReducer(m.parameters()).attach(m)
+    n = sum(p.numel() for p in m.parameters())
+    spans = sorted(r for g in red.groups.values() for r in g)
+    assert spans[0][0] == 0 and spans[-1][1] == n
+    assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    sizes = {g: sum(hi - lo for lo, hi in r) for g, r in red.groups.items()}
+    named = dict(m.named_parameters())
+    assert sizes[0] == sum(p.numel() for k, p in named.items() if k.startswith("out_linear"))
+    assert sizes[1] == sum(p.numel() for k, p in named.items() if k.startswith(("word_rnn", "embedding")))
+    sink = functional.grad_sink_for(m)
+    assert len(sink) == len(capi.PARAM_KEYS)
+    for k, g in zip(capi.PARAM_KEYS, sink):
+        assert g.data_ptr() == named[k].grad.data_ptr() and g.shape == named[k].shape
+    # the sink lives outside the module: full-module pickles keep the reference's layout
+    assert not any("sink" in k for k in m.__dict__)
