@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="batch per GPU (BASELINE configs[1]: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--decode-batch", type=int, default=None)
+    ap.add_argument("--decode-batch", type=int, default=None, help="greedy-decode batch (default 128 = BASELINE configs[4])")
     ap.add_argument("--gemm-mode", type=int, default=None, choices=[0, 1, 3],
                     help="0 fp32-input MFMA, 3 split-precision bf16x3 (default, fp32-equivalent), 1 bf16 operands "
                          "(BASELINE configs[2]: use with --batch 256)")
@@ -268,7 +268,7 @@ def main():
         roofline = roof_gemm if dominant == gname else roof_step
 
         # ---- greedy decode captions/s (one mode='test' call per measurement)
-        Bd = args.decode_batch or B
+        Bd = args.decode_batch or 128        # BASELINE configs[4]: inference at B=128
         dfe = feats[:Bd] if Bd <= B else synth.make_batch(Bd, L, F, V, seed=99)[0].to(dev)
         model.eval()
         with torch.no_grad():
