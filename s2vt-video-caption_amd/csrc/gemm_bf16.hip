@@ -1,17 +1,20 @@
-// Split-precision GEMM on the gfx950 bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32-MFMA rate).
+// GEMMs on the gfx950 bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 16x the fp32-MFMA rate): the arithmetic and the
+// dispatch; the production kernels live in gemm_x3.hip (3 planes) and gemm_b1.hip (1 plane).
 //
 // An fp32 value x is carried as NP bf16 "planes": x = p0 + p1 + p2 exactly to 24 mantissa bits
 // (p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1)).  A product a*b is then the sum of plane products;
 // bf16*bf16 is exact in fp32 and the MFMA accumulates in fp32, so keeping the six products whose weight is
 // >= 2^-16 of the leading one (hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid) reproduces an fp32 product to
-// ~2^-23 relative — fp32-equivalent arithmetic at 16/6 = 2.7x the fp32-MFMA rate.  NP = 1 is the plain bf16 GEMM
+// ~2^-23 relative - fp32-equivalent arithmetic at 16/6 = 2.7x the fp32-MFMA rate.  NP = 1 is the plain bf16 GEMM
 // (storage bf16, accumulate fp32) of BASELINE config 3.
 //
-// C[M,N] (+)= A[M,K] · B[N,K]^T (+ bias): ONLY the "NT" form — both operands k-contiguous.  Layout changes
-// (transposes, gathers, batch-major <-> time-major) are done by the memory-bound plane-splitting kernels
-// (split.hip), which write each consumer's k-major planes once, so this kernel stays a pure streaming MFMA loop:
-// 128x128x32 tile, 4 waves x (2x2) 32x32 MFMA tiles, padded LDS rows (80 B: conflict-free ds_read_b128),
-// register prefetch of the next k-tile, XCD-aware grouped tile order, optional deterministic split-K.
+// C[M,N] (+)= A[M,K] · B[N,K]^T (+ bias): ONLY the "NT" form - both operands k-contiguous.  Layout changes
+// (transposes, gathers, batch-major <-> time-major) are done by the memory-bound plane-splitting kernels (split.hip).
+//
+// gemm_bf16_nt_kernel below is the first-generation register-staged kernel (128x128 tile, 4 waves x (2x2) MFMA tiles,
+// padded LDS rows, register prefetch, XCD-aware tile order, deterministic split-K).  It is kept for the 1-plane row
+// layout as the A/B reference of gemm_b1.hip (S2VT_B1_OLD=1); its 3-plane form was superseded together with the row
+// layout of the planes (724 us vs 620 us on the logits shape).
 #include <stdlib.h>
 
 #include "common.h"
@@ -229,26 +232,23 @@ int gemm_bf16_nt(hipStream_t stream, int nplanes, int M, int N, int K, const uns
                  bool accumulate, float* splitk_ws, size_t splitk_ws_floats) {
     if (M <= 0 || N <= 0) return 0;
     S2VT_REQUIRE(nplanes == 1 || nplanes == 3, "gemm_bf16_nt: planes must be 1 or 3");
-    static int x3_rows = -1;       // S2VT_X3_ROWS=1: the superseded row-layout 128x128 kernel (needs a matching split.hip)
-    if (x3_rows < 0) { const char* e = getenv("S2VT_X3_ROWS"); x3_rows = e ? atoi(e) : 0; }
-    if (nplanes == 3 && !x3_rows)
+    if (nplanes == 3)           // split precision: the LDS-DMA kernel on the blocked plane layout (gemm_x3.hip)
         return gemm_x3(stream, M, N, K, A, lda, B, ldb, C, ldc, cmap, bias, accumulate, splitk_ws, splitk_ws_floats);
     static int b1_old = -1;        // S2VT_B1_OLD=1: the superseded register-staged 128x128 kernel below
     if (b1_old < 0) { const char* e = getenv("S2VT_B1_OLD"); b1_old = e ? atoi(e) : 0; }
-    if (nplanes == 1 && !b1_old)
+    if (!b1_old)
         return gemm_b1(stream, M, N, K, A, lda, B, ldb, C, ldc, cmap, bias, accumulate, splitk_ws, splitk_ws_floats);
-    const int BKc = (nplanes == 3) ? 32 : 64;
-    S2VT_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= (int64_t)nplanes * K &&
-                     ldb >= (int64_t)nplanes * K && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+    const int BKc = 64;
+    S2VT_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(B) & 15) == 0,
-                 "gemm_bf16_nt: K must be the zero-padded multiple of 64 of the packed plane layout, rows 16-B aligned");
+                 "gemm_bf16_nt: K must be the zero-padded multiple of 64 of the bf16 rows, rows 16-B aligned");
     GemmBfArgs p;
     p.M = M; p.N = N; p.K = K;
     p.A = A; p.lda = lda;
     p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.cmap = cmap; p.bias = bias; p.accumulate = accumulate ? 1 : 0;
-    // 256x128 tiles (8 waves, 25 % fewer L2->LDS bytes per flop) are kept as an option (S2VT_X3_WM=4); measured
-    // 5-10 % slower than 128x128 with two workgroups per CU on every shape of the path, so 128x128 is the default.
+    // 256x128 tiles (8 waves) are kept as an option (S2VT_X3_WM=4); measured 5-10 % slower than 128x128 with two
+    // workgroups per CU on every shape of the path.
     static int force_wm = -1;
     if (force_wm < 0) { const char* e = getenv("S2VT_X3_WM"); force_wm = e ? atoi(e) : 2; }
     const bool wm4 = (force_wm == 4);
@@ -269,13 +269,8 @@ int gemm_bf16_nt(hipStream_t stream, int nplanes, int M, int N, int K, const uns
     if (nsplit > 1) nsplit = cdiv(K, p.ksplit);
     p.slabs = (nsplit > 1) ? splitk_ws : nullptr;
     const dim3 grid(cdiv(tiles, 8) * 8, nsplit);
-    if (wm4) {
-        if (nplanes == 3) hipLaunchKernelGGL((gemm_bf16_nt_kernel<3, 4>), grid, dim3(512), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 4>), grid, dim3(512), 0, stream, p);
-    } else {
-        if (nplanes == 3) hipLaunchKernelGGL((gemm_bf16_nt_kernel<3, 2>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 2>), grid, dim3(256), 0, stream, p);
-    }
+    if (wm4) hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 4>), grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL((gemm_bf16_nt_kernel<1, 2>), grid, dim3(256), 0, stream, p);
     S2VT_LAUNCH_CHECK("gemm_bf16_nt_kernel");
     if (nsplit > 1) return splitk_reduce(stream, splitk_ws, nsplit, M, N, C, ldc, cmap, bias, accumulate);
     return 0;

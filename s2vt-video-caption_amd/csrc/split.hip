@@ -30,13 +30,10 @@ __device__ __forceinline__ void split3(float x, unsigned short (&o)[3]) {
 // 3 planes (split precision, gemm_x3.hip): BLOCKED - per 64-row block and 16-wide k chunk one 6-KB record of six
 // 1-KB pieces (plane, k half), each piece = 64 rows x 8 consecutive k:
 //   (r/64)*(64*ldo) + (k/16)*3072 + (pl*2 + (k%16)/8)*512 + (r%64)*8 + k%8,   ldo = 3*kpad.
-// S2VT_X3_ROWS (build define) restores the superseded row layout r*ldo + (k/32)*96 + pl*32 + k%32.
 __device__ __forceinline__ int64_t packed_off(int64_t r, int k, int pl, int64_t ldo, int np) {
-#ifndef S2VT_X3_ROWS
     if (np == 3)
         return (r >> 6) * (64 * ldo) + (int64_t)(k >> 4) * 3072 + (pl * 2 + ((k >> 3) & 1)) * 512 + (r & 63) * 8 + (k & 7);
-#endif
-    return r * ldo + (int64_t)(k >> 5) * (32 * np) + pl * 32 + (k & 31);
+    return r * ldo + k;
 }
 
 // out(r, c, pl) = plane pl of in[map(r)][c]; r < rows_pad, c < kpad (zeros beyond rows/cols). 8 columns per thread.
