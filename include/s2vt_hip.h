@@ -14,6 +14,10 @@
  *    parameter tensors use the reference's state_dict layout.
  *  - every call is asynchronous and ordered on `stream` (a hipStream_t passed as void*); nothing is
  *    allocated: scratch comes from the caller-provided workspace (size from *_workspace_bytes).
+ *  - one process drives one GPU (one process per GPU for data parallelism).  The library keeps
+ *    process-wide state - GEMM arithmetic mode, pipeline block size, its internal side stream, the gradient-ready
+ *    events of the last backward - so entry points may be called from any host thread (torch runs the backward
+ *    on its autograd thread) but not from several threads at the same time.
  *  - dims: B batch, L = `length` frames (= padded caption length), F feat_dim, H dim_hid,
  *    E dim_embed, V vocab_size; T = 2L-1 LSTM steps.  Internal activations are time-major
  *    [t][b][:]; the external tensors keep the reference's batch-major layout.
