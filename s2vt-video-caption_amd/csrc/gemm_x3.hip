@@ -26,7 +26,6 @@ typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int XT = 256;                    // tile rows = tile cols
 constexpr int X_REC = 6144;                // bytes of one (64-row block, k16 chunk) record: 6 pieces x 1 KB
-constexpr int X_STAGE = 8 * X_REC;         // 4 A records + 4 B records
 constexpr int X_NS = 3;                    // ring depth
 
 struct GemmX3Args {
@@ -45,14 +44,19 @@ __device__ __forceinline__ void glds16(const void* g, void* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// MI = 32-row MFMA tiles per wave in M: 4 -> 256x256 workgroup tile (wave tile 128x64), 2 -> 128x256 (wave tile 64x64:
+// twice the tiles for grids that would otherwise leave CUs idle or need split-K; 12 reads per 24 MFMAs instead of 18
+// per 48).  The A operand fills MI 64-row records of a stage, the B operand always four.
+template <int MI>
 __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
+    constexpr int NRA = MI, TMR = 64 * MI, X_STAGE = (NRA + 4) * X_REC;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[X_NS * X_STAGE];
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int ntn = (p.N + XT - 1) / XT, ntm = (p.M + XT - 1) / XT;
+    const int ntn = (p.N + XT - 1) / XT, ntm = (p.M + TMR - 1) / TMR;
     const int nwg = ntm * ntn, cpx = (nwg + 7) >> 3;
     const int t = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= cpx || t >= nwg) return;
@@ -60,18 +64,21 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
     const int gsz = GM * ntn, grp = t / gsz, first_m = grp * GM;
     const int gm = (ntm - first_m < GM) ? (ntm - first_m) : GM;
     const int tm = first_m + (t % gsz) % gm, tn = (t % gsz) / gm;
-    const int m0 = tm * XT, n0 = tn * XT;
+    const int m0 = tm * TMR, n0 = tn * XT;
     const int kbeg = blockIdx.y * p.ksplit;
     const int kend = (kbeg + p.ksplit < p.K) ? kbeg + p.ksplit : p.K;
     const int nk = (kend - kbeg) >> 4;                 // k16 stages
 
-    // loader role: waves 0-3 stream the four A row-blocks of the tile, waves 4-7 the four B row-blocks; a row-block
-    // past the operand's last one is clamped onto it (its outputs are never stored)
+    // loader role: waves 0..NRA-1 stream the A row-blocks of the tile, the next four waves the B row-blocks (wave index
+    // = record index inside a stage; with MI = 2 waves 6 and 7 load nothing); a row-block past the operand's last one
+    // is clamped onto it (its outputs are never stored)
+    const bool loader = (NRA + 4 == 8) || wave < NRA + 4;      // compile-time true at MI = 4
     const unsigned char* src;
     {
-        const bool isA = wave < 4;
+        const bool isA = wave < NRA;
         const int nrb = ((isA ? p.M : p.N) + 63) >> 6;
-        int rb = ((isA ? m0 : n0) >> 6) + (wave & 3);
+        int rb = isA ? (m0 >> 6) + wave : (n0 >> 6) + (wave - NRA);
+        rb = rb < 0 ? 0 : rb;
         rb = rb < nrb ? rb : nrb - 1;
         const unsigned short* base = isA ? p.A : p.B;
         const int64_t ld = isA ? p.lda : p.ldb;
@@ -84,21 +91,23 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
 #if defined(S2VT_X3_ABLATE) && (S2VT_X3_ABLATE == 1 || S2VT_X3_ABLATE >= 3)   // timing experiment: no global traffic
         if (p.K > 0) return;
 #endif
+        if (!loader) return;
 #pragma unroll
         for (int j = 0; j < 6; ++j) glds16(g + j * 1024, l + j * 1024);
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    // fragment addresses inside a stage: A record (wm*2 + mi/2), row (mi&1)*32 + li; B record 4 + wn, row ni*32 + li
-    const int a_off = (wm * 2) * X_REC + lh * 1024 + li * 16;
-    const int b_off = (4 + wn) * X_REC + lh * 1024 + li * 16;
+    // fragment addresses inside a stage: wave row wm covers tile rows [wm*32*MI, +32*MI): A record wm*MI/2 + mi/2, row
+    // (mi&1)*32 + li; B record NRA + wn, row ni*32 + li
+    const int a_off = (wm * (MI / 2)) * X_REC + lh * 1024 + li * 16;
+    const int b_off = (NRA + wn) * X_REC + lh * 1024 + li * 16;
 
 #ifndef S2VT_X3_SPREAD
 #define S2VT_X3_SPREAD 1      // 1: one DMA request after each of the six MFMA groups; 0: all six right after the barrier
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
         unsigned char* l2 = ldst + ((s + 2) % X_NS) * X_STAGE;
         if (MORE && !S2VT_X3_SPREAD) request(s + 2);
         const unsigned char* st = smem + (s % X_NS) * X_STAGE;
-        bf16x8 a[3][4], b[3][2];
+        bf16x8 a[3][MI], b[3][2];
 #if !defined(S2VT_X3_ABLATE) || S2VT_X3_ABLATE < 3
         // Fragment reads are issued in the order the products consume them - (a1 b1) (a0 b2) (a2 b0) - as inline asm
         // with hand-counted lgkmcnt waits: all 8 waves read right after the barrier, so the 18th read of a wave returns
@@ -127,17 +136,20 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
         const unsigned la = lbase + (unsigned)((s % X_NS) * X_STAGE + a_off), lb = lbase + (unsigned)((s % X_NS) * X_STAGE + b_off);
 #define X3_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF));
 #define X3_LDA(PL) X3_RD(a[PL][0], la, (PL) * 2048) X3_RD(a[PL][1], la, (PL) * 2048 + 512)                        \
-                   X3_RD(a[PL][2], la, X_REC + (PL) * 2048) X3_RD(a[PL][3], la, X_REC + (PL) * 2048 + 512)
+    if constexpr (MI == 4) { X3_RD(a[PL][MI - 2], la, X_REC + (PL) * 2048) X3_RD(a[PL][MI - 1], la, X_REC + (PL) * 2048 + 512) }
 #define X3_LDB(PL) X3_RD(b[PL][0], lb, (PL) * 2048) X3_RD(b[PL][1], lb, (PL) * 2048 + 512)
-#define X3_WAIT(N, PA, PB) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(a[PA][0]), "+v"(a[PA][1]), "+v"(a[PA][2]), \
-                                        "+v"(a[PA][3]), "+v"(b[PB][0]), "+v"(b[PB][1]));
+        // wait until at most N4 (MI = 4) / N2 (MI = 2) reads are outstanding; the operands tie the products to the wait
+#define X3_WAIT(N4, N2, PA, PB)                                                                                          \
+    if constexpr (MI == 4) asm volatile("s_waitcnt lgkmcnt(" #N4 ")" : "+v"(a[PA][0]), "+v"(a[PA][1]), "+v"(a[PA][MI - 2]),   \
+                                        "+v"(a[PA][MI - 1]), "+v"(b[PB][0]), "+v"(b[PB][1]));                                  \
+    else asm volatile("s_waitcnt lgkmcnt(" #N2 ")" : "+v"(a[PA][0]), "+v"(a[PA][1]), "+v"(b[PB][0]), "+v"(b[PB][1]));
         X3_LDA(1) X3_LDB(1) X3_LDA(0) X3_LDB(2) X3_LDA(2) X3_LDB(0)
 #endif
 #if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE >= 3     // timing experiment: MFMAs on register constants only (+ barriers)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) { a[pl][mi] = bf16x8{(short)(0x3f80 + lane + s), 1, 2, 3, 4, 5, 6, 7}; asm volatile("" : "+v"(a[pl][mi])); }
+            for (int mi = 0; mi < MI; ++mi) { a[pl][mi] = bf16x8{(short)(0x3f80 + lane + s), 1, 2, 3, 4, 5, 6, 7}; asm volatile("" : "+v"(a[pl][mi])); }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) { b[pl][ni] = bf16x8{(short)(0x3f80 + lane), 1, 2, 3, 4, 5, 6, 7}; asm volatile("" : "+v"(b[pl][ni])); }
         }
@@ -147,7 +159,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) asm volatile("" ::"v"(a[pl][mi]));
+            for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(a[pl][mi]));
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) asm volatile("" ::"v"(b[pl][ni]));
         }
@@ -158,17 +170,17 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
         // updates of the same accumulator.  The DMA requests of stage s+2 are spread over the MFMA groups: issuing
         // one costs the wave ~100 cycles, which a running MFMA group hides
 #define X3_PROD(PA, PB)                                                                                          \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)            \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)           \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][mi], b[PB][ni], acc[mi][ni], 0, 0, 0);
 #if defined(S2VT_X3_ABLATE) && (S2VT_X3_ABLATE == 1 || S2VT_X3_ABLATE >= 3)   // timing experiment: no global traffic
 #define X3_REQ(J)
 #else
-#define X3_REQ(J) if (MORE && S2VT_X3_SPREAD) glds16(g2 + (J) * 1024, l2 + (J) * 1024);
+#define X3_REQ(J) if (MORE && S2VT_X3_SPREAD && loader) glds16(g2 + (J) * 1024, l2 + (J) * 1024);
 #endif
 #if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE >= 3
-#define X3_WAIT(N, PA, PB)
+#define X3_WAIT(N4, N2, PA, PB)
 #endif
-        X3_WAIT(12, 1, 1) X3_PROD(1, 1) X3_REQ(0) X3_WAIT(6, 0, 2) X3_PROD(0, 2) X3_REQ(1) X3_WAIT(0, 2, 0) X3_PROD(2, 0) X3_REQ(2)
+        X3_WAIT(12, 8, 1, 1) X3_PROD(1, 1) X3_REQ(0) X3_WAIT(6, 4, 0, 2) X3_PROD(0, 2) X3_REQ(1) X3_WAIT(0, 0, 2, 0) X3_PROD(2, 0) X3_REQ(2)
         X3_PROD(0, 1) X3_REQ(3) X3_PROD(1, 0) X3_REQ(4) X3_PROD(0, 0) X3_REQ(5)
 #undef X3_WAIT
 #undef X3_RD
@@ -178,11 +190,11 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
 #define S2VT_X3_PIN 1         // pin the issue order: 18 fragment reads, then 6 x (8 MFMAs, 1 DMA request)
 #endif
 #if S2VT_X3_PIN && (!defined(S2VT_X3_ABLATE) || S2VT_X3_ABLATE == 0)
-        __builtin_amdgcn_sched_group_barrier(0x100, 18, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 3 * (MI + 2), 0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            if (MORE && S2VT_X3_SPREAD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MI, 0);
+            if (MORE && S2VT_X3_SPREAD && MI == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
 #endif
 #undef X3_REQ
@@ -195,10 +207,10 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
     for (; s < nk; ++s) stage(s, std::false_type{});
 
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const int m = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (m >= p.M) continue;
             if (p.slabs) {
                 float* srow = p.slabs + ((int64_t)blockIdx.y * p.M + m) * p.N;
@@ -239,22 +251,31 @@ int gemm_x3(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
     p.A = A; p.lda = lda;
     p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.cmap = cmap; p.bias = bias; p.accumulate = accumulate ? 1 : 0;
-    const int tiles = cdiv(M, XT) * cdiv(N, XT);
-    // One workgroup per CU.  K is split when the model time (rounds of 256 workgroups x per-tile time + the fixed-order
-    // slab combine) says so: ~0.14 us per k unit of a tile (2.2 us per k16 stage), ~6 us per tile of prologue/epilogue,
-    // combine = (n + 1) passes over M x N floats at ~3.5 TB/s + a launch.
-    int nsplit = 1;
-    if (splitk_ws && K >= 512) {
+    // One workgroup per CU.  Tile height (256 or 128 rows) and split-K factor are chosen by a time model: rounds of 256
+    // workgroups x per-tile time + the fixed-order slab combine.  Per k unit of a tile ~0.14 us at 256x256 (2.2 us per
+    // k16 stage) and ~0.092 us at 128x256 (measured: tools/bench_x3_split.py with S2VT_X3_TM); ~6 us per tile of prologue/epilogue; combine = (n + 1) passes over M x N
+    // floats at ~3.5 TB/s + a launch.
+    static int force_tm = -1;    // S2VT_X3_TM=128|256: experiment override
+    if (force_tm < 0) { const char* e = getenv("S2VT_X3_TM"); force_tm = e ? atoi(e) : 0; }
+    int nsplit = 1, tmr = 256;
+    {
         double best = 1e30;
-        for (int n = 1; n <= 16; ++n) {
-            if (n > 1 && (K / n < 256 || (size_t)n * M * N > splitk_ws_floats)) break;
-            const int ks = cdiv(cdiv(K, n), 64) * 64, nn = cdiv(K, ks);
-            if (nn != n) continue;
-            const double rounds = (double)cdiv(tiles * nn, 256);
-            const double t = rounds * (ks * 0.14 + 6.0) + (nn > 1 ? (nn + 1.0) * M * (double)N * 4.0 / 3.5e6 + 8.0 : 0.0);
-            if (t < best * 0.97) { best = t; nsplit = nn; }
+        for (int shape = 0; shape < 2; ++shape) {
+            const int rows = shape ? 128 : 256;
+            if (force_tm && force_tm != rows) continue;
+            const double ck = shape ? 0.092 : 0.14;
+            const int tiles = cdiv(M, rows) * cdiv(N, XT);
+            for (int n = 1; n <= 16; ++n) {
+                if (n > 1 && (!splitk_ws || K < 512 || K / n < 256 || (size_t)n * M * N > splitk_ws_floats)) break;
+                const int ks = cdiv(cdiv(K, n), 64) * 64, nn = cdiv(K, ks);
+                if (nn != n) continue;
+                const double rounds = (double)cdiv(tiles * nn, 256);
+                const double t = rounds * (ks * ck + 6.0) + (nn > 1 ? (nn + 1.0) * M * (double)N * 4.0 / 3.5e6 + 8.0 : 0.0);
+                if (t < best * 0.97) { best = t; nsplit = nn; tmr = rows; }
+            }
         }
     }
+    const int tiles = cdiv(M, tmr) * cdiv(N, XT);
     static int force_n = -1;     // S2VT_X3_NSPLIT=n: experiment override (tools/bench_x3_split.py)
     if (force_n < 0) { const char* e = getenv("S2VT_X3_NSPLIT"); force_n = e ? atoi(e) : 0; }
     if (force_n > 0 && splitk_ws && (size_t)force_n * M * N <= splitk_ws_floats && K / force_n >= 64) nsplit = force_n;
@@ -262,7 +283,8 @@ int gemm_x3(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
     if (nsplit > 1) nsplit = cdiv(K, p.ksplit);
     p.slabs = (nsplit > 1) ? splitk_ws : nullptr;
     const dim3 grid(cdiv(tiles, 8) * 8, nsplit);
-    hipLaunchKernelGGL(gemm_x3_kernel, grid, dim3(512), 0, stream, p);
+    if (tmr == 256) hipLaunchKernelGGL(gemm_x3_kernel<4>, grid, dim3(512), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_x3_kernel<2>, grid, dim3(512), 0, stream, p);
     S2VT_LAUNCH_CHECK("gemm_x3_kernel");
     if (nsplit > 1) return splitk_reduce(stream, splitk_ws, nsplit, M, N, C, ldc, cmap, bias, accumulate);
     return 0;
