@@ -31,8 +31,22 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* logits, int V,
     const float* row = logits + r * V;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool vec = (V % 4 == 0) && ((reinterpret_cast<uintptr_t>(row) & 15) == 0);
+    // Rows of up to 16384 logits are held in registers between the max pass and the exp-sum pass (16 x f32x4 per
+    // thread): the row is read from memory once.  Same operations in the same order as the two-pass form.
+    constexpr int NBUF = 16;
+    const bool reg = vec && V <= NBUF * 1024;
+    f32x4 buf[NBUF];
     float m = -INFINITY;
-    if (vec) {
+    if (reg) {
+#pragma unroll
+        for (int i = 0; i < NBUF; ++i) {
+            const int c = tid * 4 + i * 1024;
+            if (c < V) {
+                buf[i] = *reinterpret_cast<const f32x4*>(row + c);
+                m = fmaxf(fmaxf(m, fmaxf(buf[i][0], buf[i][1])), fmaxf(buf[i][2], buf[i][3]));
+            }
+        }
+    } else if (vec) {
         for (int c = tid * 4; c < V; c += 1024) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
             m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
@@ -46,7 +60,13 @@ __global__ __launch_bounds__(256) void ce_row_kernel(const float* logits, int V,
     m = fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]));
     __syncthreads();
     float s = 0.f;
-    if (vec) {
+    if (reg) {
+#pragma unroll
+        for (int i = 0; i < NBUF; ++i) {
+            const int c = tid * 4 + i * 1024;
+            if (c < V) s += expf(buf[i][0] - m) + expf(buf[i][1] - m) + expf(buf[i][2] - m) + expf(buf[i][3] - m);
+        }
+    } else if (vec) {
         for (int c = tid * 4; c < V; c += 1024) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
             s += expf(v[0] - m) + expf(v[1] - m) + expf(v[2] - m) + expf(v[3] - m);
