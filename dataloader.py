@@ -15,6 +15,8 @@ import json
 import pathlib as plb
 
 import numpy as np
+import os
+
 import torch
 from torch.utils.data import Dataset
 
@@ -55,40 +57,94 @@ class VideoDataset(Dataset):
         return len(self.feat_paths)
 
 
+COPY_THREADS = int(os.environ.get("S2VT_FEED_THREADS", "4"))      # host threads staging a batch into pinned memory
+
+
 def feed_batches(loader, dev=None, depth=2):
     """Iterate a `torch.utils.data.DataLoader` over a host-item `VideoDataset`, yielding `(feats, targets, IDs, masks)`
-    with the tensors already resident on `dev`: batches are staged in pinned memory and copied on a side stream, up
-    to `depth` batches ahead, so the copy of batch i+1 overlaps the training step of batch i.  At the target rates
-    (>= 3e5 frames/s = 5 GB/s of fp32 features) the reference's per-item synchronous copies would bound training."""
+    with the tensors already resident on `dev`.
+
+    A background thread pulls batches from the loader, stages them in a ring of PERSISTENT pinned buffers and copies
+    them on a side stream into a ring of PERSISTENT device buffers, up to `depth` batches ahead; the training thread
+    only waits on the copy's event.  Nothing is allocated per batch (pinning 84 MB per step costs tens of ms, and device
+    tensors allocated on the copy stream every step make the caching allocator stall the training thread), so the host
+    memcpy, the PCIe transfer and the previous training step overlap (measured: tools/bench_feed.py).  The yielded
+    tensors are views of the ring: they stay valid until the NEXT batch is requested from the generator - the contract
+    of a training loop that consumes one batch per step.  At the target rates (>= 3e5 frames/s = 5 GB/s of fp32 features)
+    the reference's per-item synchronous copies would bound training."""
     dev = dev or device
     if dev.type != 'cuda':
         for batch in loader:
             yield batch
         return
+    import queue
+    import threading
     copy_stream = torch.cuda.Stream(device=dev)
-    queue = []
-    it = iter(loader)
+    nslot = depth + 2                           # `depth` in flight + the one being consumed + the one being filled
+    slots = [dict(pinned=None, device=None, copied=None, consumed=None) for _ in range(nslot)]
+    ready = queue.Queue(maxsize=depth)          # bounds the read-ahead
+    stop = threading.Event()
 
-    def stage():
+    def producer():
         try:
-            feats, targets, ids, masks = next(it)
-        except StopIteration:
-            return False
-        host = [t.pin_memory() for t in (feats, targets, masks)]
-        with torch.cuda.stream(copy_stream):
-            devt = [t.to(dev, non_blocking=True) for t in host]
-            ev = torch.cuda.Event()
-            ev.record(copy_stream)
-        queue.append((devt, ids, ev, host))
-        return True
+            torch.cuda.set_device(dev)
+            # the staging memcpy runs on torch's intra-op threads; this thread's team is kept small (the default is one
+            # thread per visible core, which under a container CPU quota starves the training thread)
+            torch.set_num_threads(COPY_THREADS)
+            for i, (feats, targets, ids, masks) in enumerate(loader):
+                if stop.is_set():
+                    return
+                slot = slots[i % nslot]
+                host = (feats, targets, masks)
+                if slot["pinned"] is None or any(p.shape[1:] != h.shape[1:] or p.dtype != h.dtype or p.shape[0] < h.shape[0]
+                                                 for p, h in zip(slot["pinned"], host)):
+                    if slot["copied"] is not None:
+                        slot["copied"].synchronize()
+                    slot["pinned"] = [torch.empty(h.shape, dtype=h.dtype).pin_memory() for h in host]
+                    with torch.cuda.stream(copy_stream):
+                        slot["device"] = [torch.empty(h.shape, dtype=h.dtype, device=dev) for h in host]
+                if slot["copied"] is not None:
+                    slot["copied"].synchronize()            # the previous H2D copy has read this slot's pinned buffers
+                pviews = [p[:h.shape[0]] for p, h in zip(slot["pinned"], host)]
+                for v, h in zip(pviews, host):
+                    v.copy_(h)                              # pageable -> pinned (skipped work if the loader pins: same cost)
+                dviews = [d[:h.shape[0]] for d, h in zip(slot["device"], host)]
+                with torch.cuda.stream(copy_stream):
+                    if slot["consumed"] is not None:
+                        copy_stream.wait_event(slot["consumed"])    # the step that used this slot's device buffers is done
+                    for d, v in zip(dviews, pviews):
+                        d.copy_(v, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(copy_stream)
+                slot["copied"] = ev
+                ready.put((i % nslot, dviews, ids, ev))
+            ready.put(None)
+        except BaseException as e:                         # surface loader / copy errors in the training thread
+            ready.put(e)
 
-    for _ in range(depth):
-        if not stage():
-            break
-    while queue:
-        (f, t, m), ids, ev, host = queue.pop(0)
-        torch.cuda.current_stream(dev).wait_event(ev)
-        for x in (f, t, m):
-            x.record_stream(torch.cuda.current_stream(dev))
-        stage()
-        yield f, t, ids, m
+    th = threading.Thread(target=producer, name="s2vt-feed", daemon=True)
+    th.start()
+    prev = None
+    try:
+        while True:
+            item = ready.get()
+            cur = torch.cuda.current_stream(dev)
+            if prev is not None:                           # everything enqueued so far that reads the previous batch
+                ev = torch.cuda.Event()
+                ev.record(cur)
+                slots[prev]["consumed"] = ev
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            prev, (f, t, m), ids, ev = item
+            cur.wait_event(ev)
+            yield f, t, ids, m
+    finally:
+        stop.set()
+        while th.is_alive():                               # unblock a producer waiting on the bounded queue
+            try:
+                ready.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(timeout=0.05)

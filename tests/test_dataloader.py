@@ -67,18 +67,23 @@ import pytest
 @pytest.mark.gpu
 def test_feed_batches_on_gpu_matches_host(tmp_path):
     import dataloader
-    _make(tmp_path, n=9, L=8, F=16)
+    _make(tmp_path, n=23, L=8, F=16)
     dev = torch.device("cuda", 0)
-    ds = dataloader.VideoDataset(str(tmp_path / "captions.json"), str(tmp_path / "feats"), max_len=8, mode="train")
-    loader = torch.utils.data.DataLoader(ds, batch_size=1, shuffle=False)
+    ds = dataloader.VideoDataset(str(tmp_path / "captions.json"), str(tmp_path / "feats"), max_len=8, mode="test")   # 18 items
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False)
     np.random.seed(7)
     host = list(loader)
     np.random.seed(7)
-    got = list(dataloader.feed_batches(loader, dev=dev, depth=2))
-    assert len(got) == len(host) == 4
-    for (f, t, ids, m), (hf, ht, hids, hm) in zip(got, host):
+    n = 0
+    # many more batches than ring slots (depth + 2), a ragged last batch; a yielded batch is a view of the ring that
+    # stays valid until the next one is requested, so each is checked (after some stream work) before moving on
+    for (f, t, ids, m), (hf, ht, hids, hm) in zip(dataloader.feed_batches(loader, dev=dev, depth=2), host):
         assert f.is_cuda and t.is_cuda and m.is_cuda
+        g = (f * 2.0).sum()                              # work on the consumer stream that reads the batch
         assert torch.equal(f.cpu(), hf) and torch.equal(t.cpu(), ht) and torch.equal(m.cpu(), hm) and ids == hids
+        assert abs(float(g) - float((hf * 2.0).sum())) < 1e-2
+        n += 1
+    assert n == len(host) and n > 4
 
 
 @pytest.mark.gpu
