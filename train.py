@@ -30,6 +30,9 @@ def parse():
     ap.add_argument("--feat-dim", type=int, default=4096)
     ap.add_argument("--feat-dropout", type=float, default=0.0)
     ap.add_argument("--batch-size", type=int, default=16, help="per process")
+    ap.add_argument("--workers", type=int, default=0,
+                    help="DataLoader worker processes (0 = the reference's behaviour: items are loaded by the feed thread; "
+                         "at B=64 a batch is 64 .npy files = 84 MB per 13-ms step, so real runs want a few workers)")
     ap.add_argument("--epochs", type=int, default=300)
     ap.add_argument("--save-freq", type=int, default=100)
     ap.add_argument("--save-path", default="./checkpoint")
@@ -61,8 +64,10 @@ def main():
     validset = dataloader.VideoDataset(opt.caption_file, opt.feats_path, max_len=opt.train_length, mode='valid')
     sampler = torch.utils.data.distributed.DistributedSampler(trainset, shuffle=True, drop_last=True) if world > 1 else None
     train_loader = torch.utils.data.DataLoader(trainset, batch_size=opt.batch_size, shuffle=sampler is None,
-                                               sampler=sampler, drop_last=world > 1)
-    valid_loader = torch.utils.data.DataLoader(validset, batch_size=opt.batch_size, shuffle=False)
+                                               sampler=sampler, drop_last=world > 1, num_workers=opt.workers,
+                                               persistent_workers=opt.workers > 0)
+    valid_loader = torch.utils.data.DataLoader(validset, batch_size=opt.batch_size, shuffle=False, num_workers=opt.workers,
+                                               persistent_workers=opt.workers > 0)
     word2ix = trainset.word2ix
 
     torch.manual_seed(0)        # identical replicas
