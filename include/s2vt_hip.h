@@ -184,6 +184,19 @@ int s2vt_lstm_seq_fwd(int32_t T, int32_t B, int32_t H, const float* gx, int32_t 
 int s2vt_lstm_seq_bwd(int32_t T, int32_t B, int32_t H, const float* w_hh, const float* dh_out, int32_t dh_first,
                       const float* c_all, float* stash_dg, float* w_hh_t, float* dc, void* stream);
 
+/* Config-3 arithmetic of one LSTM layer forward (nn.LSTM at S2VTModel.py:67/:77 with bf16 operands, fp32 accumulate,
+ * fp32 cell state): gx_stash [T*B,4H] gate input in (steps < n_gx; bias for the rest), activated gates out; h_all,
+ * c_all [T*B,H] out.  persistent = 0: one launch per timestep; 1: one persistent launch per `block` timesteps
+ * (0 = all T) with the W_hh slice of each compute unit resident in registers.  workspace[0] (int32) is set to 1 if a
+ * hand-off wait of the persistent kernel timed out. */
+size_t s2vt_lstm_seq_bf16_workspace_bytes(int32_t T, int32_t B, int32_t H);
+int s2vt_lstm_seq_fwd_bf16(int32_t T, int32_t B, int32_t H, float* gx_stash, int32_t n_gx, const float* bias,
+                           const float* w_hh, float* h_all, float* c_all, void* workspace, size_t workspace_bytes,
+                           int32_t persistent, int32_t block, void* stream);
+/* Recurrence schedule inside the whole-path drivers (bf16 mode): 1 = persistent kernels where the shape allows
+ * (default), 0 = one launch per timestep; negative: query.  Returns the previous value. */
+int s2vt_set_recurrence_mode(int32_t persistent);
+
 /* One greedy decode step's out_linear + argmax (S2VTModel.py:95-96,105-106): packed[b] (zeroed by the caller)
  * receives max over v of (ordered(logit) << 32 | (0xFFFFFFFF - v)); token = 0xFFFFFFFF - low 32 bits. */
 int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, const float* w_out, const float* b_out,

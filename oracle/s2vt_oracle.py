@@ -176,7 +176,7 @@ class _Node:
 
 
 def beam_search(params, feats, beam_width=3, max_depth=30, sos_ix=3, eos_ix=4, fanout=20,
-                dtype=torch.float32):
+                dtype=torch.float32, return_gap=False):
     """``S2VT.forward(mode='beam_search')`` + ``beam_search`` (S2VTModel.py:56-61,
     149-240).  Returns list[B] of python int lists starting with <sos>.
 
@@ -186,6 +186,11 @@ def beam_search(params, feats, beam_width=3, max_depth=30, sos_ix=3, eos_ix=4, f
     one word step (:211-212), log_softmax (:213-214), push the top-20 tokens in
     ascending token order (:216-223); stop when the queue has <= beam_width entries
     (:227-228); answer = best entry, back-traced (:231-238).
+
+    ``return_gap``: also return the smallest score gap any decision of the search rested on (per depth: between the
+    last entry popped and the best entry discarded by the clear; at the end: between the winner and the runner-up).
+    Fixture screening only (oracle/make_golden.py): a reimplementation whose log-probs differ by less than this gap
+    takes the same decisions.
     """
     p = _cast(params, dtype)
     feats = feats.to(dtype)
@@ -199,6 +204,7 @@ def beam_search(params, feats, beam_width=3, max_depth=30, sos_ix=3, eos_ix=4, f
         h2, c2 = _word_step(p, None, out1[:, t], h2, c2)
 
     sentences = []
+    min_gap = float("inf")
     for b in range(B):                                                        # :170
         root = _Node((h1[b:b + 1], c1[b:b + 1]), (h2[b:b + 1], c2[b:b + 1]), None, sos_ix, 0, 1)
         heap = []
@@ -210,6 +216,8 @@ def beam_search(params, feats, beam_width=3, max_depth=30, sos_ix=3, eos_ix=4, f
             for _ in range(beam_width):                                       # :191-193
                 if heap:
                     beam.append(heapq.heappop(heap))
+            if heap and beam:
+                min_gap = min(min_gap, float(heap[0][0]) - float(beam[-1][0]))
             heap = []                                                         # :194
             for key, n in beam:
                 if n.tok == eos_ix and n.prev is not None:                    # :200-202
@@ -228,12 +236,16 @@ def beam_search(params, feats, beam_width=3, max_depth=30, sos_ix=3, eos_ix=4, f
                     heapq.heappush(heap, (-child.score(), child))             # :223
             if len(heap) <= beam_width:                                       # :227-228
                 break
-        _, fin = heapq.heappop(heap)                                          # :231
+        k_fin, fin = heapq.heappop(heap)                                      # :231
+        if heap:
+            min_gap = min(min_gap, float(heap[0][0]) - float(k_fin))
         sent = [fin.tok]
         while fin.prev is not None:                                           # :234-236
             fin = fin.prev
             sent.append(fin.tok)
         sentences.append(sent[::-1])
+    if return_gap:
+        return sentences, min_gap
     return sentences
 
 

@@ -69,6 +69,10 @@ SIGNATURES = {
     "s2vt_lstm_step_bwd": (c_int32, [c_int32, c_int32] + [c_void_p] * 7 + [c_int32, c_void_p, c_void_p]),
     "s2vt_lstm_seq_fwd": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_int32] + [c_void_p] * 6),
     "s2vt_lstm_seq_bwd": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 5),
+    "s2vt_lstm_seq_bf16_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "s2vt_lstm_seq_fwd_bf16": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_size_t, c_int32, c_int32, c_void_p]),
+    "s2vt_set_recurrence_mode": (c_int32, [c_int32]),
     "s2vt_decode_step_argmax": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5),
     "s2vt_set_gemm_mode": (c_int32, [c_int32]),
     "s2vt_set_pipeline_block": (c_int32, [c_int32]),

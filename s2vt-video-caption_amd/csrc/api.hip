@@ -100,7 +100,8 @@ struct TrainWS {
     size_t gws_floats;
     int32_t* tok;
     int* embws;              // embedding_grad scratch (heavy-token list)
-    int* err;
+    int* err;                // [0] target id out of range, [1] persistent-recurrence hand-off timed out
+    unsigned int *psync_a, *psync_b;     // hand-off counters of the persistent recurrence kernels (one block per lane)
     size_t bytes;
 };
 
@@ -124,6 +125,8 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     w.tok = c.take<int32_t>((L - 1) * B);
     w.embws = c.take<int>(embedding_grad_ws_ints((int64_t)(L - 1) * B));
     w.err = c.take<int>(4);
+    w.psync_a = c.take<unsigned int>(lstm_persist_sync_bytes() / sizeof(unsigned int));
+    w.psync_b = c.take<unsigned int>(lstm_persist_sync_bytes() / sizeof(unsigned int));
     // backward-only scratch (two of everything that the two concurrently running layers touch)
     w.wt1 = c.take<float>(H * 4 * H);
     w.wt2 = c.take<float>(H * 4 * H);
@@ -454,6 +457,31 @@ static int seq_bwd_bf16(hipStream_t st, int T, int t0, int t1, int B, int H, con
     return 0;
 }
 
+// Recurrence schedule of the bf16 timestep kernels: 1 = one persistent launch per block of timesteps (lstm_persist.hip,
+// W_hh slice resident per CU) where the shape allows it, 0 = one launch per timestep (lstm_bf16.hip).
+static int g_persist = -1;
+static bool persist_on() {
+    if (g_persist < 0) { const char* e = getenv("S2VT_PERSIST"); g_persist = e ? (atoi(e) != 0) : 1; }
+    return g_persist != 0;
+}
+static int seq_fwd_bf16_any(hipStream_t st, int t0, int t1, int B, int H, float* gx_stash, int n_gx, const float* bias,
+                            const PB& wb, const PB& hb, float* h_all, float* c_all, unsigned int* sync, int* err) {
+    if (t1 <= t0) return 0;
+    if (!(persist_on() && lstm_seq_fwd_bf16_persist_supported(B, H, hb.kpad) && hb.kpad == wb.kpad))
+        return seq_fwd_bf16(st, t0, t1, B, H, gx_stash, n_gx, bias, wb, hb, h_all, c_all);
+    ProfScope ps(st, K_STEP_FWD, t1 - t0);
+    SeqFwdBf16Args a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.H = H; a.Kp = hb.kpad;
+    a.t0 = t0; a.t1 = t1; a.n_gx = n_gx;
+    a.wb = wb.p; a.ldwb = wb.ld;
+    a.hb = hb.p; a.ldhb = hb.ld;
+    a.gx_stash = gx_stash; a.bias = bias;
+    a.h_all = h_all; a.c_all = c_all;
+    a.sync = sync; a.err = err;
+    return lstm_seq_fwd_bf16_persist(st, a);
+}
+
 // ---- argument builders for single timesteps (used by the paired-launch schedule)
 static StepFwdArgs fwd_args(int t, int B, int H, float* gx_stash, int n_gx, const float* bias, const float* w_hh,
                             float* h_all, float* c_all) {
@@ -578,7 +606,8 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
     for (size_t k = 0; k + 1 < bd.size(); ++k) {
         const int t0 = bd[k], t1 = bd[k + 1];
         if (bf) {
-            if ((rc = seq_fwd_bf16(st, t0, t1, B, H, w.s1, L, w.bsum1, q.whh1, q.h1, w.h1, w.c1))) return rc;
+            if ((rc = seq_fwd_bf16_any(st, t0, t1, B, H, w.s1, L, w.bsum1, q.whh1, q.h1, w.h1, w.c1, w.psync_a, w.err + 1)))
+                return rc;
         } else {
             if ((rc = seq_fwd(st, t0, t1, B, H, w.s1, L, w.bsum1, p->vid_w_hh, w.h1, w.c1, true))) return rc;
         }
@@ -590,7 +619,8 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
                         cap ? nullptr : w.bsum2, cap)))
             return rc;
         if (bf) {
-            if ((rc = seq_fwd_bf16(sx, t0, t1, B, H, w.s2, T, w.bsum2, q.whh2, q.h2r, w.h2, w.c2))) return rc;
+            if ((rc = seq_fwd_bf16_any(sx, t0, t1, B, H, w.s2, T, w.bsum2, q.whh2, q.h2r, w.h2, w.c2, w.psync_b, w.err + 1)))
+                return rc;
         } else {
             if ((rc = seq_fwd(sx, t0, t1, B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, true))) return rc;
         }
@@ -1230,6 +1260,79 @@ int s2vt_lstm_seq_bwd(int32_t T, int32_t B, int32_t H, const float* w_hh, const 
     int rc;
     if ((rc = transpose_f32(st, w_hh, 4 * H, H, w_hh_t))) return rc;
     return seq_bwd(st, T, 0, T, B, H, w_hh_t, dh_out, dh_first, c_all, stash_dg, dc);
+}
+
+#ifdef S2VT_EXPERIMENT_STAMPS
+static unsigned long long* g_xstamps = nullptr;
+static int g_xstamp_block = 0;
+#endif
+// bf16-operand layer forward (config 3 arithmetic) as its own entry point: kernel-level parity tests and benchmarks.
+// workspace: [err int x64][sync][W_hh bf16 rows][h bf16 rows]
+struct SeqBf16WS { int* err; unsigned int* sync; PB wb, hb; size_t bytes; };
+static SeqBf16WS carve_seq_bf16(int T, int B, int H, void* base) {
+    Carver c{reinterpret_cast<char*>(base), 0, 0};
+    SeqBf16WS w;
+    w.err = c.take<int>(64);
+    w.sync = c.take<unsigned int>(lstm_persist_sync_bytes() / sizeof(unsigned int));
+    auto mk = [&](size_t rows, size_t k) {
+        PB b;
+        b.kpad = pad64((int)k);
+        b.ld = b.kpad;
+        b.p = c.take<unsigned short>(rows64(rows) * (size_t)b.ld);
+        return b;
+    };
+    w.wb = mk((size_t)4 * H, H);
+    w.hb = mk((size_t)T * B, H);
+    w.bytes = align_up(c.off, 256);
+    return w;
+}
+size_t s2vt_lstm_seq_bf16_workspace_bytes(int32_t T, int32_t B, int32_t H) {
+    if (T <= 0 || B <= 0 || H <= 0) return 0;
+    return carve_seq_bf16(T, B, H, nullptr).bytes;
+}
+int s2vt_lstm_seq_fwd_bf16(int32_t T, int32_t B, int32_t H, float* gx_stash, int32_t n_gx, const float* bias,
+                           const float* w_hh, float* h_all, float* c_all, void* workspace, size_t workspace_bytes,
+                           int32_t persistent, int32_t block, void* stream) {
+    S2VT_REQUIRE(T > 0 && B > 0 && H > 0 && gx_stash && w_hh && h_all && c_all && workspace && n_gx >= 0 && n_gx <= T,
+                 "s2vt_lstm_seq_fwd_bf16: bad arguments");
+    S2VT_REQUIRE(n_gx == T || bias, "s2vt_lstm_seq_fwd_bf16: bias needed for steps without gx");
+    const SeqBf16WS w = carve_seq_bf16(T, B, H, workspace);
+    S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_lstm_seq_fwd_bf16: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = fill_zero(st, w.err, 64 * sizeof(int)))) return rc;
+    if ((rc = split_planes(st, 1, false, w_hh, H, ID, 4 * H, H, w.wb.p, w.wb.ld, w.wb.kpad, (int)rows64((size_t)4 * H)))) return rc;
+    if ((rc = zero_pad_cols_u16(st, w.hb.p, (int64_t)T * B, w.hb.ld, H, w.hb.kpad))) return rc;
+    if (!persistent) return seq_fwd_bf16(st, 0, T, B, H, gx_stash, n_gx, bias, w.wb, w.hb, h_all, c_all);
+    S2VT_REQUIRE(lstm_seq_fwd_bf16_persist_supported(B, H, w.hb.kpad), "s2vt_lstm_seq_fwd_bf16: shape not supported by the persistent kernel");
+    const int blk = block > 0 ? block : T;
+    for (int t0 = 0; t0 < T; t0 += blk) {
+        SeqFwdBf16Args a;
+        memset(&a, 0, sizeof(a));
+        a.B = B; a.H = H; a.Kp = w.hb.kpad;
+        a.t0 = t0; a.t1 = (t0 + blk < T) ? t0 + blk : T; a.n_gx = n_gx;
+        a.wb = w.wb.p; a.ldwb = w.wb.ld;
+        a.hb = w.hb.p; a.ldhb = w.hb.ld;
+        a.gx_stash = gx_stash; a.bias = bias;
+        a.h_all = h_all; a.c_all = c_all;
+        a.sync = w.sync; a.err = w.err;
+#ifdef S2VT_EXPERIMENT_STAMPS
+        a.stamps = g_xstamps; a.stamp_block = g_xstamp_block;
+#endif
+        ProfScope ps(st, K_STEP_FWD, a.t1 - a.t0);
+        if ((rc = lstm_seq_fwd_bf16_persist(st, a))) return rc;
+    }
+    return 0;
+}
+
+#ifdef S2VT_EXPERIMENT_STAMPS
+extern "C" int s2vt_experiment_set_stamps(unsigned long long* buf, int block) { g_xstamps = buf; g_xstamp_block = block; return 0; }
+#endif
+
+int s2vt_set_recurrence_mode(int32_t persistent) {
+    const int prev = persist_on() ? 1 : 0;
+    if (persistent >= 0) g_persist = persistent ? 1 : 0;
+    return prev;
 }
 
 int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, const float* w_out, const float* b_out,

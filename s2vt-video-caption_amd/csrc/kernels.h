@@ -1,4 +1,4 @@
-// Internal launch interface between the HIP kernels and the C-ABI drivers (api.cpp).
+// Internal launch interface between the HIP kernels and the C-ABI drivers (api.hip).
 #pragma once
 #include "common.h"
 
@@ -99,6 +99,25 @@ struct StepBwdBf16Args {
     unsigned short* dgb; int64_t lddgbo;            // bf16 row image of dG_t
 };
 int lstm_step_bwd_bf16(hipStream_t stream, const StepBwdBf16Args& a);
+
+// ---- lstm_persist.hip: persistent bf16 recurrence (one launch per block of timesteps, W_hh slice resident per CU)
+struct SeqFwdBf16Args {
+    int B, H, Kp;                                   // Kp: H zero-padded to a multiple of 64 (<= 1024)
+    int t0, t1, n_gx;                               // steps [t0, t1); gx present for t < n_gx, bias otherwise
+    const unsigned short* wb; int64_t ldwb;         // bf16 W_hh rows [4H][Kp]
+    unsigned short* hb; int64_t ldhb;               // bf16 h rows, time-major [T*B][ldhb]: h_{t-1} in, h_t out
+    float* gx_stash;                                // [T*B][4H]: gate input in, activated gates i,f,g,o out (in place)
+    const float* bias;                              // [4H]
+    float* h_all;                                   // [T*B][H] fp32 h_t (optional)
+    float* c_all;                                   // [T*B][H] fp32 c_t
+    unsigned int* sync;                             // lstm_persist_sync_bytes() of counters (zeroed by the launcher)
+    int* err;                                       // set to 1 if a hand-off wait timed out
+    int RB, NS;                                     // set by the launcher: rows per workgroup, 64-row sub-chains
+    unsigned long long* stamps; int stamp_block;    // timing experiments only (experiment.h); null in the product
+};
+int lstm_seq_fwd_bf16_persist_supported(int B, int H, int Kp);
+size_t lstm_persist_sync_bytes();
+int lstm_seq_fwd_bf16_persist(hipStream_t stream, SeqFwdBf16Args a);
 
 struct LogitsArgmaxArgs {
     int B, H, V;

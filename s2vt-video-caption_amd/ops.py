@@ -199,3 +199,24 @@ def beam_step(params, dims, row_b, row_state, tok, vid_h, vid_c, word_h, word_c)
                                       _ptr(_f32c(word_h, "word_h")), _ptr(_f32c(word_c, "word_c")), _ptr(wh), _ptr(wc),
                                       _ptr(tix), _ptr(tlp), _ptr(ws), nbytes, _stream(dev)), "s2vt_beam_step")
     return vh, vc, wh[:R], wc[:R], tix[:R], tlp[:R]
+
+
+def lstm_seq_fwd_bf16(gx, n_gx, bias, w_hh, T, B, H, persistent=False, block=0):
+    """Config-3 arithmetic of one LSTM layer (bf16 operands, fp32 accumulate / cell state): returns (h_all, c_all, gates)
+    [T*B,H], [T*B,H], [T*B,4H].  `gx` [T*B,4H] is left untouched (the kernels work on a copy: the gate stash is written
+    in place of the gate input).  persistent: one launch per `block` steps (0 = all)."""
+    lib = capi.load()
+    dev = w_hh.device
+    stash = _f32c(gx, "gx").clone()
+    w_hh = _f32c(w_hh, "w_hh")
+    with torch.cuda.device(dev):
+        nbytes = lib.s2vt_lstm_seq_bf16_workspace_bytes(T, B, H)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        h_all = torch.empty(T * B, H, dtype=torch.float32, device=dev)
+        c_all = torch.empty(T * B, H, dtype=torch.float32, device=dev)
+        capi.check(lib.s2vt_lstm_seq_fwd_bf16(T, B, H, _ptr(stash), int(n_gx), _ptr(bias), _ptr(w_hh), _ptr(h_all),
+                                              _ptr(c_all), _ptr(ws), nbytes, int(persistent), int(block), _stream(dev)),
+                   "s2vt_lstm_seq_fwd_bf16")
+        if int(ws[:4].view(torch.int32)[0].item()) != 0:
+            raise capi.S2VTHipError("persistent recurrence: a hand-off wait timed out (workgroups not co-resident?)")
+    return h_all, c_all, stash

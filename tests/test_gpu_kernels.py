@@ -246,3 +246,80 @@ def test_beam_step_matches_cell_and_topk(lib):
     assert (wh - rwh).abs().max() < 2e-6 and (wc - rwc).abs().max() < 2e-6
     assert torch.equal(tix.long(), rix)
     assert (tlp - logp.gather(1, rix)).abs().max() < 5e-6
+
+
+# ---------------------------------------------------------------------------------------------- config-3 (bf16) kernels
+def _bf16r(x):
+    return x.to(torch.bfloat16).to(torch.float64)
+
+
+def _check_seq_bf16_teacher_forced(h_all, c_all, gates, gx, n_gx, bias, w_hh, T, B, H, tol=2e-5):
+    """Every step checked on its own against fp64 math on the bf16-rounded operands the kernel itself saw: the h the
+    kernel wrote for step t-1 (rounded to bf16 as the kernel rounds it) and its fp32 c_{t-1}.  A wrong k mapping, a
+    stale or torn hand-off of h_{t-1}, a lost row or column shows as an O(0.1) error; fp32 accumulation order as ~1e-6."""
+    wb = _bf16r(w_hh.cpu())
+    h_all, c_all, gates = h_all.cpu().double(), c_all.cpu().double(), gates.cpu().double()
+    gx, bias = gx.cpu().double(), bias.cpu().double()
+    worst = 0.0
+    for t in range(T):
+        hp = _bf16r(h_all[(t - 1) * B:t * B].float()) if t else torch.zeros(B, H, dtype=torch.float64)
+        cp = c_all[(t - 1) * B:t * B] if t else torch.zeros(B, H, dtype=torch.float64)
+        pre = (gx[t * B:(t + 1) * B] if t < n_gx else bias[None, :]) + hp @ wb.t()
+        i, f, g, o = pre.chunk(4, dim=1)
+        i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+        c = f * cp + i * g
+        h = o * torch.tanh(c)
+        worst = max(worst, (h_all[t * B:(t + 1) * B] - h).abs().max().item(), (c_all[t * B:(t + 1) * B] - c).abs().max().item(),
+                    (gates[t * B:(t + 1) * B] - torch.cat([i, f, g, o], dim=1)).abs().max().item())
+    assert worst < tol, worst
+    return worst
+
+
+@pytest.mark.parametrize("T,B,H,n_gx", [(3, 37, 1000, 2), (4, 5, 72, 4), (3, 129, 1000, 3), (5, 64, 200, 3)])
+def test_bf16_step_kernels_h1000_odd_batch(lib, T, B, H, n_gx):
+    """lstm_step_fwd_bf16_kernel at the config-3 hidden size (H = 1000: k padded to 1024, gate tiles ragged) and batch
+    sizes that are not multiples of any tile."""
+    from s2vt_video_caption_amd import ops
+    gx, bias, w = _r(T * B, 4 * H, seed=11), _r(4 * H, seed=12, scale=0.3), _r(4 * H, H, seed=13, scale=H ** -0.5)
+    h_all, c_all, gates = ops.lstm_seq_fwd_bf16(gx.to(DEV), n_gx, bias.to(DEV), w.to(DEV), T, B, H)
+    _check_seq_bf16_teacher_forced(h_all, c_all, gates, gx, n_gx, bias, w, T, B, H)
+
+
+@pytest.mark.parametrize("T,B,H,n_gx,block", [(6, 64, 128, 4, 0), (7, 128, 1000, 4, 3), (5, 256, 1000, 3, 0),
+                                              (9, 192, 520, 9, 4), (12, 256, 1000, 6, 5)])
+def test_persistent_bf16_recurrence(lib, T, B, H, n_gx, block):
+    """lstm_seq_fwd_bf16_persist_kernel (one launch per block of steps, W_hh slice resident per CU, cross-workgroup
+    hand-off of h_t): every step teacher-forced against fp64 math, the run repeated bit for bit (a stale hand-off is
+    timing dependent), and against the one-launch-per-step kernels."""
+    from s2vt_video_caption_amd import ops
+    gx, bias, w = _r(T * B, 4 * H, seed=21), _r(4 * H, seed=22, scale=0.3), _r(4 * H, H, seed=23, scale=H ** -0.5)
+    args = (gx.to(DEV), n_gx, bias.to(DEV), w.to(DEV), T, B, H)
+    h1, c1, g1 = ops.lstm_seq_fwd_bf16(*args, persistent=True, block=block)
+    _check_seq_bf16_teacher_forced(h1, c1, g1, gx, n_gx, bias, w, T, B, H)
+    h2, c2, g2 = ops.lstm_seq_fwd_bf16(*args, persistent=True, block=block)
+    assert torch.equal(h1, h2) and torch.equal(c1, c2) and torch.equal(g1, g2)
+    h0, c0, g0 = ops.lstm_seq_fwd_bf16(*args, persistent=False)
+    # same arithmetic, different fp32 summation order; a bf16 rounding flip of one h value moves a later pre-activation
+    # by ~|w| * 2^-9 |h|: bounded far below a structural error
+    assert (h1 - h0).abs().max().item() < 2e-3 and (c1 - c0).abs().max().item() < 2e-3
+
+
+def test_persistent_bf16_recurrence_under_load(lib):
+    """The hand-off again while another stream keeps the memory system and the other compute units busy (uneven load is
+    what exposes a missing release / acquire): result identical to the quiet run, every step teacher-forced."""
+    from s2vt_video_caption_amd import ops
+    T, B, H, n_gx = 40, 256, 1000, 20
+    gx, bias, w = _r(T * B, 4 * H, seed=31), _r(4 * H, seed=32, scale=0.3), _r(4 * H, H, seed=33, scale=H ** -0.5)
+    args = (gx.to(DEV), n_gx, bias.to(DEV), w.to(DEV), T, B, H)
+    quiet = ops.lstm_seq_fwd_bf16(*args, persistent=True, block=16)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.randn(64 * 1024 * 1024, device=DEV)
+    with torch.cuda.stream(side):
+        for _ in range(30):
+            big = big * 1.0001 + 1.0          # 512 MB of traffic per pass on the CUs the recurrence leaves free
+    loaded = ops.lstm_seq_fwd_bf16(*args, persistent=True, block=16)
+    torch.cuda.synchronize()
+    for a, b in zip(quiet, loaded):
+        assert torch.equal(a, b)
+    _check_seq_bf16_teacher_forced(*loaded, gx, n_gx, bias, w, T, B, H)

@@ -1,0 +1,34 @@
+"""Time the bf16 layer forward: one launch per timestep vs the persistent kernel (tools, GPU box)."""
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+import s2vt_video_caption_amd  # noqa
+from s2vt_video_caption_amd import build, capi, ops
+
+build.build()
+capi.load()
+DEV = "cuda:0"
+T, H = 159, 1000
+for B in (256, 128, 64):
+    g = torch.Generator().manual_seed(1)
+    gx = torch.randn(T * B, 4 * H, generator=g).to(DEV)
+    bias = (torch.randn(4 * H, generator=g) * 0.3).to(DEV)
+    w = (torch.randn(4 * H, H, generator=g) * H ** -0.5).to(DEV)
+    for persistent, block in ((False, 0), (True, 0), (True, 32)):
+        lib = capi.load()
+        for rep in range(3):
+            lib.s2vt_prof_reset()
+            lib.s2vt_prof_enable(1)
+            ops.lstm_seq_fwd_bf16(gx, 80, bias, w, T, B, H, persistent=persistent, block=block)
+            torch.cuda.synchronize()
+            lib.s2vt_prof_enable(0)
+            ms, n = capi.prof_read(1)
+            dt = ms * 1e-3
+        # bytes of the SURVEY 8(d) accounting for a vid-shaped layer (I = H, bf16 operands, train)
+        s = 2
+        by = s * 4 * H * 2 * H + 4 * 8 * H + s * B * 2 * H + 4 * B * H + s * B * H + 4 * B * H + s * B * 4 * H
+        print("B=%d persistent=%s block=%d: %.3f ms per layer pass (HIP events), %.2f us/step, %.2f TB/s (8d bytes)" %
+              (B, persistent, block, dt * 1e3, dt / T * 1e6, by / (dt / T) / 1e12), flush=True)
