@@ -96,6 +96,43 @@ def usable_cores():
     return max(1, min(n, int(os.environ.get("S2VT_CPU_THREADS", "16"))))
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: this process has not touched the GPU; it starts the N ranks as
+    CHILD processes through torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) and relays rank 0's JSON line
+    (the children inherit stdout).  Never an exec: a process that has initialised the GPU must not be replaced."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def launcher_selftest(args):
+    """CPU rehearsal of the multi-rank plumbing (tests/test_bench_launcher.py): every rank joins a gloo group, the
+    world size must equal --gpus, one all-reduce must see every rank, rank 0 prints the line."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(backend="gloo")
+    world = dist.get_world_size()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but the process group has %d ranks" % (args.gpus, world))
+    t = torch.ones(1)
+    dist.all_reduce(t)
+    if int(t.item()) != world:
+        raise SystemExit("all-reduce saw %d of %d ranks" % (int(t.item()), world))
+    if dist.get_rank() == 0:
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks": world, "backend": "gloo"}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -107,12 +144,20 @@ def main():
     ap.add_argument("--gemm-mode", type=int, default=None, choices=[0, 1, 3],
                     help="0 fp32-input MFMA, 3 split-precision bf16x3 (default, fp32-equivalent), 1 bf16 operands "
                          "(BASELINE configs[2]: use with --batch 256)")
+    ap.add_argument("--selftest-launcher", action="store_true",
+                    help="CPU-only rehearsal of the N-rank launch path (gloo); prints n_gpus")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher around us: start the N ranks ourselves (before anything touches the GPU) and exit with their code
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.selftest_launcher:
+        return launcher_selftest(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
@@ -122,6 +167,8 @@ def main():
     if use_pg:      # one process per GPU over RCCL ("nccl" backend); a 1-rank group exercises the same code path
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("--gpus %d but the RCCL group has %d ranks" % (args.gpus, dist.get_world_size()))
 
     import S2VTModel
     import utils

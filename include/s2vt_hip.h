@@ -32,7 +32,12 @@
 extern "C" {
 #endif
 
-#define S2VT_ABI_VERSION 2
+#define S2VT_ABI_VERSION 3
+
+/* negative return codes (positive ones are hipError_t values) */
+#define S2VT_ERR_ARG (-1)      /* bad argument */
+#define S2VT_ERR_INDEX (-2)    /* a target id outside [0, vocab_size): the reference raises IndexError (S2VTModel.py:71) */
+#define S2VT_ERR_TIMEOUT (-3)  /* a hand-off wait of a persistent recurrence kernel timed out */
 
 typedef struct s2vt_dims {
     int32_t B, L, F, H, E, V;
@@ -75,6 +80,13 @@ size_t s2vt_train_workspace_bytes(const s2vt_dims* d);
  *   logits  [B, L-1, V] out.  The workspace then holds what s2vt_train_backward needs. */
 int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
                        int64_t targets_ld, float* logits, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Device-side errors are asynchronous: a target id outside [0, V) (the reference's nn.Embedding raises IndexError,
+ * S2VTModel.py:71) or a timed-out hand-off of the persistent recurrence raise a flag that every s2vt_train_forward
+ * copies to the host at its end.  The NEXT s2vt_train_forward / s2vt_train_backward that finds the copy complete returns
+ * S2VT_ERR_INDEX / S2VT_ERR_TIMEOUT for it; a caller that has just synchronised the stream (loss.item()) calls this with
+ * wait = 1 and gets the error of the forward it has just run.  0 = no error (or, with wait = 0, not known yet). */
+int s2vt_check_async_error(int32_t wait);
 
 /* One depth of the batched beam search (beam.py; S2VTModel.py:205-223 for every expandable node of every sample at once):
  *   1. one zero-input vid_rnn step for the whole batch: (vid_h_in, vid_c_in) [B,H] -> (vid_h_out, vid_c_out);
@@ -193,6 +205,12 @@ size_t s2vt_lstm_seq_bf16_workspace_bytes(int32_t T, int32_t B, int32_t H);
 int s2vt_lstm_seq_fwd_bf16(int32_t T, int32_t B, int32_t H, float* gx_stash, int32_t n_gx, const float* bias,
                            const float* w_hh, float* h_all, float* c_all, void* workspace, size_t workspace_bytes,
                            int32_t persistent, int32_t block, void* stream);
+/* Two independent layers of one shape with every block of timesteps of BOTH in one persistent launch (the schedule
+ * of the whole-path driver: vid_rnn block k+1 next to word_rnn block k); workspace = 2 x the single-layer size. */
+int s2vt_lstm_seq_fwd_bf16_pair(int32_t T, int32_t B, int32_t H, float* gx_stash0, float* gx_stash1, int32_t n_gx,
+                                const float* bias0, const float* bias1, const float* w_hh0, const float* w_hh1,
+                                float* h_all0, float* h_all1, float* c_all0, float* c_all1, void* workspace,
+                                size_t workspace_bytes, int32_t block, void* stream);
 /* Recurrence schedule inside the whole-path drivers (bf16 mode): 1 = persistent kernels where the shape allows
  * (default), 0 = one launch per timestep; negative: query.  Returns the previous value. */
 int s2vt_set_recurrence_mode(int32_t persistent);

@@ -33,7 +33,7 @@ class Grads(ctypes.Structure):
 
 
 # name -> (restype, argtypes): every symbol include/s2vt_hip.h declares
-ABI_VERSION = 2          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
+ABI_VERSION = 3          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
 
 SIGNATURES = {
     "s2vt_abi_version": (c_int32, []),
@@ -41,6 +41,7 @@ SIGNATURES = {
     "s2vt_train_workspace_bytes": (c_size_t, [POINTER(Dims)]),
     "s2vt_train_forward": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
+    "s2vt_check_async_error": (c_int32, [c_int32]),
     "s2vt_train_backward": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_void_p, POINTER(Grads), c_void_p,
                                       c_void_p, c_size_t, c_void_p]),
     "s2vt_backward_wait_grads": (c_int32, [c_int32, c_void_p]),
@@ -72,6 +73,8 @@ SIGNATURES = {
     "s2vt_lstm_seq_bf16_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "s2vt_lstm_seq_fwd_bf16": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p,
                                          c_void_p, c_void_p, c_size_t, c_int32, c_int32, c_void_p]),
+    "s2vt_lstm_seq_fwd_bf16_pair": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 9 +
+                                    [c_size_t, c_int32, c_void_p]),
     "s2vt_set_recurrence_mode": (c_int32, [c_int32]),
     "s2vt_decode_step_argmax": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5),
     "s2vt_set_gemm_mode": (c_int32, [c_int32]),
@@ -117,10 +120,22 @@ def load():
     return lib
 
 
+ERR_INDEX, ERR_TIMEOUT = -2, -3      # S2VT_ERR_INDEX / S2VT_ERR_TIMEOUT of include/s2vt_hip.h
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().s2vt_last_error()
-        raise S2VTHipError("%s failed (rc=%d): %s" % (what, rc, msg.decode(errors="replace") if msg else "?"))
+        text = "%s failed (rc=%d): %s" % (what, rc, msg.decode(errors="replace") if msg else "?")
+        if rc == ERR_INDEX:
+            raise IndexError(text)           # what nn.Embedding raises in the reference (S2VTModel.py:71)
+        raise S2VTHipError(text)
+
+
+def check_async_error(wait=True):
+    """Raise the device-side error (target id out of range -> IndexError, hand-off time-out) of the last
+    s2vt_train_forward, if any.  Call after a stream synchronisation (loss.item()) to get it without delay."""
+    check(load().s2vt_check_async_error(1 if wait else 0), "s2vt_check_async_error")
 
 
 def prof_read(kind):

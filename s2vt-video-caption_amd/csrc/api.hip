@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <map>
 #include <vector>
 
 #include "../../include/s2vt_hip.h"
@@ -26,6 +27,55 @@ int check_hip(hipError_t e, const char* what) {
     if (e == hipSuccess) return 0;
     set_error("%s: %s", what, hipGetErrorString(e));
     return (int)e;
+}
+
+// ------------------------------------------------------------------ asynchronous device-side errors
+// Kernels cannot return an error code: they raise a flag in the workspace (err[0]: a target id outside [0, V), which
+// nn.Embedding / CrossEntropyLoss reject with IndexError in the reference, S2VTModel.py:71; err[1]: a hand-off wait of
+// the persistent recurrence timed out).  Every s2vt_train_forward ends with a 16-byte copy of the flags into a pinned
+// host word block + an event; the NEXT entry on this process (forward, backward or s2vt_check_async_error) that finds the
+// event complete reports the error.  One step late by construction, never silent; callers that synchronise anyway
+// (loss.item()) call s2vt_check_async_error(1) right there and get it immediately.
+static int* g_err_host = nullptr;
+static hipEvent_t g_err_ev = nullptr;
+static bool g_err_pending = false;
+static int poll_async_error(bool wait) {
+    if (!g_err_pending) return 0;
+    if (wait) {
+        S2VT_HIP(hipEventSynchronize(g_err_ev));
+    } else {
+        const hipError_t q = hipEventQuery(g_err_ev);
+        if (q == hipErrorNotReady) return 0;
+        S2VT_HIP(q);
+    }
+    g_err_pending = false;
+    const int bad_target = g_err_host[0], timed_out = g_err_host[1];
+    g_err_host[0] = g_err_host[1] = 0;
+    if (bad_target) {
+        set_error("index out of range: a target id of the previous s2vt_train_forward lies outside [0, vocab_size) "
+                  "(the reference raises IndexError in nn.Embedding, S2VTModel.py:71)");
+        return S2VT_ERR_INDEX;
+    }
+    if (timed_out) {
+        set_error("persistent recurrence kernel: a hand-off wait timed out (its workgroups were not co-resident)");
+        return S2VT_ERR_TIMEOUT;
+    }
+    return 0;
+}
+static int post_async_error(hipStream_t st, const int* dev_flags) {
+    if (!g_err_host) {
+        S2VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&g_err_host), 4 * sizeof(int), hipHostMallocDefault));
+        g_err_host[0] = g_err_host[1] = g_err_host[2] = g_err_host[3] = 0;
+        S2VT_HIP(hipEventCreateWithFlags(&g_err_ev, hipEventDisableTiming));
+    }
+    if (g_err_pending) {       // an unread record: it must not be overwritten (a step without any later entry)
+        int rc = poll_async_error(true);
+        if (rc) return rc;
+    }
+    S2VT_HIP(hipMemcpyAsync(g_err_host, dev_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    S2VT_HIP(hipEventRecord(g_err_ev, st));
+    g_err_pending = true;
+    return 0;
 }
 
 // ------------------------------------------------------------------ live kernel timing
@@ -482,6 +532,29 @@ static int seq_fwd_bf16_any(hipStream_t st, int t0, int t1, int B, int H, float*
     return lstm_seq_fwd_bf16_persist(st, a);
 }
 
+// What a forward was run with, keyed by its workspace: s2vt_train_backward must find the same arithmetic mode and
+// recurrence schedule (they decide how the workspace is carved and which images the forward left in it), otherwise it
+// refuses instead of reading a differently carved workspace.  Host-side only.
+struct FwdRecord { s2vt_dims d; int gemm_mode, planes, persist; };
+static std::map<const void*, FwdRecord> g_fwd_records;
+static void record_forward(const void* ws, const s2vt_dims& d, bool planes) {
+    if (g_fwd_records.size() >= 64) g_fwd_records.erase(g_fwd_records.begin());     // forwards that never ran a backward
+    g_fwd_records[ws] = FwdRecord{d, gemm_mode(), planes ? ((gemm_mode() == 1) ? 1 : 3) : 0, persist_on() ? 1 : 0};
+}
+static int check_forward_record(const void* ws, const s2vt_dims& d, bool planes) {
+    auto it = g_fwd_records.find(ws);
+    S2VT_REQUIRE(it != g_fwd_records.end(), "s2vt_train_backward: no s2vt_train_forward has run on this workspace");
+    const FwdRecord r = it->second;
+    g_fwd_records.erase(it);
+    S2VT_REQUIRE(memcmp(&r.d, &d, sizeof(d)) == 0, "s2vt_train_backward: dims differ from the forward that filled this workspace");
+    const int planes_now = planes ? ((gemm_mode() == 1) ? 1 : 3) : 0;
+    S2VT_REQUIRE(r.gemm_mode == gemm_mode() && r.planes == planes_now && r.persist == (persist_on() ? 1 : 0),
+                 "s2vt_train_backward: the forward ran with gemm mode %d / recurrence mode %d, now %d / %d: the workspace "
+                 "layout differs (do not change s2vt_set_gemm_mode / s2vt_set_recurrence_mode between a forward and its backward)",
+                 r.gemm_mode, r.persist, gemm_mode(), persist_on() ? 1 : 0);
+    return 0;
+}
+
 // ---- argument builders for single timesteps (used by the paired-launch schedule)
 static StepFwdArgs fwd_args(int t, int B, int H, float* gx_stash, int n_gx, const float* bias, const float* w_hh,
                             float* h_all, float* c_all) {
@@ -763,8 +836,10 @@ size_t s2vt_train_workspace_bytes(const s2vt_dims* d) {
     if (!dims_ok(d)) return 0;
     size_t n = carve_train(*d, nullptr).bytes;
     if (planes_ok(*d)) {
+        const int keep = XP;                       // a size query must not change the state of a running path
         XP = (gemm_mode() == 1) ? 1 : 3;
         n += carve_planes(*d, nullptr).bytes;
+        XP = keep;
     }
     return n;
 }
@@ -775,12 +850,18 @@ int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* fe
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
+    {   // a device-side error of the previous forward, if its flags have arrived
+        int rc0 = poll_async_error(false);
+        if (rc0) return rc0;
+    }
+    record_forward(workspace, *d, planes_ok(*d));
     if (planes_ok(*d)) {
         XP = (gemm_mode() == 1) ? 1 : 3;
         const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
         S2VT_REQUIRE(workspace_bytes >= w.bytes + q.bytes, "s2vt_train_forward: workspace %zu < %zu bytes",
                      workspace_bytes, w.bytes + q.bytes);
-        return train_forward_x3(d, p, feats, targets, targets_ld, logits, w, q, st);
+        int rc0 = train_forward_x3(d, p, feats, targets, targets_ld, logits, w, q, st);
+        return rc0 ? rc0 : post_async_error(st, w.err);
     }
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
@@ -823,8 +904,11 @@ int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* fe
     if ((rc = lgemm(lb, true, true, (L - 1) * B, V, H, w.h2 + L * BH, H, ID, p->out_w, H, ID, logits, V, perm(B, L - 1),
                     p->out_b, false)))
         return rc;
-    return handoff(sx, st, ev++);
+    if ((rc = handoff(sx, st, ev++))) return rc;
+    return post_async_error(st, w.err);
 }
+
+int s2vt_check_async_error(int32_t wait) { return poll_async_error(wait != 0); }
 
 int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
                         const s2vt_grads* g, float* dfeats, void* workspace, size_t workspace_bytes, void* stream) {
@@ -832,6 +916,11 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
+    {
+        int rc0 = poll_async_error(false);          // flags of the forward, if they have arrived already
+        if (rc0) return rc0;
+        if ((rc0 = check_forward_record(workspace, *d, planes_ok(*d)))) return rc0;
+    }
     if (planes_ok(*d)) {
         XP = (gemm_mode() == 1) ? 1 : 3;
         const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
@@ -1290,6 +1379,29 @@ size_t s2vt_lstm_seq_bf16_workspace_bytes(int32_t T, int32_t B, int32_t H) {
     if (T <= 0 || B <= 0 || H <= 0) return 0;
     return carve_seq_bf16(T, B, H, nullptr).bytes;
 }
+static int seq_bf16_prepare(hipStream_t st, const SeqBf16WS& w, int T, int B, int H, const float* w_hh) {
+    int rc;
+    if ((rc = fill_zero(st, w.err, 64 * sizeof(int)))) return rc;
+    if ((rc = split_planes(st, 1, false, w_hh, H, ID, 4 * H, H, w.wb.p, w.wb.ld, w.wb.kpad, (int)rows64((size_t)4 * H)))) return rc;
+    return zero_pad_cols_u16(st, w.hb.p, (int64_t)T * B, w.hb.ld, H, w.hb.kpad);
+}
+static SeqFwdBf16Args seq_bf16_args(const SeqBf16WS& w, int B, int H, int t0, int t1, float* gx_stash, int n_gx,
+                                    const float* bias, float* h_all, float* c_all) {
+    SeqFwdBf16Args a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.H = H; a.Kp = w.hb.kpad;
+    a.t0 = t0; a.t1 = t1; a.n_gx = n_gx;
+    a.wb = w.wb.p; a.ldwb = w.wb.ld;
+    a.hb = w.hb.p; a.ldhb = w.hb.ld;
+    a.gx_stash = gx_stash; a.bias = bias;
+    a.h_all = h_all; a.c_all = c_all;
+    a.sync = w.sync; a.err = w.err;
+#ifdef S2VT_EXPERIMENT_STAMPS
+    a.stamps = g_xstamps; a.stamp_block = g_xstamp_block;
+#endif
+    return a;
+}
+
 int s2vt_lstm_seq_fwd_bf16(int32_t T, int32_t B, int32_t H, float* gx_stash, int32_t n_gx, const float* bias,
                            const float* w_hh, float* h_all, float* c_all, void* workspace, size_t workspace_bytes,
                            int32_t persistent, int32_t block, void* stream) {
@@ -1300,27 +1412,44 @@ int s2vt_lstm_seq_fwd_bf16(int32_t T, int32_t B, int32_t H, float* gx_stash, int
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_lstm_seq_fwd_bf16: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if ((rc = fill_zero(st, w.err, 64 * sizeof(int)))) return rc;
-    if ((rc = split_planes(st, 1, false, w_hh, H, ID, 4 * H, H, w.wb.p, w.wb.ld, w.wb.kpad, (int)rows64((size_t)4 * H)))) return rc;
-    if ((rc = zero_pad_cols_u16(st, w.hb.p, (int64_t)T * B, w.hb.ld, H, w.hb.kpad))) return rc;
+    if ((rc = seq_bf16_prepare(st, w, T, B, H, w_hh))) return rc;
     if (!persistent) return seq_fwd_bf16(st, 0, T, B, H, gx_stash, n_gx, bias, w.wb, w.hb, h_all, c_all);
     S2VT_REQUIRE(lstm_seq_fwd_bf16_persist_supported(B, H, w.hb.kpad), "s2vt_lstm_seq_fwd_bf16: shape not supported by the persistent kernel");
     const int blk = block > 0 ? block : T;
     for (int t0 = 0; t0 < T; t0 += blk) {
-        SeqFwdBf16Args a;
-        memset(&a, 0, sizeof(a));
-        a.B = B; a.H = H; a.Kp = w.hb.kpad;
-        a.t0 = t0; a.t1 = (t0 + blk < T) ? t0 + blk : T; a.n_gx = n_gx;
-        a.wb = w.wb.p; a.ldwb = w.wb.ld;
-        a.hb = w.hb.p; a.ldhb = w.hb.ld;
-        a.gx_stash = gx_stash; a.bias = bias;
-        a.h_all = h_all; a.c_all = c_all;
-        a.sync = w.sync; a.err = w.err;
-#ifdef S2VT_EXPERIMENT_STAMPS
-        a.stamps = g_xstamps; a.stamp_block = g_xstamp_block;
-#endif
-        ProfScope ps(st, K_STEP_FWD, a.t1 - a.t0);
-        if ((rc = lstm_seq_fwd_bf16_persist(st, a))) return rc;
+        const int t1 = (t0 + blk < T) ? t0 + blk : T;
+        ProfScope ps(st, K_STEP_FWD, t1 - t0);
+        if ((rc = lstm_seq_fwd_bf16_persist(st, seq_bf16_args(w, B, H, t0, t1, gx_stash, n_gx, bias, h_all, c_all)))) return rc;
+    }
+    return 0;
+}
+
+// Two independent layers of the same shape, every block of timesteps of both in ONE persistent launch (the schedule the
+// whole-path driver uses for vid_rnn block k+1 next to word_rnn block k); workspace = 2 x the single-layer size.
+int s2vt_lstm_seq_fwd_bf16_pair(int32_t T, int32_t B, int32_t H, float* gx_stash0, float* gx_stash1, int32_t n_gx,
+                                const float* bias0, const float* bias1, const float* w_hh0, const float* w_hh1,
+                                float* h_all0, float* h_all1, float* c_all0, float* c_all1, void* workspace,
+                                size_t workspace_bytes, int32_t block, void* stream) {
+    S2VT_REQUIRE(T > 0 && B > 0 && H > 0 && gx_stash0 && gx_stash1 && w_hh0 && w_hh1 && h_all0 && h_all1 && c_all0 && c_all1 &&
+                     workspace && n_gx >= 0 && n_gx <= T && (n_gx == T || (bias0 && bias1)),
+                 "s2vt_lstm_seq_fwd_bf16_pair: bad arguments");
+    const size_t one = carve_seq_bf16(T, B, H, nullptr).bytes;
+    S2VT_REQUIRE(workspace_bytes >= 2 * one, "s2vt_lstm_seq_fwd_bf16_pair: workspace %zu < %zu bytes", workspace_bytes, 2 * one);
+    const SeqBf16WS w0 = carve_seq_bf16(T, B, H, workspace);
+    const SeqBf16WS w1 = carve_seq_bf16(T, B, H, reinterpret_cast<char*>(workspace) + one);
+    S2VT_REQUIRE(lstm_seq_fwd_bf16_persist_supported(B, H, w0.hb.kpad), "s2vt_lstm_seq_fwd_bf16_pair: shape not supported by the persistent kernel");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = seq_bf16_prepare(st, w0, T, B, H, w_hh0))) return rc;
+    if ((rc = seq_bf16_prepare(st, w1, T, B, H, w_hh1))) return rc;
+    const int blk = block > 0 ? block : T;
+    for (int t0 = 0; t0 < T; t0 += blk) {
+        const int t1 = (t0 + blk < T) ? t0 + blk : T;
+        ProfScope ps(st, K_STEP_FWD, 2 * (t1 - t0));
+        SeqFwdBf16Args a1 = seq_bf16_args(w1, B, H, t0, t1, gx_stash1, n_gx, bias1, h_all1, c_all1);
+        a1.err = w0.err;
+        if ((rc = lstm_seq_fwd_bf16_persist2(st, seq_bf16_args(w0, B, H, t0, t1, gx_stash0, n_gx, bias0, h_all0, c_all0), &a1)))
+            return rc;
     }
     return 0;
 }

@@ -112,12 +112,14 @@ struct SeqFwdBf16Args {
     float* c_all;                                   // [T*B][H] fp32 c_t
     unsigned int* sync;                             // lstm_persist_sync_bytes() of counters (zeroed by the launcher)
     int* err;                                       // set to 1 if a hand-off wait timed out
-    int RB, NS;                                     // set by the launcher: rows per workgroup, 64-row sub-chains
+    int RB, NS;                                     // set by the launcher: rows per workgroup, 32-row chains in it
     unsigned long long* stamps; int stamp_block;    // timing experiments only (experiment.h); null in the product
 };
 int lstm_seq_fwd_bf16_persist_supported(int B, int H, int Kp);
 size_t lstm_persist_sync_bytes();
 int lstm_seq_fwd_bf16_persist(hipStream_t stream, SeqFwdBf16Args a);
+// two layers (e.g. vid_rnn block k+1 and word_rnn block k) side by side in ONE launch; b == nullptr: one layer
+int lstm_seq_fwd_bf16_persist2(hipStream_t stream, SeqFwdBf16Args a, const SeqFwdBf16Args* b);
 
 struct LogitsArgmaxArgs {
     int B, H, V;

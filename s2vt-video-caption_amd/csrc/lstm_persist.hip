@@ -1,5 +1,6 @@
 // Persistent bf16 LSTM recurrence for gfx950 (BASELINE config 3: B = 256, bf16 operands, fp32 accumulate):
-// ONE launch runs a whole block of timesteps of one layer (S2VTModel.py:67 / :77 -> nn.LSTM over the steps).
+// ONE launch runs a whole block of timesteps of one layer - or of both layers side by side - instead of one launch
+// per timestep (S2VTModel.py:67 / :77 -> nn.LSTM over the steps).
 //
 // Why: a one-launch-per-timestep kernel re-fetches W_hh (8 MB bf16) through the fabric on every step, because the
 // per-XCD L2s do not survive a kernel boundary, and pays launch + prologue + epilogue serially 159 times per layer.
@@ -7,27 +8,31 @@
 // h_{t-1} (512 KB at B = 256).
 //
 // Decomposition.  Workgroup (rg, cs) owns batch rows [rg*RB, rg*RB+RB) and hidden units [16 cs, 16 cs + 16), i.e. the
-// 64 gate columns {i,f,g,o} x 16 units: complete cells.  Its 8 waves are (kw, rw, cw): k half, 32-row half of the
-// 64-row sub-step, 8-unit half; each wave holds W[its 32 gate columns][its k half] as MFMA B operands in 128 VGPRs
-// (v_mfma_f32_32x32x16_bf16; B operand of lane (n, kh) = 8 consecutive k of column n).  The RB rows are cut into
-// sub-chains of 64 rows that are independent recurrences; the workgroup works on them round-robin, so the hand-off
-// latency of one chain is hidden behind the arithmetic of the other.
+// 64 gate columns {i,f,g,o} x 16 units: complete cells.  Its 4 waves are (kw, cw): k half and 8-unit half; each wave
+// holds W[its 32 gate columns][its k half] as MFMA B operands in 128 VGPRs (v_mfma_f32_32x32x16_bf16; B operand of lane
+// (n, kh) = 8 consecutive k of column n).  A workgroup needs 74 KB of LDS and 4 waves: TWO of them share a compute unit,
+// and each hides the other's hand-off latencies (measured on the first version, one 8-wave workgroup per CU: of a
+// 5.9-us sub-step 2.0 us were the h_{t-1} transfer, 1.4 us the signal round trip; per-CU ingest from L2 is ~65 GB/s).
+// With two layer argument sets in one launch the grid is [layer A workgroups | layer B workgroups]: vid_rnn block k+1
+// and word_rnn block k of the layer pipeline run side by side with no second stream.
 //
-// One sub-step (64 rows x 64 gate columns x Kp):
-//   1. wait until all column slices of the row group have published h_{t-1} of this chain (one counter per chain,
-//      one lane polls, bounded spin);
-//   2. LDS-DMA the chain's h_{t-1} rows (64 x Kp bf16, <= 128 KB) into LDS: one global_load_lds_dwordx4 per 8 rows x
+// One sub-step (32 rows x 64 gate columns x Kp) of a workgroup:
+//   1. wait until all column slices of the row group have published h_{t-1} (one counter per 32-row chain, one lane
+//      polls, bounded spin);
+//   2. LDS-DMA the chain's h_{t-1} rows (32 x Kp bf16, <= 64 KB) into LDS: one global_load_lds_dwordx4 per 8 rows x
 //      128 B, XOR-swizzled through the per-lane SOURCE address (position q of row r holds piece q ^ ((r>>1)&7)) so the
 //      A-fragment ds_read_b128 are conflict-free; all requests are issued up front and consumed k chunk by k chunk
 //      behind counted vmcnt waits;
-//   3. 32 MFMAs per wave (A from LDS, B from registers), the two k halves are summed through LDS;
-//   4. cell epilogue (2 cells per thread, c_t stays in LDS between steps): activated gates -> stash, c_t, h_t
-//      (fp32) as plain stores, bf16 h_t tile through LDS as 8-byte WRITE-THROUGH (sc1) stores;
-//   5. every wave drains its stores (vmcnt(0)), workgroup barrier, one lane adds 1 to the chain's counter (agent scope).
-// Hand-off correctness (cdna guide, Guideline 16): payload stored sc1 and drained before the counter add; the consumer
-// polls with an sc1 load, then a workgroup barrier, then loads.  h_t of every step has its own address (time-major
-// h image), so no CU ever holds an older copy of a line it is about to read; the LDS-DMA loads carry sc1 as well.
-// Every spin is bounded (1 s of wall clock): on a time-out the workgroup sets *err and exits.
+//   3. 32 MFMAs per wave (A from LDS, B from registers); the two k halves are summed through LDS;
+//   4. cell epilogue (2 adjacent units per thread, c_t stays in LDS between steps): activated gates -> stash, c_t, h_t
+//      (fp32) as plain 8-byte stores; the bf16 h_t tile (32 rows x 32 B) goes through LDS and leaves as ONE 16-byte
+//      write-through (sc1) store instruction of wave 0;
+//   5. wave 0 drains its stores (vmcnt(0)) and one lane adds 1 to the chain's counter (agent scope).
+// Hand-off correctness (cdna guide, Guideline 16): payload stored sc1 by ONE wave and drained before that wave's
+// counter add; the consumer polls with an sc1 load, then a workgroup barrier, then loads.  h_t of every step has its
+// own address (time-major h image), so no CU ever holds an older copy of a line it is about to read; the LDS-DMA loads
+// carry sc1 as well.  Every spin is bounded (1 s of wall clock): on a time-out the workgroup sets *err and exits.
+// All workgroups of a launch must be co-resident (2 per CU): the launcher refuses grids above 2 x 252.
 #include "common.h"
 #include "experiment.h"
 #include "kernels.h"
@@ -35,20 +40,21 @@
 namespace s2vt {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) unsigned int gu32;
-typedef __attribute__((address_space(1))) unsigned long long gu64;
 
-constexpr int P_SR = 64;                          // batch rows per sub-step
+constexpr int P_SR = 32;                          // batch rows per sub-step (= per chain)
 constexpr int P_UN = 16;                          // hidden units per workgroup (64 gate columns)
-constexpr int P_NT = 512;                         // 8 waves
+constexpr int P_NT = 256;                         // 4 waves
 constexpr int P_KCH = 16;                         // k chunks of 64 (Kp <= 1024)
-constexpr int P_SLAB = P_KCH * P_SR * 128;        // h_{t-1} image: 128 KB
+constexpr int P_SLAB = P_KCH * P_SR * 128;        // h_{t-1} image: 64 KB
 constexpr int P_RLD = 68;                         // row stride of the partial-sum image (floats)
-constexpr int P_HSM = P_SLAB;                     // bf16 h_t tile [64][16]
+constexpr int P_HSM = P_SLAB;                     // bf16 h_t tile [32][16]
 constexpr int P_MAXNS = 4;
-constexpr int P_CST = P_SLAB + P_SR * P_UN * 2;                // fp32 c_t of the workgroup's cells, per chain [64][16]
+constexpr int P_CST = P_HSM + P_SR * P_UN * 2;    // fp32 c_t of the workgroup's cells, per chain [32][16]
 constexpr int P_LDS = P_CST + P_MAXNS * P_SR * P_UN * 4;
+constexpr int P_MAX_WG = 504;                     // 2 workgroups on each of 252 CUs
 constexpr unsigned long long P_SPIN_TICKS = 100000000ull;      // 1 s of the 100-MHz wall clock
 
 __device__ __forceinline__ unsigned short f2bf_rn(float x) {
@@ -57,6 +63,11 @@ __device__ __forceinline__ unsigned short f2bf_rn(float x) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
+
+// sigmoid / tanh on the hardware exp and reciprocal (1 ulp each): absolute error ~2e-7, far below the bf16 rounding of
+// the operands this kernel works on
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
 __device__ __forceinline__ void glds16_sc1(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -80,16 +91,14 @@ __device__ __forceinline__ bool spin_until(const unsigned int* cnt, unsigned int
 
 // FULL: Kp == 1024 (16 k chunks: the config-3 shape), counted vmcnt pipeline; otherwise every request is awaited first
 template <bool FULL>
-__global__ __launch_bounds__(P_NT) void lstm_seq_fwd_bf16_persist_kernel(SeqFwdBf16Args p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_LDS];
-    __shared__ int s_flag;                 // poll result of the polling lane
+__device__ __forceinline__ void seq_fwd_body(const SeqFwdBf16Args& p, const int bid, unsigned char* smem, int& s_flag) {
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int kw = wave >> 2, rw = (wave >> 1) & 1, cw = wave & 1;
+    const int kw = wave >> 1, cw = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int H = p.H, B = p.B;
     const int nC = (H + P_UN - 1) / P_UN;
-    const int cs = blockIdx.x % nC, rg = blockIdx.x / nC;
+    const int cs = bid % nC, rg = bid / nC;
     const int u0 = cs * P_UN, row0 = rg * p.RB;
     const int nch = FULL ? P_KCH : (p.Kp >> 6), half = FULL ? P_KCH / 2 : ((nch + 1) >> 1);
     const int cbeg = kw * half, cend = (cbeg + half < nch) ? cbeg + half : nch;
@@ -114,31 +123,33 @@ __global__ __launch_bounds__(P_NT) void lstm_seq_fwd_bf16_persist_kernel(SeqFwdB
         for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wreg[i]));
     }
 
-    // ---- loader role: wave w moves rows 8w..8w+7 of the 64 of every k chunk
+    // ---- loader role: wave w moves rows 8w..8w+7 of the 32 of every k chunk (chunk image: 32 rows x 128 B = 4 KB)
     const int lrow = wave * 8 + (lane >> 3);
     const int lpiece = (lane & 7) ^ ((lrow >> 1) & 7);
-    // ---- A-fragment read address of lane (row li of this wave's 32, k half lh): piece 2s+lh of a chunk
-    const int arow = rw * 32 + li;
+    // ---- A-fragment read address of lane (row li, k half lh): piece 2s+lh of a chunk
     unsigned fa[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
-        fa[s] = lbase + (unsigned)(cbeg * 8192 + arow * 128 + (((2 * s + lh) ^ ((arow >> 1) & 7)) * 16));
+        fa[s] = lbase + (unsigned)(cbeg * 4096 + li * 128 + (((2 * s + lh) ^ ((li >> 1) & 7)) * 16));
 
-    // ---- epilogue role: 2 cells per thread, the same (row, unit) in every step
-    const int erow = tid >> 4, eul = tid & 15;         // rows erow, erow + 32
+    // ---- epilogue role: 2 adjacent units of one row per thread, the same (row, units) in every step
+    const int erow = tid >> 3, eul = (tid & 7) * 2;
     const int eunit = u0 + eul;
-    const bool eu_ok = eunit < H;
+    const bool e_ok0 = eunit < H, e_ok1 = eunit + 1 < H;
+    const bool e_vec = e_ok1 && ((H & 1) == 0);        // 8-byte accesses: both units valid and rows 8-byte aligned
     const int ecol = (eul >> 3) * 32 + (eul & 7);      // + g*8: column of gate g inside the workgroup's 64
     // c_t of this thread's cells lives in LDS between steps (only this thread touches its entries)
     float* cst = reinterpret_cast<float*>(smem + P_CST);
-    for (int s = 0; s < p.NS; ++s)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int b = row0 + s * P_SR + erow + 32 * e;
-            float c0 = 0.f;
-            if (p.t0 > 0 && eu_ok && b < B) c0 = p.c_all[((int64_t)(p.t0 - 1) * B + b) * H + eunit];
-            cst[(s * P_SR + erow + 32 * e) * P_UN + eul] = c0;
+    for (int s = 0; s < p.NS; ++s) {
+        const int b = row0 + s * P_SR + erow;
+        f32x2 c0 = {0.f, 0.f};
+        if (p.t0 > 0 && b < B) {
+            const float* q = p.c_all + ((int64_t)(p.t0 - 1) * B + b) * H + eunit;
+            if (e_ok0) c0[0] = q[0];
+            if (e_ok1) c0[1] = q[1];
         }
+        *reinterpret_cast<f32x2*>(cst + (s * P_SR + erow) * P_UN + eul) = c0;
+    }
 
     float* red = reinterpret_cast<float*>(smem);
     unsigned short* hsm = reinterpret_cast<unsigned short*>(smem + P_HSM);
@@ -148,9 +159,9 @@ __global__ __launch_bounds__(P_NT) void lstm_seq_fwd_bf16_persist_kernel(SeqFwdB
 #pragma unroll 1
         for (int s = 0; s < p.NS; ++s) {
             const int rbase = row0 + s * P_SR;            // first batch row of this sub-step
-            const int xrec = (blockIdx.x == p.stamp_block) ? (t - p.t0) * p.NS + s : -1;
-            XSTAMP(p.stamps, xrec, 0);
             unsigned int* cnt = p.sync + (rg * P_MAXNS + s) * 32;
+            const int xrec = (bid == p.stamp_block) ? (t - p.t0) * p.NS + s : -1;
+            XSTAMP(p.stamps, xrec, 0);
 
             if (t > p.t0) {          // h_{t-1} of this chain published by every column slice of the row group?
                 if (tid == 0) {
@@ -164,19 +175,19 @@ __global__ __launch_bounds__(P_NT) void lstm_seq_fwd_bf16_persist_kernel(SeqFwdB
             XSTAMP(p.stamps, xrec, 1);
 
             // epilogue operands requested now, consumed after the contraction
-            float gxv[2][4];
+            const int eb = rbase + erow;
+            const bool rok = eb < B;
+            f32x2 gxv[4];
             {
-                const float* gsrc = (t < p.n_gx) ? p.gx_stash + (int64_t)t * B * H4 : nullptr;
+                const float* gsrc = (t < p.n_gx) ? p.gx_stash + ((int64_t)t * B + eb) * H4 : p.bias;
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int b = rbase + erow + 32 * e;
-                    const bool ok = eu_ok && b < B;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float* q = !ok ? g_zero4
-                                             : (gsrc ? gsrc + (int64_t)b * H4 + (int64_t)g * H + eunit
-                                                     : p.bias + (int64_t)g * H + eunit);
-                        gxv[e][g] = *q;
+                for (int g = 0; g < 4; ++g) {
+                    const float* q = gsrc + (int64_t)g * H + eunit;
+                    if (e_vec) {
+                        gxv[g] = *reinterpret_cast<const f32x2*>(rok ? q : g_zero4);
+                    } else {
+                        gxv[g][0] = *((rok && e_ok0) ? q : g_zero4);
+                        gxv[g][1] = *((rok && e_ok1) ? q + 1 : g_zero4);
                     }
                 }
             }
@@ -186,14 +197,14 @@ __global__ __launch_bounds__(P_NT) void lstm_seq_fwd_bf16_persist_kernel(SeqFwdB
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
             if (t > 0) {
-                // h_{t-1} rows of this chain -> LDS (chunk c at c*8 KB; this wave's piece at + wave*1 KB)
+                // h_{t-1} rows of this chain -> LDS (chunk c at c*4 KB; this wave's piece at + wave*1 KB)
                 const unsigned char* src = reinterpret_cast<const unsigned char*>(
                                                p.hb + ((int64_t)(t - 1) * B + rbase + lrow) * p.ldhb) + lpiece * 16;
                 unsigned char* ldst = smem + wave * 1024;
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
-                    if (FULL || i < half) glds16_sc1(src + i * 128, ldst + i * 8192);
-                    if (FULL || half + i < nch) glds16_sc1(src + (half + i) * 128, ldst + (half + i) * 8192);
+                    if (FULL || i < half) glds16_sc1(src + i * 128, ldst + i * 4096);
+                    if (FULL || half + i < nch) glds16_sc1(src + (half + i) * 128, ldst + (half + i) * 4096);
                 }
                 if (!FULL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 XSTAMP(p.stamps, xrec, 2);
@@ -204,8 +215,8 @@ __global__ __launch_bounds__(P_NT) void lstm_seq_fwd_bf16_persist_kernel(SeqFwdB
                     asm volatile("s_barrier" ::: "memory");                                                        \
                     if (FULL || cbeg + (I) < cend) {                                                               \
                         bf16x8 a0, a1, a2, a3;                                                                     \
-                        P_DSR(a0, fa[0], (I) * 8192); P_DSR(a1, fa[1], (I) * 8192);                                \
-                        P_DSR(a2, fa[2], (I) * 8192); P_DSR(a3, fa[3], (I) * 8192);                                \
+                        P_DSR(a0, fa[0], (I) * 4096); P_DSR(a1, fa[1], (I) * 4096);                                \
+                        P_DSR(a2, fa[2], (I) * 4096); P_DSR(a3, fa[3], (I) * 4096);                                \
                         asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a0));                                           \
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, wreg[(I) * 4 + 0], acc, 0, 0, 0);        \
                         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a1));                                           \
@@ -229,90 +240,129 @@ __global__ __launch_bounds__(P_NT) void lstm_seq_fwd_bf16_persist_kernel(SeqFwdB
                 float* rp = red + (kw * P_SR) * P_RLD;
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    rp[(rw * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * P_RLD + cw * 32 + li] = acc[r];
+                    rp[((r & 3) + 8 * (r >> 2) + 4 * lh) * P_RLD + cw * 32 + li] = acc[r];
             }
             P_BARRIER();
             XSTAMP(p.stamps, xrec, 5);
 
-            float gate[2][4], cv[2], hv[2];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int rl = erow + 32 * e, b = rbase + rl;
-                float pre[4];
+            f32x2 gate[4], cv, hv;
+            {
+                f32x2 pre[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    pre[g] = red[rl * P_RLD + ecol + g * 8] + red[(P_SR + rl) * P_RLD + ecol + g * 8] + gxv[e][g];
-                gate[e][0] = 1.0f / (1.0f + expf(-pre[0]));
-                gate[e][1] = 1.0f / (1.0f + expf(-pre[1]));
-                gate[e][2] = tanhf(pre[2]);
-                gate[e][3] = 1.0f / (1.0f + expf(-pre[3]));
-                float* cp = cst + (s * P_SR + rl) * P_UN + eul;
-                const bool ok = eu_ok && b < B;
-                cv[e] = ok ? gate[e][1] * *cp + gate[e][0] * gate[e][2] : 0.f;
-                hv[e] = gate[e][3] * tanhf(cv[e]);
-                *cp = cv[e];
-                hsm[rl * P_UN + eul] = ok ? f2bf_rn(hv[e]) : (unsigned short)0;
+                    pre[g] = *reinterpret_cast<const f32x2*>(red + erow * P_RLD + ecol + g * 8) +
+                             *reinterpret_cast<const f32x2*>(red + (P_SR + erow) * P_RLD + ecol + g * 8) + gxv[g];
+                f32x2* cp = reinterpret_cast<f32x2*>(cst + (s * P_SR + erow) * P_UN + eul);
+                const f32x2 cprev = *cp;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    gate[0][j] = fast_sigmoid(pre[0][j]);
+                    gate[1][j] = fast_sigmoid(pre[1][j]);
+                    gate[2][j] = fast_tanh(pre[2][j]);
+                    gate[3][j] = fast_sigmoid(pre[3][j]);
+                    const bool ok = rok && (j ? e_ok1 : e_ok0);
+                    cv[j] = ok ? gate[1][j] * cprev[j] + gate[0][j] * gate[2][j] : 0.f;
+                    hv[j] = gate[3][j] * fast_tanh(cv[j]);
+                }
+                *cp = cv;
+                *reinterpret_cast<unsigned int*>(hsm + erow * P_UN + eul) =
+                    (unsigned int)f2bf_rn(hv[0]) | ((unsigned int)f2bf_rn(hv[1]) << 16);
             }
             XSTAMP(p.stamps, xrec, 6);
             P_BARRIER();
-            if (tid < 256) {   // bf16 h_t tile: 64 rows x 32 B, as 8-byte write-through stores (issued first: they are
-                               // what the other workgroups wait for)
-                const int rl = tid >> 2, part = tid & 3, b = rbase + rl;
-                if (b < B) {
-                    const unsigned long long v = *reinterpret_cast<const unsigned long long*>(hsm + rl * P_UN + part * 4);
-                    unsigned short* dst = p.hb + ((int64_t)t * B + b) * p.ldhb + u0 + part * 4;
-                    __hip_atomic_store((gu64*)dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+            if (wave == 0) {   // bf16 h_t tile: 32 rows x 32 B = ONE 16-byte write-through store instruction, issued first:
+                               // it is what the other workgroups wait for
+                const int rl = lane >> 1, part = lane & 1;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(hsm + rl * P_UN + part * 8);
+                unsigned short* dst = p.hb + ((int64_t)t * B + rbase + rl) * p.ldhb + u0 + part * 8;
+                if (rbase + rl < B) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
             }
+            if (rok) {
+                const int64_t rowi = (int64_t)t * B + eb;
+                float* cdst = p.c_all + rowi * H + eunit;
+                float* hdst = p.h_all ? p.h_all + rowi * H + eunit : nullptr;
+                float* st = p.gx_stash + rowi * H4 + eunit;
+                if (e_vec) {
+                    *reinterpret_cast<f32x2*>(cdst) = cv;
+                    if (hdst) *reinterpret_cast<f32x2*>(hdst) = hv;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int b = rbase + erow + 32 * e;
-                if (eu_ok && b < B) {
-                    const int64_t rowi = (int64_t)t * B + b;
-                    p.c_all[rowi * H + eunit] = cv[e];
-                    if (p.h_all) p.h_all[rowi * H + eunit] = hv[e];
-                    float* st = p.gx_stash + rowi * H4 + eunit;
-                    st[0] = gate[e][0];
-                    st[(int64_t)H] = gate[e][1];
-                    st[(int64_t)2 * H] = gate[e][2];
-                    st[(int64_t)3 * H] = gate[e][3];
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x2*>(st + (int64_t)g * H) = gate[g];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (j ? e_ok1 : e_ok0) {
+                            cdst[j] = cv[j];
+                            if (hdst) hdst[j] = hv[j];
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) st[(int64_t)g * H + j] = gate[g][j];
+                        }
                 }
             }
             XSTAMP(p.stamps, xrec, 7);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its stores
-            XSTAMP(p.stamps, xrec, 8);
-            P_BARRIER();
-            if (tid == 0) __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (wave == 0) {   // the ONE wave that stored the hand-off payload drains and signals for the workgroup
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                XSTAMP(p.stamps, xrec, 8);
+                if (lane == 0) __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             XSTAMP(p.stamps, xrec, 9);
+            P_BARRIER();       // hsm / cst / partial sums are free again
         }
     }
 }
 
+// grid = [na workgroups of layer pa | workgroups of layer pb] (nb may be 0)
+template <bool FULL>
+__global__ __launch_bounds__(P_NT, 2) void lstm_seq_fwd_bf16_persist_kernel(SeqFwdBf16Args pa, SeqFwdBf16Args pb, int na) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[P_LDS];
+    __shared__ int s_flag;                 // poll result of the polling lane
+    if ((int)blockIdx.x < na) seq_fwd_body<FULL>(pa, blockIdx.x, smem, s_flag);
+    else seq_fwd_body<FULL>(pb, blockIdx.x - na, smem, s_flag);
+}
+
 int lstm_seq_fwd_bf16_persist_supported(int B, int H, int Kp) {
-    return (B % P_SR == 0 && Kp % 64 == 0 && Kp >= H && Kp <= 64 * P_KCH) ? 1 : 0;
+    if (!(B > 0 && B % P_SR == 0 && Kp % 64 == 0 && Kp >= H && Kp <= 64 * P_KCH)) return 0;
+    const int nC = cdiv(H, P_UN);
+    int R = B / P_SR;                       // row groups (one 32-row chain each) ...
+    int ns = 1;
+    while (R * nC > P_MAX_WG / 2 && ns < P_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }   // ... merged until a layer fits half
+    return (R * nC <= P_MAX_WG / 2 && R <= 64) ? ns : 0;                               // the chip (two layers co-run)
 }
 
 size_t lstm_persist_sync_bytes() { return (size_t)64 * P_MAXNS * 32 * sizeof(unsigned int); }   // <= 64 row groups
 
-int lstm_seq_fwd_bf16_persist(hipStream_t stream, SeqFwdBf16Args a) {
-    S2VT_REQUIRE(lstm_seq_fwd_bf16_persist_supported(a.B, a.H, a.Kp), "lstm_seq_fwd_bf16_persist: unsupported shape");
-    S2VT_REQUIRE(a.t1 > a.t0 && a.t0 >= 0 && a.wb && a.hb && a.gx_stash && a.c_all && a.sync && a.err,
-                 "lstm_seq_fwd_bf16_persist: bad arguments");
+static int prep(SeqFwdBf16Args& a, const char* who) {
+    const int ns = lstm_seq_fwd_bf16_persist_supported(a.B, a.H, a.Kp);
+    S2VT_REQUIRE(ns > 0, "%s: unsupported shape (B %% 32, Kp <= 1024, <= 252 workgroups)", who);
+    S2VT_REQUIRE(a.t1 > a.t0 && a.t0 >= 0 && a.wb && a.hb && a.gx_stash && a.c_all && a.sync && a.err && (a.bias || a.n_gx >= a.t1),
+                 "%s: bad arguments", who);
     S2VT_REQUIRE(a.ldhb % 8 == 0 && a.ldwb % 8 == 0 && a.ldhb >= a.Kp && a.ldwb >= a.Kp &&
                      (reinterpret_cast<uintptr_t>(a.hb) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.wb) & 15) == 0,
-                 "lstm_seq_fwd_bf16_persist: operands must be 16-B aligned bf16 rows zero-padded to Kp");
-    a.RB = (a.B % 128 == 0) ? 128 : 64;
-    a.NS = a.RB / P_SR;
-    const int R = a.B / a.RB, nC = cdiv(a.H, P_UN);
-    S2VT_REQUIRE(R <= 64, "lstm_seq_fwd_bf16_persist: batch too large for the counter block");
-    S2VT_REQUIRE(R * nC <= 256, "lstm_seq_fwd_bf16_persist: %d workgroups would not be co-resident", R * nC);
+                 "%s: operands must be 16-B aligned bf16 rows zero-padded to Kp", who);
+    a.NS = ns;
+    a.RB = ns * P_SR;
+    return 0;
+}
+
+// one layer (b == nullptr) or two layers side by side in one launch
+int lstm_seq_fwd_bf16_persist2(hipStream_t stream, SeqFwdBf16Args a, const SeqFwdBf16Args* b) {
+    int rc;
+    if ((rc = prep(a, "lstm_seq_fwd_bf16_persist"))) return rc;
+    SeqFwdBf16Args bb = b ? *b : a;
+    if (b) {
+        if ((rc = prep(bb, "lstm_seq_fwd_bf16_persist"))) return rc;
+        S2VT_REQUIRE(bb.Kp == a.Kp && bb.sync != a.sync, "lstm_seq_fwd_bf16_persist: paired layers need the same Kp and their own counters");
+    }
+    const int na = (a.B / a.RB) * cdiv(a.H, P_UN), nb = b ? (bb.B / bb.RB) * cdiv(bb.H, P_UN) : 0;
+    S2VT_REQUIRE(na + nb <= P_MAX_WG, "lstm_seq_fwd_bf16_persist: %d workgroups would not be co-resident", na + nb);
     S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
+    if (b) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
     if (a.Kp == 64 * P_KCH)
-        hipLaunchKernelGGL((lstm_seq_fwd_bf16_persist_kernel<true>), dim3(R * nC), dim3(P_NT), 0, stream, a);
+        hipLaunchKernelGGL((lstm_seq_fwd_bf16_persist_kernel<true>), dim3(na + nb), dim3(P_NT), 0, stream, a, bb, na);
     else
-        hipLaunchKernelGGL((lstm_seq_fwd_bf16_persist_kernel<false>), dim3(R * nC), dim3(P_NT), 0, stream, a);
+        hipLaunchKernelGGL((lstm_seq_fwd_bf16_persist_kernel<false>), dim3(na + nb), dim3(P_NT), 0, stream, a, bb, na);
     S2VT_LAUNCH_CHECK("lstm_seq_fwd_bf16_persist_kernel");
     return 0;
 }
+int lstm_seq_fwd_bf16_persist(hipStream_t stream, SeqFwdBf16Args a) { return lstm_seq_fwd_bf16_persist2(stream, a, nullptr); }
 
 }  // namespace s2vt

@@ -138,6 +138,16 @@ class FlatGradAllReducer:
         main.wait_stream(cs)
 
 
+def global_mean(total, count, device="cpu"):
+    """sum(total over ranks) / sum(count over ranks): the SAME number on every rank.  train.py feeds it to
+    ReduceLROnPlateau / EarlyStopping: replicas that stepped their schedulers on rank-local validation losses would cut
+    the learning rate at different epochs and drift apart while their gradients are still being averaged."""
+    t = torch.tensor([float(total), float(count)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t[0] / torch.clamp(t[1], min=1.0))
+
+
 def train_step(model, criterion, optimizer, feats, caps, mask, reducer=None):
     """One optimisation step of train.py:116-127 on this rank's shard; returns the (local) loss tensor.
     With `reducer`, gradients are averaged over ranks before the optimiser step."""

@@ -220,3 +220,21 @@ def lstm_seq_fwd_bf16(gx, n_gx, bias, w_hh, T, B, H, persistent=False, block=0):
         if int(ws[:4].view(torch.int32)[0].item()) != 0:
             raise capi.S2VTHipError("persistent recurrence: a hand-off wait timed out (workgroups not co-resident?)")
     return h_all, c_all, stash
+
+
+def lstm_seq_fwd_bf16_pair(gx0, gx1, n_gx, bias0, bias1, w0, w1, T, B, H, block=0):
+    """Two independent layers, every block of timesteps of both in ONE persistent launch.  Returns two (h_all, c_all, gates)."""
+    lib = capi.load()
+    dev = w0.device
+    st0, st1 = _f32c(gx0, "gx0").clone(), _f32c(gx1, "gx1").clone()
+    w0, w1 = _f32c(w0, "w0"), _f32c(w1, "w1")
+    with torch.cuda.device(dev):
+        nbytes = 2 * lib.s2vt_lstm_seq_bf16_workspace_bytes(T, B, H)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        outs = [torch.empty(T * B, H, dtype=torch.float32, device=dev) for _ in range(4)]
+        capi.check(lib.s2vt_lstm_seq_fwd_bf16_pair(T, B, H, _ptr(st0), _ptr(st1), int(n_gx), _ptr(bias0), _ptr(bias1), _ptr(w0),
+                                                   _ptr(w1), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), _ptr(outs[3]), _ptr(ws),
+                                                   nbytes, int(block), _stream(dev)), "s2vt_lstm_seq_fwd_bf16_pair")
+        if int(ws[:4].view(torch.int32)[0].item()) != 0:
+            raise capi.S2VTHipError("persistent recurrence: a hand-off wait timed out (workgroups not co-resident?)")
+    return (outs[0], outs[2], st0), (outs[1], outs[3], st1)

@@ -79,6 +79,42 @@ def test_two_rank_dp_equals_global_batch(tmp_path):
         assert abs(0.5 * (r0["losses"][s] + r1["losses"][s]) - losses[s]) < 2e-6
 
 
+def _plateau_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from s2vt_video_caption_amd import dp
+    # what train.py does per epoch: rank-local validation sums (different on every rank: each rank sees its own shard and
+    # its own random caption choice), reduced to ONE number that drives ReduceLROnPlateau on every rank
+    w = torch.nn.Parameter(torch.ones(3))
+    opt = torch.optim.Adam([w], lr=1e-2)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=1)
+    g = torch.Generator().manual_seed(100 + rank)
+    lrs, vals = [], []
+    for epoch in range(12):
+        local = 1.0 + 0.3 * float(torch.rand(1, generator=g)) + (0.5 if epoch < 2 else 0.0)   # plateaus after epoch 2
+        count = 3 + rank                                                                    # ragged shards
+        v = dp.global_mean(local * count, count)
+        sched.step(v)
+        lrs.append(opt.param_groups[0]["lr"])
+        vals.append(v)
+    torch.save({"lrs": lrs, "vals": vals}, os.path.join(out_dir, "plateau%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_validation_loss_is_identical_on_all_ranks_so_lr_schedules_stay_in_step(tmp_path):
+    world = 2
+    mp.spawn(_plateau_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0, r1 = torch.load(tmp_path / "plateau0.pt"), torch.load(tmp_path / "plateau1.pt")
+    assert r0["vals"] == r1["vals"]                  # bitwise the same validation loss on both ranks
+    assert r0["lrs"] == r1["lrs"]                    # so the plateau scheduler cuts the LR at the same epochs
+    assert r0["lrs"][-1] < r0["lrs"][0]              # and it did cut it
+
+
 def test_shard_rows_and_buckets():
     sys.path.insert(0, ROOT)
     from s2vt_video_caption_amd import dp

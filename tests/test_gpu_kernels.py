@@ -285,8 +285,8 @@ def test_bf16_step_kernels_h1000_odd_batch(lib, T, B, H, n_gx):
     _check_seq_bf16_teacher_forced(h_all, c_all, gates, gx, n_gx, bias, w, T, B, H)
 
 
-@pytest.mark.parametrize("T,B,H,n_gx,block", [(6, 64, 128, 4, 0), (7, 128, 1000, 4, 3), (5, 256, 1000, 3, 0),
-                                              (9, 192, 520, 9, 4), (12, 256, 1000, 6, 5)])
+@pytest.mark.parametrize("T,B,H,n_gx,block", [(6, 32, 128, 4, 0), (7, 128, 1000, 4, 3), (5, 256, 1000, 3, 0),
+                                              (9, 96, 520, 9, 4), (12, 256, 1000, 6, 5), (4, 512, 1000, 2, 0)])
 def test_persistent_bf16_recurrence(lib, T, B, H, n_gx, block):
     """lstm_seq_fwd_bf16_persist_kernel (one launch per block of steps, W_hh slice resident per CU, cross-workgroup
     hand-off of h_t): every step teacher-forced against fp64 math, the run repeated bit for bit (a stale hand-off is
@@ -323,3 +323,20 @@ def test_persistent_bf16_recurrence_under_load(lib):
     for a, b in zip(quiet, loaded):
         assert torch.equal(a, b)
     _check_seq_bf16_teacher_forced(*loaded, gx, n_gx, bias, w, T, B, H)
+
+
+def test_persistent_bf16_recurrence_two_layers_one_launch(lib):
+    """Two layers side by side in ONE persistent launch (504 workgroups, two per CU at B = 256): each must equal its own
+    single-layer launch bit for bit, and both pass the teacher-forced check."""
+    from s2vt_video_caption_amd import ops
+    T, B, H, n_gx = 20, 256, 1000, 12
+    ins = []
+    for k in range(2):
+        ins.append((_r(T * B, 4 * H, seed=41 + k), _r(4 * H, seed=43 + k, scale=0.3), _r(4 * H, H, seed=45 + k, scale=H ** -0.5)))
+    (gx0, b0, w0), (gx1, b1, w1) = ins
+    pair = ops.lstm_seq_fwd_bf16_pair(gx0.to(DEV), gx1.to(DEV), n_gx, b0.to(DEV), b1.to(DEV), w0.to(DEV), w1.to(DEV), T, B, H, block=8)
+    for (gx, b, w), got in zip(ins, pair):
+        solo = ops.lstm_seq_fwd_bf16(gx.to(DEV), n_gx, b.to(DEV), w.to(DEV), T, B, H, persistent=True, block=8)
+        for x, y in zip(got, solo):
+            assert torch.equal(x, y)
+        _check_seq_bf16_teacher_forced(*got, gx, n_gx, b, w, T, B, H)

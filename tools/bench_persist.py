@@ -30,5 +30,15 @@ for B in (256, 128, 64):
         # bytes of the SURVEY 8(d) accounting for a vid-shaped layer (I = H, bf16 operands, train)
         s = 2
         by = s * 4 * H * 2 * H + 4 * 8 * H + s * B * 2 * H + 4 * B * H + s * B * H + 4 * B * H + s * B * 4 * H
+        if persistent and block == 32:      # both layers in one launch: time per PAIR of layer steps
+            for rep in range(3):
+                lib.s2vt_prof_reset()
+                lib.s2vt_prof_enable(1)
+                ops.lstm_seq_fwd_bf16_pair(gx, gx, 80, bias, bias, w, w, T, B, H, block=block)
+                torch.cuda.synchronize()
+                lib.s2vt_prof_enable(0)
+                ms2, n2 = capi.prof_read(1)
+            print("B=%d two layers in one launch, block=%d: %.3f ms, %.2f us per step PAIR, %.2f TB/s (8d bytes of a vid+word pair)" %
+                  (B, block, ms2, ms2 / T * 1e3, (by + s * 4 * H * H + s * B * H) / (ms2 * 1e-3 / T) / 1e12), flush=True)
         print("B=%d persistent=%s block=%d: %.3f ms per layer pass (HIP events), %.2f us/step, %.2f TB/s (8d bytes)" %
               (B, persistent, block, dt * 1e3, dt / T * 1e6, by / (dt / T) / 1e12), flush=True)
