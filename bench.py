@@ -231,6 +231,31 @@ def main():
     torch.cuda.synchronize(dev)
     log("timed region: %.3f ms/step, %.0f frames/s" % (ms_per_step, frames_per_s))
 
+    # ---- BASELINE configs[3] shard: B=128 per GPU (global 1024 at 8 GPUs), same step, every rank takes part (sub-record;
+    # the headline stays B per GPU so that N=1 agrees with the single-GPU line)
+    shard128 = None
+    if B != 128 and mode != 1:
+        f2, c2, m2 = synth.make_batch(128, L, F, V, seed=4321 + rank)
+        f2, c2, m2 = f2.to(dev), c2.to(dev), m2.to(dev)
+        for _ in range(2):
+            dp.train_step(model, crit, opt, f2, c2, m2, reducer)
+        sync_all()
+        t0 = time.perf_counter()
+        n128 = 5
+        for _ in range(n128):
+            dp.train_step(model, crit, opt, f2, c2, m2, reducer)
+        sync_all()
+        d128 = time.perf_counter() - t0
+        if use_pg:
+            t = torch.tensor([d128], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            d128 = float(t.item())
+        shard128 = {"workload": "BASELINE configs[3] shard: B=128 per GPU x %d GPU = global %d" % (world, 128 * world),
+                    "value": round(world * 128 * L * n128 / d128, 1), "unit": "frames/s", "ms_per_step": round(d128 / n128 * 1e3, 3),
+                    "steps": n128, "global_batch": 128 * world}
+        del f2, c2, m2
+        log("B=128 shard: %s" % shard128)
+
     out = None
     if rank == 0:
         # ---- live per-kernel timing with HIP events on the launch stream (extra steps, not part of `value`).
@@ -271,12 +296,16 @@ def main():
             e = pmc.get(kernel)
             return int(e["hbm_bytes_per_launch"]) if e and "hbm_bytes_per_launch" in e else None
 
+        persist = bf and bool(lib.s2vt_set_recurrence_mode(-1))
+
         def rooflines(pr, how):
             gemm_ms, gemm_n = pr["gemm"]
-            sf_ms = pr["step_fwd"][0]
+            sf_ms, sb_ms = pr["step_fwd"][0], pr["step_bwd"][0]
             gemm_tf = gflop / gemm_ms                 # GFLOP / ms = TFLOP/s
-            step_us = sf_ms * 1e3 / (2 * T)           # average launch of lstm_step_fwd_kernel (both layers)
+            step_us = sf_ms * 1e3 / (2 * T)           # average timestep of one layer, forward (2T per step: both layers)
+            bstep_us = sb_ms * 1e3 / (2 * T)
             step_gbs = (pair_bytes / 2) / (step_us * 1e-6) / 1e9
+            bstep_gbs = (pair_bytes / 2) / (bstep_us * 1e-6) / 1e9
             if bf:
                 gk, gpeak, gnote = "gemm_b1_kernel", MFMA_BF16_PEAK_TF, "bf16 operands, fp32 accumulate"
             elif x3:   # each algorithmic fp32 product costs six bf16 MFMA products (three planes per operand)
@@ -290,34 +319,47 @@ def main():
                   "traffic": traffic(gk), "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 3),
                   "algorithmic_bytes_or_flops_per_launch": round(gflop * 1e9 / max(gemm_n, 1)),
                   "algorithmic_gflop_per_step": round(gflop, 1), "timing": how, "note": gnote}
-            rs = {"kernel": "lstm_step_fwd_bf16_kernel" if bf else "lstm_step_fwd_kernel", "bound": "hbm", "achieved": round(step_gbs, 1),
+            if persist:
+                fk = "lstm_seq_fwd_bf16_persist_kernel"
+                fnote = ("PERSISTENT-WEIGHTS kernel: one launch runs a block of timesteps of BOTH layers with every W_hh slice "
+                         "resident in registers, so W is not re-streamed and the fraction may exceed 1 (SURVEY.md §8(d)); "
+                         "achieved = §8(d) bytes of a (vid, word) timestep pair / 2 over the average per-layer timestep = launch "
+                         "duration / timesteps in the launch")
+            else:
+                fk = "lstm_step_fwd_bf16_kernel" if bf else "lstm_step_fwd_kernel"
+                fnote = ("bytes per SURVEY.md §8(d) incl. W_ih although the x-part is hoisted into a batched GEMM; avg over vid+word "
+                         "launches, loop-bracketed events (includes launch gaps)")
+            bk = "lstm_step_bwd_bf16_kernel" if bf else "lstm_step_bwd_kernel"
+            rs = {"kernel": fk, "bound": "hbm", "achieved": round(step_gbs, 1),
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
-                  "traffic": traffic("lstm_step_fwd_kernel"),
-                  "avg_launch_us": round(step_us, 3), "launches_per_step": 2 * T,
+                  "traffic": traffic(fk), "avg_launch_us": round(step_us, 3), "launches_per_step": 2 * T,
+                  "algorithmic_bytes_per_launch": pair_bytes // 2, "timing": how, "note": fnote}
+            rb = {"kernel": bk, "bound": "hbm", "achieved": round(bstep_gbs, 1),
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bstep_gbs / HBM_PEAK_GBS, 4),
+                  "traffic": traffic(bk), "avg_launch_us": round(bstep_us, 3), "launches_per_step": 2 * T,
                   "algorithmic_bytes_per_launch": pair_bytes // 2, "timing": how,
-                  "note": "bytes per SURVEY.md §8(d) incl. W_ih although the x-part is hoisted into a batched GEMM; "
-                          "avg over vid+word launches, loop-bracketed events (includes launch gaps)"}
-            return rg, rs
+                  "note": "BPTT timestep: dh = dG_{t+1} W_hh + gate derivatives; same §8(d) byte accounting as the forward timestep"}
+            return rg, rs, rb
 
         live = profile()
         prev_blk = lib.s2vt_set_pipeline_block(0)
         alone = profile()
         lib.s2vt_set_pipeline_block(prev_blk)
         log("profiled steps done (pipeline block %d)" % prev_blk)
-        roof_gemm, roof_step = rooflines(live, "live, layers pipelined on two streams (block %d)" % prev_blk)
-        roof_gemm_alone, roof_step_alone = rooflines(alone, "pipeline off: every kernel alone on the GPU")
-        gname = "gemm_b1_kernel" if bf else ("gemm_x3_kernel" if x3 else "gemm_f32_kernel")
-        fam = {gname: live["gemm"][0], "lstm_step_fwd_kernel": live["step_fwd"][0],
-               "lstm_step_bwd_kernel": live["step_bwd"][0], "ce": live["ce"][0]}
-        fam_alone = {gname: alone["gemm"][0], "lstm_step_fwd_kernel": alone["step_fwd"][0],
-                     "lstm_step_bwd_kernel": alone["step_bwd"][0], "ce": alone["ce"][0]}
-        # the dominant kernel is picked on the ISOLATED times: live times of the two step lanes overlap each other (a
-        # launch's duration includes the share of the chip it cedes to the other lane), which made the choice flip
-        # from run to run; both rooflines are reported below in any case
-        dominant = max(fam_alone, key=fam_alone.get)
-        roofline = roof_gemm if dominant == gname else roof_step
+        roof_gemm, roof_step, roof_bstep = rooflines(live, "live, layers pipelined (block %d)" % prev_blk)
+        roof_gemm_alone, roof_step_alone, roof_bstep_alone = rooflines(alone, "pipeline off: every kernel alone on the GPU")
+        gname = roof_gemm["kernel"]
+        fam = {gname: live["gemm"][0], roof_step["kernel"]: live["step_fwd"][0],
+               roof_bstep["kernel"]: live["step_bwd"][0], "ce": live["ce"][0]}
+        fam_alone = {gname: alone["gemm"][0], roof_step["kernel"]: alone["step_fwd"][0],
+                     roof_bstep["kernel"]: alone["step_bwd"][0], "ce": alone["ce"][0]}
+        # The headline roofline is the fused LSTM TIMESTEP (forward): it is the kernel north_star puts its target on, and the
+        # timestep family (forward + BPTT) is the largest share of the kernel time of a step (the batched GEMMs are second).
+        roofline = dict(roof_step)
+        roofline["family_ms_per_step"] = {"timestep_fwd+bwd": round(fam_alone[roof_step["kernel"]] + fam_alone[roof_bstep["kernel"]], 3),
+                                          "batched_gemm": round(fam_alone[gname], 3)}
 
-        # ---- greedy decode captions/s (one mode='test' call per measurement)
+        # ---- greedy decode captions/s (one mode='test' call per measurement) + its out_linear/argmax kernel
         Bd = args.decode_batch or 128        # BASELINE configs[4]: inference at B=128
         dfe = feats[:Bd] if Bd <= B else synth.make_batch(Bd, L, F, V, seed=99)[0].to(dev)
         model.eval()
@@ -325,13 +367,40 @@ def main():
             model(dfe, mode="test")
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
-            nd = 3
+            nd = 10
             for _ in range(nd):
                 ids = model(dfe, mode="test")
             torch.cuda.synchronize(dev)
             ddt = (time.perf_counter() - t1) / nd
+            capi.check(lib.s2vt_prof_reset(), "prof_reset")
+            capi.check(lib.s2vt_prof_enable(1), "prof_enable")
+            model(dfe, mode="test")
+            torch.cuda.synchronize(dev)
+            capi.check(lib.s2vt_prof_enable(0), "prof_enable")
+            am_ms, am_n = capi.prof_read(4)
+            capi.check(lib.s2vt_prof_reset(), "prof_reset")
+        am_us = am_ms * 1e3 / max(am_n, 1)
+        am_bytes = 4 * V * H + 4 * V + 4 * Bd * H + 8 * Bd         # W_o + b_o + h + packed argmax words
         decode = {"metric": "greedy-decode captions/sec", "value": round(Bd / ddt, 1), "unit": "captions/s",
-                  "batch": Bd, "ms_per_call": round(ddt * 1e3, 2), "n_gpus": 1}
+                  "batch": Bd, "ms_per_call": round(ddt * 1e3, 2), "n_gpus": 1, "calls_timed": nd,
+                  "roofline_logits_argmax": {"kernel": "logits_argmax_kernel", "bound": "hbm", "achieved": round(am_bytes / (am_us * 1e-6) / 1e9, 1),
+                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(am_bytes / (am_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                             "avg_launch_us": round(am_us, 2), "launches_per_call": am_n,
+                                             "algorithmic_bytes_per_launch": am_bytes,
+                                             "gflop_per_launch": round(2.0 * Bd * V * H / 1e9, 2), "traffic": None}}
+        # ---- beam search (BASELINE configs[4]: B=128, beam_size 5, depth 30)
+        with torch.no_grad():
+            model(dfe, mode="beam_search", beam_width=5, max_beam_depth=30)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            nbm = 3
+            for _ in range(nbm):
+                model(dfe, mode="beam_search", beam_width=5, max_beam_depth=30)
+            torch.cuda.synchronize(dev)
+            bdt = (time.perf_counter() - t1) / nbm
+        beam = {"metric": "beam-search captions/sec (beam 5, depth 30)", "value": round(Bd / bdt, 1), "unit": "captions/s",
+                "batch": Bd, "ms_per_call": round(bdt * 1e3, 2), "n_gpus": 1, "calls_timed": nbm}
+        model.train()
 
         log("decode: %s" % decode)
         cpu = None
@@ -340,7 +409,7 @@ def main():
             cores = usable_cores()
             log("cpu_baseline on %d threads" % cores)
             torch.set_num_threads(cores)
-            Bc = min(16, B)
+            Bc = min(64, B)          # the full BASELINE configs[1] batch: ~2-3 s per step on 16 cores
             cm = orc.ReferenceShapedCPUModel(sd)
             copt = torch.optim.Adam(cm.parameters(), lr=1e-4)
             cf, cc, ck = feats[:Bc].cpu(), caps[:Bc].cpu(), mask[:Bc].cpu()
@@ -386,11 +455,16 @@ def main():
             "roofline": roofline,
             "roofline_gemm": roof_gemm,
             "roofline_lstm_step": roof_step,
-            "roofline_isolated": {"gemm": roof_gemm_alone, "lstm_step": roof_step_alone},
+            "roofline_lstm_step_bwd": roof_bstep,
+            "roofline_isolated": {"gemm": roof_gemm_alone, "lstm_step": roof_step_alone, "lstm_step_bwd": roof_bstep_alone},
             "kernel_ms_per_step": {k: round(v, 3) for k, v in fam.items()},
             "kernel_ms_per_step_isolated": {k: round(v, 3) for k, v in fam_alone.items()},
             "decode": decode,
+            "beam": beam,
             "cpu_baseline": cpu,
+            "rccl_ranks": dist.get_world_size() if use_pg else 1,
+            "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if use_pg else None,
+            "dp_b128": shard128,
         }
         print(json.dumps(out), flush=True)
     if use_pg:

@@ -514,12 +514,11 @@ static bool persist_on() {
     if (g_persist < 0) { const char* e = getenv("S2VT_PERSIST"); g_persist = e ? (atoi(e) != 0) : 1; }
     return g_persist != 0;
 }
-static int seq_fwd_bf16_any(hipStream_t st, int t0, int t1, int B, int H, float* gx_stash, int n_gx, const float* bias,
-                            const PB& wb, const PB& hb, float* h_all, float* c_all, unsigned int* sync, int* err) {
-    if (t1 <= t0) return 0;
-    if (!(persist_on() && lstm_seq_fwd_bf16_persist_supported(B, H, hb.kpad) && hb.kpad == wb.kpad))
-        return seq_fwd_bf16(st, t0, t1, B, H, gx_stash, n_gx, bias, wb, hb, h_all, c_all);
-    ProfScope ps(st, K_STEP_FWD, t1 - t0);
+static bool persist_fwd_ok(int B, int H, const PB& wb, const PB& hb) {
+    return persist_on() && lstm_seq_fwd_bf16_persist_supported(B, H, hb.kpad) && hb.kpad == wb.kpad;
+}
+static SeqFwdBf16Args persist_fwd_args(int t0, int t1, int B, int H, float* gx_stash, int n_gx, const float* bias,
+                                       const PB& wb, const PB& hb, float* h_all, float* c_all, unsigned int* sync, int* err) {
     SeqFwdBf16Args a;
     memset(&a, 0, sizeof(a));
     a.B = B; a.H = H; a.Kp = hb.kpad;
@@ -529,7 +528,7 @@ static int seq_fwd_bf16_any(hipStream_t st, int t0, int t1, int B, int H, float*
     a.gx_stash = gx_stash; a.bias = bias;
     a.h_all = h_all; a.c_all = c_all;
     a.sync = sync; a.err = err;
-    return lstm_seq_fwd_bf16_persist(st, a);
+    return a;
 }
 
 // What a forward was run with, keyed by its workspace: s2vt_train_backward must find the same arithmetic mode and
@@ -676,11 +675,42 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
         if ((rc = handoff(sx, st, ev++))) return rc;
         return pgemm(la, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
     }
+    if (bf && persist_fwd_ok(B, H, q.whh1, q.h1) && blk > 0) {
+        // Persistent schedule, ONE stream: the launch of pipeline stage k runs vid_rnn block k next to word_rnn block k-1
+        // (lstm_persist.hip: two workgroups per CU, each layer's W_hh slices resident in registers); between two
+        // launches the plane split + input GEMM of the vid block just finished run alone on the chip.
+        if ((rc = handoff(sx, st, ev++))) return rc;              // weight planes / embedded-word half from lane B
+        const int nb = (int)bd.size() - 1;
+        for (int k = 0; k <= nb; ++k) {
+            const bool hv = k < nb, hw = k >= 1;
+            SeqFwdBf16Args av, aw;
+            if (hv) av = persist_fwd_args(bd[k], bd[k + 1], B, H, w.s1, L, w.bsum1, q.whh1, q.h1, w.h1, w.c1, w.psync_a, w.err + 1);
+            if (hw) aw = persist_fwd_args(bd[k - 1], bd[k], B, H, w.s2, T, w.bsum2, q.whh2, q.h2r, w.h2, w.c2, w.psync_b, w.err + 1);
+            {
+                ProfScope ps(st, K_STEP_FWD, (hv ? bd[k + 1] - bd[k] : 0) + (hw ? bd[k] - bd[k - 1] : 0));
+                if (hv && hw) rc = lstm_seq_fwd_bf16_persist2(st, av, &aw);
+                else rc = lstm_seq_fwd_bf16_persist2(st, hv ? av : aw, nullptr);
+                if (rc) return rc;
+            }
+            if (hw) {   // h2 of word block k-1: transposed planes for dW_hh2 (the row planes were written by the kernel)
+                const int t0 = bd[k - 1], t1 = bd[k];
+                if ((rc = pdual(la, w.h2 + t0 * BH, H, ID, (t1 - t0) * B, H, nullptr, t0 * B, &q.h2T, t0 * B, nullptr))) return rc;
+            }
+            if (hv) {   // vid_out half of the word_rnn gate input for block k
+                const int t0 = bd[k], t1 = bd[k + 1];
+                const bool cap = t0 >= L;
+                if ((rc = pdual(la, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H, nullptr, t0 * B, &q.h1T, t0 * B, nullptr))) return rc;
+                if ((rc = pgemm(la, (t1 - t0) * B, 4 * H, H, q.h1, t0 * B, 0, q.wv, 0, 0, w.s2 + t0 * B4H, 4 * H, ID,
+                                cap ? nullptr : w.bsum2, cap)))
+                    return rc;
+            }
+        }
+        return pgemm(la, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
+    }
     for (size_t k = 0; k + 1 < bd.size(); ++k) {
         const int t0 = bd[k], t1 = bd[k + 1];
         if (bf) {
-            if ((rc = seq_fwd_bf16_any(st, t0, t1, B, H, w.s1, L, w.bsum1, q.whh1, q.h1, w.h1, w.c1, w.psync_a, w.err + 1)))
-                return rc;
+            if ((rc = seq_fwd_bf16(st, t0, t1, B, H, w.s1, L, w.bsum1, q.whh1, q.h1, w.h1, w.c1))) return rc;
         } else {
             if ((rc = seq_fwd(st, t0, t1, B, H, w.s1, L, w.bsum1, p->vid_w_hh, w.h1, w.c1, true))) return rc;
         }
@@ -692,8 +722,7 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
                         cap ? nullptr : w.bsum2, cap)))
             return rc;
         if (bf) {
-            if ((rc = seq_fwd_bf16_any(sx, t0, t1, B, H, w.s2, T, w.bsum2, q.whh2, q.h2r, w.h2, w.c2, w.psync_b, w.err + 1)))
-                return rc;
+            if ((rc = seq_fwd_bf16(sx, t0, t1, B, H, w.s2, T, w.bsum2, q.whh2, q.h2r, w.h2, w.c2))) return rc;
         } else {
             if ((rc = seq_fwd(sx, t0, t1, B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, true))) return rc;
         }

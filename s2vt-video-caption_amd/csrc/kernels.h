@@ -121,6 +121,21 @@ int lstm_seq_fwd_bf16_persist(hipStream_t stream, SeqFwdBf16Args a);
 // two layers (e.g. vid_rnn block k+1 and word_rnn block k) side by side in ONE launch; b == nullptr: one layer
 int lstm_seq_fwd_bf16_persist2(hipStream_t stream, SeqFwdBf16Args a, const SeqFwdBf16Args* b);
 
+struct SeqBwdBf16Args {
+    int B, H, Kp;                                   // Kp: 4H zero-padded to a multiple of 64 (<= 4096)
+    int T, t0, t1;                                  // BPTT over steps t1-1 .. t0 of a T-step layer
+    const unsigned short* wtb; int64_t ldwtb;       // bf16 W_hh^T rows [H][Kp]
+    unsigned short* dgb; int64_t lddgb;             // bf16 dG rows, time-major [T*B][lddgb]: dG_{t+1} in, dG_t out
+    const float* dh_out; int dh_first;              // gradient from above for steps >= dh_first, [(T-dh_first)*B][H] (nullable)
+    float* stash_dg;                                // [T*B][4H]: activated gates in, fp32 dG out (in place)
+    const float* c_all;                             // [T*B][H]
+    float* dc;                                      // [B][H] dL/dc carried between launches (ignored when t1 == T)
+    unsigned int* sync; int* err;
+    int RB, NS;                                     // set by the launcher
+};
+int lstm_seq_bwd_bf16_persist_supported(int B, int H, int Kp4);
+int lstm_seq_bwd_bf16_persist2(hipStream_t stream, SeqBwdBf16Args a, const SeqBwdBf16Args* b);
+
 struct LogitsArgmaxArgs {
     int B, H, V;
     const float* h; int64_t ldh;

@@ -319,6 +319,267 @@ __global__ __launch_bounds__(P_NT, 2) void lstm_seq_fwd_bf16_persist_kernel(SeqF
     else seq_fwd_body<FULL>(pb, blockIdx.x - na, smem, s_flag);
 }
 
+int lstm_seq_fwd_bf16_persist_supported(int B, int H, int Kp);
+size_t lstm_persist_sync_bytes();
+
+// =============================================================================================== backward (BPTT)
+// Same decomposition and hand-off protocol, time reversed: workgroup (rg, cs) owns rows x 16 hidden units, keeps
+// W_hh^T[its 16 units][all 4H] in registers (4 waves split k: 128 VGPRs each, v_mfma_f32_16x16x32_bf16) and per sub-step
+//   dh[32 rows x 16 units] = dG_{t+1}[32 rows x 4H] . W_hh[4H x 16 units]  (+ dh_out_t)  ->  cell derivatives  ->  dG_t, dc.
+// The A operand is 4x wider than the forward's (4H = 4000 -> 4032 bf16 per row: 258 KB per sub-step, far more than LDS):
+// every wave streams ITS k quarter through a private 4-slot LDS ring (4 KB per 64-k chunk, LDS-DMA, XOR-swizzled
+// like the forward image), so the contraction needs no workgroup barrier at all; the four partial tiles meet in LDS.
+// The sub-step is bound by the ~65 GB/s a CU can take in from L2 (4 us for 258 KB); two workgroups per CU (the other
+// chain, or the other layer of a fused launch) overlap their epilogues and hand-offs with it.
+// dG_t leaves as fp32 (in place of the gate stash: the batched weight-gradient GEMMs' source) and as bf16 rows
+// (next step's operand AND the k-major plane of the batched bf16 GEMMs); the bf16 tile (32 rows x 4 gates x 32 B) goes
+// through LDS and is stored write-through by wave 0, which then drains and signals the chain's counter.
+constexpr int Q_NSLOT = 4;                           // ring slots per wave
+constexpr int Q_RING = Q_NSLOT * 4096;               // 16 KB per wave
+constexpr int Q_RLD = 18;                            // row stride of a partial tile (floats)
+constexpr int Q_DGSM = 4 * Q_RING;                   // bf16 dG_t tile [32][64]
+constexpr int Q_DCST = Q_DGSM + P_SR * 64 * 2;       // fp32 dc of the workgroup's cells, per chain [32][16]
+constexpr int Q_LDS = Q_DCST + P_MAXNS * P_SR * P_UN * 4;
+constexpr int Q_KCH = 64;                            // k chunks of 64 (4H padded <= 4096), 16 per wave
+
+template <int DUMMY>
+__device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int bid, unsigned char* smem, int& s_flag) {
+    const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lm = lane & 15, lq = lane >> 4;
+    const int H = p.H, B = p.B;
+    const int nC = (H + P_UN - 1) / P_UN;
+    const int cs = bid % nC, rg = bid / nC;
+    const int u0 = cs * P_UN, row0 = rg * p.RB;
+    const int nch = p.Kp >> 6;
+    const int c0 = wave * 16;                          // this wave's chunks [c0, c0 + 16)
+    const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero4);
+
+    // ---- this wave's quarter of W_hh^T for the workgroup's 16 units: B operand of step (chunk j, half ks)
+    bf16x8 wreg[32];
+    {
+        const int unit = u0 + lm;
+        const unsigned short* wrow = p.wtb + (int64_t)unit * p.ldwtb + lq * 8;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const unsigned short* q = (unit < H && c0 + j < nch) ? wrow + (c0 + j) * 64 + ks * 32 : zero;
+                wreg[j * 2 + ks] = *reinterpret_cast<const bf16x8*>(q);
+            }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wreg[i]));
+    }
+
+    // ---- loader role (each wave for itself): piece i of a chunk = rows 8i..8i+7; lane -> (row, 16-B position)
+    int lrow[4], lsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        lrow[i] = 8 * i + (lane >> 3);
+        lsrc[i] = ((lane & 7) ^ ((lrow[i] >> 1) & 7)) * 16;
+    }
+    unsigned char* ring = smem + wave * Q_RING;
+    // ---- A-fragment read addresses: row tile rt, k half ks of a chunk: lane (m, kq) reads piece ks*4 + kq of row rt*16 + m
+    unsigned fa[2][2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int row = rt * 16 + lm;
+            fa[rt][ks] = lbase + (unsigned)(wave * Q_RING + row * 128 + (((ks * 4 + lq) ^ ((row >> 1) & 7)) * 16));
+        }
+
+    // ---- epilogue role: 2 adjacent units of one row per thread
+    const int erow = tid >> 3, eul = (tid & 7) * 2;
+    const int eunit = u0 + eul;
+    const bool e_ok = eunit + 1 < H;                   // H % 8 == 0: a pair is valid or not as a whole
+    float* dcst = reinterpret_cast<float*>(smem + Q_DCST);
+    const bool last_block = (p.t1 == p.T);
+    for (int s = 0; s < p.NS; ++s) {
+        const int b = row0 + s * P_SR + erow;
+        f32x2 d0 = {0.f, 0.f};
+        if (!last_block && e_ok && b < B) d0 = *reinterpret_cast<const f32x2*>(p.dc + (int64_t)b * H + eunit);
+        *reinterpret_cast<f32x2*>(dcst + (s * P_SR + erow) * P_UN + eul) = d0;
+    }
+    unsigned short* dgsm = reinterpret_cast<unsigned short*>(smem + Q_DGSM);
+    const int64_t H4 = 4 * (int64_t)H;
+
+    for (int t = p.t1 - 1; t >= p.t0; --t) {
+#pragma unroll 1
+        for (int s = 0; s < p.NS; ++s) {
+            const int rbase = row0 + s * P_SR;
+            unsigned int* cnt = p.sync + (rg * P_MAXNS + s) * 32;
+            const int done = p.t1 - 1 - t;             // steps of this launch already finished by every workgroup?
+            if (done > 0) {
+                if (tid == 0) {
+                    const bool ok = spin_until(cnt, (unsigned int)(nC * done));
+                    s_flag = ok ? 1 : 0;
+                    if (!ok) atomicExch(p.err, 1);
+                }
+                P_BARRIER();
+                if (s_flag == 0) return;
+            }
+
+            // epilogue operands requested now (older than every ring request: they never hold a counted wait up)
+            const int eb = rbase + erow;
+            const bool ok = e_ok && eb < B;
+            const int64_t rowi = (int64_t)t * B + eb;
+            f32x2 stv[4], cv, cpv, dhov;
+            {
+                const float* st = p.stash_dg + rowi * H4 + eunit;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) stv[g] = *reinterpret_cast<const f32x2*>(ok ? st + (int64_t)g * H : g_zero4);
+                cv = *reinterpret_cast<const f32x2*>(ok ? p.c_all + rowi * H + eunit : g_zero4);
+                cpv = *reinterpret_cast<const f32x2*>((ok && t > 0) ? p.c_all + (rowi - B) * H + eunit : g_zero4);
+                dhov = *reinterpret_cast<const f32x2*>((ok && p.dh_out && t >= p.dh_first)
+                                                           ? p.dh_out + ((int64_t)(t - p.dh_first) * B + eb) * H + eunit : g_zero4);
+            }
+
+            f32x4 acc[2];
+            acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (t < p.T - 1) {
+                const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.dgb + ((int64_t)(t + 1) * B + rbase) * p.lddgb);
+                const unsigned char* src[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) src[i] = abase + (int64_t)lrow[i] * p.lddgb * 2 + lsrc[i];
+                const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(zero);
+#define Q_ISSUE(J)                                                                                           \
+                {                                                                                             \
+                    const bool in = (c0 + (J)) < nch;                                                         \
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+                        glds16_sc1(in ? src[i] + (c0 + (J)) * 128 : zsrc, ring + ((J) % Q_NSLOT) * 4096 + i * 1024); \
+                }
+#define Q_STEP(J, VM)                                                                                        \
+                if ((J) + 3 < 16) Q_ISSUE((J) + 3)                                                            \
+                asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                        \
+                {                                                                                             \
+                    bf16x8 a00, a01, a10, a11;                                                                \
+                    P_DSR(a00, fa[0][0], ((J) % Q_NSLOT) * 4096); P_DSR(a10, fa[1][0], ((J) % Q_NSLOT) * 4096); \
+                    P_DSR(a01, fa[0][1], ((J) % Q_NSLOT) * 4096); P_DSR(a11, fa[1][1], ((J) % Q_NSLOT) * 4096); \
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a00), "+v"(a10));                              \
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, wreg[(J) * 2], acc[0], 0, 0, 0);    \
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, wreg[(J) * 2], acc[1], 0, 0, 0);    \
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01), "+v"(a11));                              \
+                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, wreg[(J) * 2 + 1], acc[0], 0, 0, 0); \
+                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, wreg[(J) * 2 + 1], acc[1], 0, 0, 0); \
+                }
+                Q_ISSUE(0) Q_ISSUE(1) Q_ISSUE(2)
+                // chunk J landed when at most the requests of the younger chunks (3 of them, fewer at the end) are out
+                Q_STEP(0, 12) Q_STEP(1, 12) Q_STEP(2, 12) Q_STEP(3, 12) Q_STEP(4, 12) Q_STEP(5, 12) Q_STEP(6, 12)
+                Q_STEP(7, 12) Q_STEP(8, 12) Q_STEP(9, 12) Q_STEP(10, 12) Q_STEP(11, 12) Q_STEP(12, 12)
+                Q_STEP(13, 8) Q_STEP(14, 4) Q_STEP(15, 0)
+#undef Q_STEP
+#undef Q_ISSUE
+            }
+            // partial tile of this wave -> its own (idle) ring
+            {
+                float* rp = reinterpret_cast<float*>(ring);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rp[(rt * 16 + 4 * lq + r) * Q_RLD + lm] = acc[rt][r];
+            }
+            P_BARRIER();
+
+            f32x2 dg[4], dcn;
+            {
+                f32x2 dh = dhov;
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    dh += *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(smem + w * Q_RING) + erow * Q_RLD + eul);
+                f32x2* dp = reinterpret_cast<f32x2*>(dcst + (s * P_SR + erow) * P_UN + eul);
+                const f32x2 dcv = *dp;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float ig = stv[0][j], fg = stv[1][j], gg = stv[2][j], og = stv[3][j];
+                    const float tc = fast_tanh(cv[j]);
+                    const float dc = dh[j] * og * (1.0f - tc * tc) + dcv[j];
+                    const float d_o = dh[j] * tc;
+                    dg[0][j] = dc * gg * ig * (1.0f - ig);
+                    dg[1][j] = dc * cpv[j] * fg * (1.0f - fg);
+                    dg[2][j] = dc * ig * (1.0f - gg * gg);
+                    dg[3][j] = d_o * og * (1.0f - og);
+                    dcn[j] = ok ? dc * fg : 0.f;
+                }
+                *dp = dcn;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<unsigned int*>(dgsm + erow * 64 + g * 16 + eul) =
+                        ok ? ((unsigned int)f2bf_rn(dg[g][0]) | ((unsigned int)f2bf_rn(dg[g][1]) << 16)) : 0u;
+            }
+            P_BARRIER();
+            if (wave == 0) {   // bf16 dG_t tile: 4 gates x (32 rows x 32 B): four 16-byte write-through store instructions
+                const int rl = lane >> 1, part = lane & 1;
+                if (rbase + rl < B && u0 + part * 8 < H) {
+                    unsigned short* drow = p.dgb + ((int64_t)t * B + rbase + rl) * p.lddgb + u0 + part * 8;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(dgsm + rl * 64 + g * 16 + part * 8);
+                        unsigned short* dst = drow + (int64_t)g * H;
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                    }
+                }
+            }
+            if (ok) {
+                float* st = p.stash_dg + rowi * H4 + eunit;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x2*>(st + (int64_t)g * H) = dg[g];
+                if (t == p.t0) *reinterpret_cast<f32x2*>(p.dc + (int64_t)eb * H + eunit) = dcn;      // carried to the next launch
+            }
+            if (wave == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            P_BARRIER();       // rings (partial tiles), dG tile and dc state are free again
+        }
+    }
+}
+
+__global__ __launch_bounds__(P_NT, 2) void lstm_seq_bwd_bf16_persist_kernel(SeqBwdBf16Args pa, SeqBwdBf16Args pb, int na) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[Q_LDS];
+    __shared__ int s_flag;
+    if ((int)blockIdx.x < na) seq_bwd_body<0>(pa, blockIdx.x, smem, s_flag);
+    else seq_bwd_body<0>(pb, blockIdx.x - na, smem, s_flag);
+}
+
+int lstm_seq_bwd_bf16_persist_supported(int B, int H, int Kp4) {
+    if (!(H % 8 == 0 && Kp4 % 64 == 0 && Kp4 >= 4 * H && Kp4 <= 64 * Q_KCH)) return 0;
+    return lstm_seq_fwd_bf16_persist_supported(B, H, ((H + 63) / 64) * 64);
+}
+
+static int prep_bwd(SeqBwdBf16Args& a) {
+    const int ns = lstm_seq_bwd_bf16_persist_supported(a.B, a.H, a.Kp);
+    S2VT_REQUIRE(ns > 0, "lstm_seq_bwd_bf16_persist: unsupported shape (B %% 32, H %% 8, 4H <= 4096, <= 252 workgroups)");
+    S2VT_REQUIRE(a.T > 0 && a.t1 > a.t0 && a.t0 >= 0 && a.t1 <= a.T && a.wtb && a.dgb && a.stash_dg && a.c_all && a.dc && a.sync && a.err,
+                 "lstm_seq_bwd_bf16_persist: bad arguments");
+    S2VT_REQUIRE(a.lddgb % 8 == 0 && a.ldwtb % 8 == 0 && a.lddgb >= a.Kp && a.ldwtb >= a.Kp &&
+                     (reinterpret_cast<uintptr_t>(a.dgb) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.wtb) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(a.stash_dg) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.c_all) & 7) == 0 &&
+                     (reinterpret_cast<uintptr_t>(a.dc) & 7) == 0 && (!a.dh_out || (reinterpret_cast<uintptr_t>(a.dh_out) & 7) == 0),
+                 "lstm_seq_bwd_bf16_persist: operands must be aligned bf16 rows zero-padded to Kp / 8-byte aligned fp32 rows");
+    a.NS = ns;
+    a.RB = ns * P_SR;
+    return 0;
+}
+
+int lstm_seq_bwd_bf16_persist2(hipStream_t stream, SeqBwdBf16Args a, const SeqBwdBf16Args* b) {
+    int rc;
+    if ((rc = prep_bwd(a))) return rc;
+    SeqBwdBf16Args bb = b ? *b : a;
+    if (b) {
+        if ((rc = prep_bwd(bb))) return rc;
+        S2VT_REQUIRE(bb.sync != a.sync, "lstm_seq_bwd_bf16_persist: paired layers need their own counters");
+    }
+    const int na = (a.B / a.RB) * cdiv(a.H, P_UN), nb = b ? (bb.B / bb.RB) * cdiv(bb.H, P_UN) : 0;
+    S2VT_REQUIRE(na + nb <= P_MAX_WG, "lstm_seq_bwd_bf16_persist: %d workgroups would not be co-resident", na + nb);
+    S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
+    if (b) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
+    hipLaunchKernelGGL(lstm_seq_bwd_bf16_persist_kernel, dim3(na + nb), dim3(P_NT), 0, stream, a, bb, na);
+    S2VT_LAUNCH_CHECK("lstm_seq_bwd_bf16_persist_kernel");
+    return 0;
+}
+
 int lstm_seq_fwd_bf16_persist_supported(int B, int H, int Kp) {
     if (!(B > 0 && B % P_SR == 0 && Kp % 64 == 0 && Kp >= H && Kp <= 64 * P_KCH)) return 0;
     const int nC = cdiv(H, P_UN);

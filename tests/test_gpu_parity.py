@@ -115,12 +115,12 @@ def test_c1_beam_search_against_reference_golden(lib, golden):
 
 @pytest.mark.parametrize("gemm_mode", [3, 0])
 def test_c2_full_size_against_reference_golden(lib, golden, gemm_mode):
-    """Both arithmetic modes of the batched GEMMs (3 = split-precision bf16x3 on the bf16 matrix cores, the default at
-    B % 64 == 0; 0 = fp32-input MFMA).
-    BASELINE config 2 (B=64, H=E=1000, V=12000, fp32): loss within 1e-4 of the reference over two Adam steps;
-    greedy ids equal to the reference's wherever the reference's own top-2 margin leaves room for fp32
-    summation-order differences (a flip at a near-tie legitimately changes that caption's suffix)."""
+    """BASELINE config 2 (B=64, H=E=1000, V=12000, fp32) in both arithmetic modes of the batched GEMMs (3 = split-precision
+    bf16x3 on the bf16 matrix cores, the default at B % 64 == 0; 0 = fp32-input MFMA): ALL 64 x 79 greedy token ids equal
+    the reference's (the fixture's weakest top-2 margin is 1.3e-3: screened seed, oracle/make_golden.py), loss within 1e-4
+    over two Adam steps, logits slice, and every gradient by norm, by sum and element-wise on its first 32 entries."""
     g = golden("c2")
+    assert float(g["greedy_margin"].min()) >= 1e-3          # the fixture itself leaves no near-tie
     d, sd, feats, caps, mask = _setup(g, "c2")
     prev = lib.s2vt_set_gemm_mode(gemm_mode)
     try:
@@ -134,21 +134,20 @@ def _c2_body(g, d, sd, feats, caps, mask):
     m.eval()
     with torch.no_grad():
         ids = m(feats.to(DEV), mode="test").cpu().numpy()
-    ref, marg = g["greedy_ids"], g["greedy_margin"]
-    exact_rows = 0
-    for b in range(d["B"]):
-        risky = np.nonzero(marg[b] < 2e-4)[0]
-        upto = int(risky[0]) if len(risky) else ref.shape[1]
-        np.testing.assert_array_equal(ids[b, :upto], ref[b, :upto])
-        exact_rows += int((ids[b] == ref[b]).all())
-    assert exact_rows >= int(0.9 * d["B"]), exact_rows
+    np.testing.assert_array_equal(ids, g["greedy_ids"])          # bit-exact, every row, every step
     m.train()
     losses, grads, logits = _train(m, feats, caps, mask, int(g["n_steps"]))
     assert np.abs(np.array(losses) - g["losses"]).max() < 1e-4, (losses, g["losses"])
-    assert np.abs(logits[:, ::13, :64].numpy() - g["logits_rows"]).max() < 5e-5
+    scale = float(g["out_scale"])
+    assert np.abs(logits[:, ::13, :64].numpy() - g["logits_rows"]).max() < 5e-5 * scale
     for k in orc.KEYS:
         gn = float(g["gradnorm/" + k])
         assert abs(float(grads[k].double().norm()) - gn) <= 5e-4 * gn + 1e-7, k
+        # direction, not only size: the sum of all entries (bound relative to the norm: sums cancel) and the first 32 entries
+        n = grads[k].numel()
+        assert abs(float(grads[k].double().sum()) - float(g["gradsum/" + k])) <= 2e-4 * gn * n ** 0.5 + 1e-7, k
+        ref = g["gradhead/" + k]
+        assert np.abs(grads[k].reshape(-1)[:32].numpy() - ref).max() <= 2e-6 + 5e-4 * np.abs(ref).max(), k
 
 
 def test_against_oracle_on_fresh_seeds(lib):
@@ -204,7 +203,8 @@ def test_full_size_properties_c2_shape(lib):
     # a sample does not see its batch mates; only the split-K factor of the batched GEMMs (chosen from the grid
     # size) may change the fp32 summation order between batch sizes
     assert (full[8:24] - part).abs().max().item() < 3e-5
-    assert (ids_full[40:48] == ids_part).all(dim=1).sum().item() >= 7
+    # (ids of a sub-batch are compared on the screened fixtures, where no decision is a near-tie; these weights are unscreened)
+    assert ids_part.shape == (8, d["L"] - 1)
     assert torch.isfinite(full).all()
     assert int(ids_full.min()) >= 0 and int(ids_full.max()) < d["V"]
     m.train()
@@ -217,33 +217,126 @@ def test_full_size_properties_c2_shape(lib):
         logits.backward(dl * scale)
         outs.append({n: p.grad.clone() for n, p in m.named_parameters()})
     for n in outs[0]:
-        if n == "embedding.weight":      # atomics: order-dependent rounding, compare loosely
-            assert (outs[1][n] - 2 * outs[0][n]).abs().max().item() <= 1e-5 * outs[0][n].abs().max().item() + 1e-12
-        else:
-            assert torch.equal(outs[1][n], 2 * outs[0][n]), n
+        assert torch.equal(outs[1][n], 2 * outs[0][n]), n      # every reduction has a fixed order (no atomics anywhere)
 
 
 def test_c5_dims_beam_and_greedy_against_reference_golden(lib, golden):
-    """BASELINE config 5 dims (H=E=1000, V=12000), beam_size 5, depth 30: token ids of the batched on-GPU beam search
-    against the reference's own per-sample Python beam search (4 captions; the reference needs ~18 s per caption)."""
+    """BASELINE config 5 dims (H=E=1000, V=12000), beam_size 5, depth 30: ALL token ids of the batched on-GPU beam search
+    equal the reference's own per-sample Python beam search, and all greedy ids equal the reference's (4 captions: the
+    reference needs ~20 s per caption).  The fixture is screened (oracle/make_golden.py): weakest greedy top-2 margin and
+    weakest beam decision gap are both >= 1e-3."""
     g = golden("c5beam")
+    assert float(g["greedy_margin"].min()) >= 1e-3 and float(g["beam_min_gap"]) >= 1e-3
     d = dict(synth.CONFIGS["c5"]); d["B"] = int(g["dims"][0])
     seed = int(g["seed"])
-    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed)
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed, out_scale=float(g["out_scale"]))
     feats, caps, mask = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
     m = _model(d, sd).eval()
     with torch.no_grad():
         ids = m(feats.to(DEV), mode="test").cpu().numpy()
         out = m(feats.to(DEV), mode="beam_search", beam_width=int(g["beam_width"]), max_beam_depth=30)
-    ref, marg = g["greedy_ids"], g["greedy_margin"]
-    for b in range(d["B"]):
-        risky = np.nonzero(marg[b] < 2e-4)[0]
-        upto = int(risky[0]) if len(risky) else ref.shape[1]
-        np.testing.assert_array_equal(ids[b, :upto], ref[b, :upto])
-    same = 0
+    np.testing.assert_array_equal(ids, g["greedy_ids"])
     for b, s in enumerate(out):
-        same += int([int(t.item()) for t in s] == [int(x) for x in g["beam_ids"][b] if x >= 0])
-    assert same >= d["B"] - 1, same      # a near-tie in log-prob order may legitimately flip one caption
+        assert [int(t.item()) for t in s] == [int(x) for x in g["beam_ids"][b] if x >= 0], b
+
+
+def test_c3_full_size_bf16_against_reference_golden(lib, golden):
+    """BASELINE configs[2] at its own size: B=256, L=80, F=4096, H=E=1000, V=12000 with s2vt_set_gemm_mode(1) (bf16
+    operands for the batched GEMMs and the recurrence - k padded 1000 -> 1024, 4000 -> 4032 - fp32 accumulation, cell
+    state and gradients), against ONE fp32 train step of the reference on the same seeded inputs (tests/golden/c3.npz).
+    Stated bf16 bounds: loss within 2e-3 (measured ~1e-4: the mean over 20 224 rows averages the rounding out), logits
+    slice within 2e-2 of the largest logit, every gradient's norm within 2 %, its first 32 entries within 8 % of their
+    largest.  Plus the size-independent properties: finite, deterministic (bitwise), batch-independent rows, and the
+    persistent recurrence schedule equal to the launch-per-timestep one within bf16 re-rounding."""
+    import utils
+    g = golden("c3")
+    d, sd, feats, caps, mask = _setup(g, "c3")
+    f, c, k = feats.to(DEV), caps.to(DEV), mask.to(DEV)
+    crit = utils.MaskCriterion()
+    prev = lib.s2vt_set_gemm_mode(1)
+    try:
+        m = _model(d, sd)
+        m.train()
+        logits = m(f, targets=c[:, :-1], mode="train")
+        loss = crit(logits, c, k)
+        loss.backward()
+        torch.cuda.synchronize()
+        assert torch.isfinite(logits).all()
+        assert abs(float(loss) - float(g["losses"][0])) < 2e-3, (float(loss), float(g["losses"][0]))
+        ref_rows = g["logits_rows"]
+        assert np.abs(logits.detach()[:, ::13, :64].cpu().numpy() - ref_rows).max() < 2e-2 * np.abs(ref_rows).max()
+        for key, p in m.named_parameters():
+            gn = float(g["gradnorm/" + key])
+            assert torch.isfinite(p.grad).all(), key
+            assert abs(float(p.grad.double().norm()) - gn) <= 2e-2 * gn, (key, float(p.grad.double().norm()), gn)
+            ref = g["gradhead/" + key]
+            assert np.abs(p.grad.reshape(-1)[:32].cpu().numpy() - ref).max() <= 8e-2 * np.abs(ref).max() + 1e-9, key
+        with torch.no_grad():
+            again = m(f, targets=c[:, :-1], mode="train")
+            part = m(f[64:128], targets=c[64:128, :-1], mode="train")
+            assert torch.equal(again, logits.detach())                   # deterministic
+            # a sample does not see its batch mates (only the split-K factor of a batched GEMM may change the summation
+            # order between batch sizes, and a re-rounded bf16 activation moves a logit by ~1e-3 of its scale)
+            assert (part - logits.detach()[64:128]).abs().max().item() < 2e-2 * logits.detach().abs().max().item()
+            before = lib.s2vt_set_recurrence_mode(0)
+            try:
+                per_step = m(f, targets=c[:, :-1], mode="train")
+            finally:
+                lib.s2vt_set_recurrence_mode(before)
+            assert (per_step - logits.detach()).abs().max().item() < 2e-2 * logits.detach().abs().max().item()
+            from s2vt_video_caption_amd import capi
+            capi.check_async_error()
+    finally:
+        lib.s2vt_set_gemm_mode(prev)
+
+
+def test_out_of_range_target_raises_index_error(lib):
+    """The reference's nn.Embedding raises IndexError for a caption id outside the vocabulary (S2VTModel.py:71).  Here the
+    check runs on the device: the error surfaces at the next synchronisation point (capi.check_async_error) or, at the
+    latest, from the next forward / backward."""
+    import utils
+    from s2vt_video_caption_amd import capi
+    d = synth.CONFIGS["tiny"]
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=3)
+    feats, caps, mask = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=3)
+    m = _model(d, sd)
+    bad = caps.clone()
+    bad[1, 2] = d["V"]                       # one id past the vocabulary
+    m(feats.to(DEV), targets=bad[:, :-1].to(DEV), mode="train")
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        capi.check_async_error()
+    capi.check_async_error()                 # reported once
+    neg = caps.clone()
+    neg[0, 1] = -1
+    m(feats.to(DEV), targets=neg[:, :-1].to(DEV), mode="train")
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):          # ... or by the next forward
+        m(feats.to(DEV), targets=caps[:, :-1].to(DEV), mode="train")
+    logits = m(feats.to(DEV), targets=caps[:, :-1].to(DEV), mode="train")       # a clean call works again
+    capi.check_async_error()
+    assert torch.isfinite(logits).all()
+
+
+def test_backward_refuses_a_workspace_of_another_mode(lib):
+    """Changing the arithmetic mode between a forward and its backward would carve the workspace differently: refused."""
+    import utils
+    from s2vt_video_caption_amd import capi
+    B, L, Fd, H, E, V = 64, 4, 64, 64, 64, 100
+    sd = synth.make_state_dict(V, Fd, H, E, seed=9)
+    feats, caps, mask = synth.make_batch(B, L, Fd, V, seed=9, min_words=1, max_words=2)
+    import S2VTModel
+    m = S2VTModel.S2VT(V, Fd, L, dim_hid=H, dim_embed=E)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    logits = m(feats.to(DEV), targets=caps[:, :-1].to(DEV), mode="train")
+    loss = utils.MaskCriterion()(logits, caps.to(DEV), mask.to(DEV))
+    prev = lib.s2vt_set_gemm_mode(1 if lib.s2vt_set_gemm_mode(-1) != 1 else 3)
+    try:
+        with pytest.raises(capi.S2VTHipError):
+            loss.backward()
+    finally:
+        lib.s2vt_set_gemm_mode(prev)
 
 
 def test_bf16_mode_config3_arithmetic(lib):

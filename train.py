@@ -20,7 +20,7 @@ import torch.distributed as dist
 from torch import optim
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--caption-file", default="./data/captions_server.json")
     ap.add_argument("--feats-path", default="./data/feats/vgg16_bn")
@@ -39,11 +39,17 @@ def parse():
     ap.add_argument("--early-stopping-patience", type=int, default=30)
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--learning-rate-patience", type=int, default=20)
-    return ap.parse_args()
+    # reproducibility switches (not in the reference, whose runs are unseeded): used by the harness parity test
+    ap.add_argument("--no-shuffle", action="store_true", help="iterate the training set in file order")
+    ap.add_argument("--seed", type=int, default=None, help="seed numpy's global RNG (caption sampling, dataloader.py:41)")
+    ap.add_argument("--init-state", default=None, help="state_dict file to start from instead of the seeded default init")
+    return ap.parse_args(argv)
 
 
-def main():
-    opt = parse()
+def run(opt):
+    """The reference's training loop (train.py:108-168).  Returns the history it went through:
+    {"train_loss": [...], "valid_loss": [...], "lr": [lr in force DURING each epoch], "stopped_at": epoch or None,
+     "checkpoints": [file names in the order they were written]}."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -53,17 +59,21 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
+    import numpy as np
     import dataloader
     from S2VTModel import S2VT
     from utils import EarlyStopping, MaskCriterion
     from s2vt_video_caption_amd import capi, dp
 
+    if opt.seed is not None:
+        np.random.seed(opt.seed + rank)
     start_time = time.strftime('%y_%m_%d_%H_%M_%S-', time.localtime())
     os.makedirs(opt.save_path, exist_ok=True)
     trainset = dataloader.VideoDataset(opt.caption_file, opt.feats_path, max_len=opt.train_length)
     validset = dataloader.VideoDataset(opt.caption_file, opt.feats_path, max_len=opt.train_length, mode='valid')
-    sampler = torch.utils.data.distributed.DistributedSampler(trainset, shuffle=True, drop_last=True) if world > 1 else None
-    train_loader = torch.utils.data.DataLoader(trainset, batch_size=opt.batch_size, shuffle=sampler is None,
+    shuffle = not opt.no_shuffle
+    sampler = torch.utils.data.distributed.DistributedSampler(trainset, shuffle=shuffle, drop_last=True) if world > 1 else None
+    train_loader = torch.utils.data.DataLoader(trainset, batch_size=opt.batch_size, shuffle=shuffle and sampler is None,
                                                sampler=sampler, drop_last=world > 1, num_workers=opt.workers,
                                                persistent_workers=opt.workers > 0)
     # validation is sharded over the ranks too; its loss is reduced over all of them below (one number for every rank)
@@ -74,17 +84,27 @@ def main():
 
     torch.manual_seed(0)        # identical replicas
     model = S2VT(len(word2ix), opt.feat_dim, length=opt.train_length, dim_hid=opt.dim_hidden, dim_embed=opt.dim_embed,
-                 feat_dropout=opt.feat_dropout, sos_ix=word2ix['<sos>'], eos_ix=word2ix['<eos>']).to(dev)
-    optimizer = optim.Adam(model.parameters(), lr=opt.lr)
-    lr_scheduler = optim.lr_scheduler.ReduceLROnPlateau(optimizer, patience=opt.learning_rate_patience)
+                 feat_dropout=opt.feat_dropout, sos_ix=word2ix['<sos>'], eos_ix=word2ix['<eos>'])
+    if opt.init_state:
+        model.load_state_dict(torch.load(opt.init_state))
+    model.to(dev)
+    optimizer = optim.Adam(model.parameters(), lr=opt.lr)                                           # train.py:89-93
+    lr_scheduler = optim.lr_scheduler.ReduceLROnPlateau(optimizer, patience=opt.learning_rate_patience)   # :95-97
     early_stopping = EarlyStopping(patience=opt.early_stopping_patience, verbose=rank == 0,
-                                   path=os.path.join(opt.save_path, start_time + 'stop.pth'))
+                                   path=os.path.join(opt.save_path, start_time + 'stop.pth'))        # :98-100
     criterion = MaskCriterion()
     reducer = dp.FlatGradAllReducer(model.parameters()).attach(model) if world > 1 else None
+    hist = {"train_loss": [], "valid_loss": [], "lr": [], "stopped_at": None, "checkpoints": []}
+
+    def save(name):
+        if rank == 0:
+            torch.save(model, os.path.join(opt.save_path, start_time + name))
+            hist["checkpoints"].append(name)
 
     for epoch in range(opt.epochs):
         if sampler is not None:
             sampler.set_epoch(epoch)
+        hist["lr"].append(optimizer.param_groups[0]['lr'])
         running, count = 0.0, 0
         for feats, targets, ids, masks in dataloader.feed_batches(train_loader, dev):
             loss = dp.train_step(model, criterion, optimizer, feats, targets, masks, reducer)   # train.py:116-127
@@ -100,25 +120,36 @@ def main():
                 running += float(criterion(probs, targets, masks))
                 count += 1
         valid_loss = dp.global_mean(running, count, dev)   # identical on every rank: the schedulers below stay in step
+        hist["train_loss"].append(train_loss)
+        hist["valid_loss"].append(valid_loss)
         if rank == 0:
             print("epoch {} train loss:{} valid loss: {} lr: {}".format(epoch, train_loss, valid_loss,
                                                                         optimizer.param_groups[0]['lr']))
-        lr_scheduler.step(valid_loss)
+        lr_scheduler.step(valid_loss)                                                          # train.py:155
+        n_before = early_stopping.val_loss_min
         if rank == 0:
-            early_stopping(valid_loss, model)
-            if epoch % opt.save_freq == 0:
-                torch.save(model, os.path.join(opt.save_path, start_time + str(epoch) + '.pth'))
+            early_stopping(valid_loss, model)                                                  # train.py:158
+            if early_stopping.val_loss_min != n_before:
+                hist["checkpoints"].append('stop.pth')
         stop = torch.tensor([1 if (rank == 0 and early_stopping.early_stop) else 0], device=dev)
         if world > 1:
             dist.broadcast(stop, 0)
-        if int(stop):
+        if int(stop):                                                                          # train.py:159-161
             if rank == 0:
                 print("Early stopping")
+            hist["stopped_at"] = epoch
             break
-    if rank == 0:
-        torch.save(model, os.path.join(opt.save_path, start_time + 'final.pth'))
+        if epoch % opt.save_freq == 0:                                                         # train.py:164-167
+            save(str(epoch) + '.pth')
+    save('final.pth')                                                                          # train.py:175
+    hist["start_time"] = start_time
     if world > 1:
         dist.destroy_process_group()
+    return hist
+
+
+def main():
+    run(parse())
 
 
 if __name__ == '__main__':
