@@ -211,6 +211,18 @@ int s2vt_lstm_seq_fwd_bf16_pair(int32_t T, int32_t B, int32_t H, float* gx_stash
                                 const float* bias0, const float* bias1, const float* w_hh0, const float* w_hh1,
                                 float* h_all0, float* h_all1, float* c_all0, float* c_all1, void* workspace,
                                 size_t workspace_bytes, int32_t block, void* stream);
+/* Config-3 arithmetic of one layer's BPTT (autograd of nn.LSTM, train.py:124, with bf16 operands dG / W_hh^T and fp32
+ * accumulation, cell-state gradient and outputs): stash_dg [T*B,4H] activated gates in, fp32 dG out (in place); dh_out =
+ * gradient arriving from above for steps >= dh_first ([(T-dh_first)*B, H], nullable); c_all [T*B,H] from the forward.
+ * persistent / block as in s2vt_lstm_seq_fwd_bf16; the _pair form runs two layers side by side in one launch. */
+size_t s2vt_lstm_seq_bwd_bf16_workspace_bytes(int32_t T, int32_t B, int32_t H);
+int s2vt_lstm_seq_bwd_bf16(int32_t T, int32_t B, int32_t H, const float* w_hh, const float* dh_out, int32_t dh_first,
+                           const float* c_all, float* stash_dg, void* workspace, size_t workspace_bytes,
+                           int32_t persistent, int32_t block, void* stream);
+int s2vt_lstm_seq_bwd_bf16_pair(int32_t T, int32_t B, int32_t H, const float* w_hh0, const float* w_hh1, const float* dh_out0,
+                                const float* dh_out1, int32_t dh_first, const float* c_all0, const float* c_all1,
+                                float* stash_dg0, float* stash_dg1, void* workspace, size_t workspace_bytes, int32_t block,
+                                void* stream);
 /* Recurrence schedule inside the whole-path drivers (bf16 mode): 1 = persistent kernels where the shape allows
  * (default), 0 = one launch per timestep; negative: query.  Returns the previous value. */
 int s2vt_set_recurrence_mode(int32_t persistent);

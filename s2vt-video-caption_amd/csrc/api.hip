@@ -36,21 +36,20 @@ int check_hip(hipError_t e, const char* what) {
 // host word block + an event; the NEXT entry on this process (forward, backward or s2vt_check_async_error) that finds the
 // event complete reports the error.  One step late by construction, never silent; callers that synchronise anyway
 // (loss.item()) call s2vt_check_async_error(1) right there and get it immediately.
-static int* g_err_host = nullptr;
-static hipEvent_t g_err_ev = nullptr;
-static bool g_err_pending = false;
-static int poll_async_error(bool wait) {
-    if (!g_err_pending) return 0;
+struct ErrRecord { int* host; hipEvent_t ev; bool pending; };
+static ErrRecord g_async[2] = {{nullptr, nullptr, false}, {nullptr, nullptr, false}};     // [0] forward, [1] backward
+static int read_record(ErrRecord& r, bool wait) {
+    if (!r.pending) return 0;
     if (wait) {
-        S2VT_HIP(hipEventSynchronize(g_err_ev));
+        S2VT_HIP(hipEventSynchronize(r.ev));
     } else {
-        const hipError_t q = hipEventQuery(g_err_ev);
+        const hipError_t q = hipEventQuery(r.ev);
         if (q == hipErrorNotReady) return 0;
         S2VT_HIP(q);
     }
-    g_err_pending = false;
-    const int bad_target = g_err_host[0], timed_out = g_err_host[1];
-    g_err_host[0] = g_err_host[1] = 0;
+    r.pending = false;
+    const int bad_target = r.host[0], timed_out = r.host[1];
+    r.host[0] = r.host[1] = 0;
     if (bad_target) {
         set_error("index out of range: a target id of the previous s2vt_train_forward lies outside [0, vocab_size) "
                   "(the reference raises IndexError in nn.Embedding, S2VTModel.py:71)");
@@ -62,19 +61,27 @@ static int poll_async_error(bool wait) {
     }
     return 0;
 }
-static int post_async_error(hipStream_t st, const int* dev_flags) {
-    if (!g_err_host) {
-        S2VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&g_err_host), 4 * sizeof(int), hipHostMallocDefault));
-        g_err_host[0] = g_err_host[1] = g_err_host[2] = g_err_host[3] = 0;
-        S2VT_HIP(hipEventCreateWithFlags(&g_err_ev, hipEventDisableTiming));
-    }
-    if (g_err_pending) {       // an unread record: it must not be overwritten (a step without any later entry)
-        int rc = poll_async_error(true);
+static int poll_async_error(bool wait) {
+    for (int k = 0; k < 2; ++k) {
+        int rc = read_record(g_async[k], wait);
         if (rc) return rc;
     }
-    S2VT_HIP(hipMemcpyAsync(g_err_host, dev_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
-    S2VT_HIP(hipEventRecord(g_err_ev, st));
-    g_err_pending = true;
+    return 0;
+}
+static int post_async_error(hipStream_t st, const int* dev_flags, int kind = 0) {
+    ErrRecord& r = g_async[kind];
+    if (!r.host) {
+        S2VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.host), 4 * sizeof(int), hipHostMallocDefault));
+        r.host[0] = r.host[1] = r.host[2] = r.host[3] = 0;
+        S2VT_HIP(hipEventCreateWithFlags(&r.ev, hipEventDisableTiming));
+    }
+    if (r.pending) {           // an unread record of the same kind: one whole step old, its copy has long completed
+        int rc = read_record(r, true);
+        if (rc) return rc;
+    }
+    S2VT_HIP(hipMemcpyAsync(r.host, dev_flags, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+    S2VT_HIP(hipEventRecord(r.ev, st));
+    r.pending = true;
     return 0;
 }
 
@@ -531,6 +538,19 @@ static SeqFwdBf16Args persist_fwd_args(int t0, int t1, int B, int H, float* gx_s
     return a;
 }
 
+static SeqBwdBf16Args seq_bwd_bf16_args(int T, int t0, int t1, int B, int H, const PB& wt, const PB& dgb, const float* dh_out,
+                                        int dh_first, const float* c_all, float* stash_dg, float* dc, unsigned int* sync, int* err) {
+    SeqBwdBf16Args a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.H = H; a.Kp = dgb.kpad;
+    a.T = T; a.t0 = t0; a.t1 = t1;
+    a.wtb = wt.p; a.ldwtb = wt.ld;
+    a.dgb = dgb.p; a.lddgb = dgb.ld;
+    a.dh_out = dh_out; a.dh_first = dh_first;
+    a.stash_dg = stash_dg; a.c_all = c_all; a.dc = dc;
+    a.sync = sync; a.err = err;
+    return a;
+}
 // What a forward was run with, keyed by its workspace: s2vt_train_backward must find the same arithmetic mode and
 // recurrence schedule (they decide how the workspace is carved and which images the forward left in it), otherwise it
 // refuses instead of reading a differently carved workspace.  Host-side only.
@@ -767,7 +787,40 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = grads_ready(0, sx))) return rc;
     if (!paired && (rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     const std::vector<int> bd = pipe_bounds(T, L, blk);
-    if (paired) {
+    if (bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad) {
+        // Persistent schedule, ONE stream (mirror of the forward): the launch of stage k runs the word_rnn BPTT of block k
+        // next to the vid_rnn BPTT of block k+1 (lstm_persist.hip); between two launches the dG planes / partial column sums
+        // of the blocks just finished and the dh1 GEMM of the word block run alone on the chip.
+        if ((rc = handoff(sx, st, ev++))) return rc;               // out_linear gradients of lane B first: no GEMM beside
+        const int nb = (int)bd.size() - 1;                         // a persistent launch
+        for (int k = nb - 1; k >= -1; --k) {
+            const bool hw = k >= 0, hv = k + 1 <= nb - 1;
+            SeqBwdBf16Args aw, av;
+            if (hw) aw = seq_bwd_bf16_args(T, bd[k], bd[k + 1], B, H, q.whh2T, q.dg2, w.dh2dec, L, w.c2, w.s2, w.dc2, w.psync_a, w.err + 1);
+            if (hv) av = seq_bwd_bf16_args(T, bd[k + 1], bd[k + 2], B, H, q.whh1T, q.dg1, w.dh1, 0, w.c1, w.s1, w.dc1, w.psync_b, w.err + 1);
+            {
+                ProfScope ps(st, K_STEP_BWD, (hw ? bd[k + 1] - bd[k] : 0) + (hv ? bd[k + 2] - bd[k + 1] : 0));
+                if (hw && hv) rc = lstm_seq_bwd_bf16_persist2(st, aw, &av);
+                else rc = lstm_seq_bwd_bf16_persist2(st, hw ? aw : av, nullptr);
+                if (rc) return rc;
+            }
+            if (hw) {
+                const int t0 = bd[k], t1 = bd[k + 1];
+                if ((rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, nullptr, t0 * B, &q.dg2T, t0 * B,
+                                w.colsum_a + (int64_t)(t0 * B / 64) * 4 * H)))
+                    return rc;
+                if ((rc = pgemm(la, (t1 - t0) * B, H, 4 * H, q.dg2, t0 * B, 0, q.wvT, 0, 0, w.dh1 + t0 * BH, H, ID, nullptr, false)))
+                    return rc;
+            }
+            if (hv) {
+                const int t0 = bd[k + 1], t1 = bd[k + 2];
+                if ((rc = pdual(la, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, nullptr, t0 * B, &q.dg1T, t0 * B,
+                                w.colsum_b + (int64_t)(t0 * B / 64) * 4 * H)))
+                    return rc;
+            }
+        }
+        if ((rc = handoff(st, sx, ev++))) return rc;               // lane B's parameter-gradient GEMMs need dG1
+    } else if (paired) {
         // Paired-launch schedule (see the forward): word_rnn BPTT step of block k with vid_rnn BPTT step of block k+1
         const int nb = (int)bd.size() - 1;
         for (int k = nb - 1; k >= -1; --k) {
@@ -955,7 +1008,8 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
         const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
         S2VT_REQUIRE(workspace_bytes >= w.bytes + q.bytes, "s2vt_train_backward: workspace %zu < %zu bytes",
                      workspace_bytes, w.bytes + q.bytes);
-        return train_backward_x3(d, p, feats, dlogits, g, dfeats, w, q, st);
+        int rc0 = train_backward_x3(d, p, feats, dlogits, g, dfeats, w, q, st);
+        return rc0 ? rc0 : post_async_error(st, w.err, 1);
     }
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
@@ -1478,6 +1532,88 @@ int s2vt_lstm_seq_fwd_bf16_pair(int32_t T, int32_t B, int32_t H, float* gx_stash
         SeqFwdBf16Args a1 = seq_bf16_args(w1, B, H, t0, t1, gx_stash1, n_gx, bias1, h_all1, c_all1);
         a1.err = w0.err;
         if ((rc = lstm_seq_fwd_bf16_persist2(st, seq_bf16_args(w0, B, H, t0, t1, gx_stash0, n_gx, bias0, h_all0, c_all0), &a1)))
+            return rc;
+    }
+    return 0;
+}
+
+// bf16-operand BPTT of one layer as its own entry point (kernel-level parity tests and benchmarks).
+// workspace: [err int x64][sync][W_hh^T bf16 rows][dG bf16 rows][dc]
+struct SeqBwdBf16WS { int* err; unsigned int* sync; PB wt, dgb; float* dc; size_t bytes; };
+static SeqBwdBf16WS carve_seq_bwd_bf16(int T, int B, int H, void* base) {
+    Carver c{reinterpret_cast<char*>(base), 0, 0};
+    SeqBwdBf16WS w;
+    w.err = c.take<int>(64);
+    w.sync = c.take<unsigned int>(lstm_persist_sync_bytes() / sizeof(unsigned int));
+    auto mk = [&](size_t rows, size_t k) {
+        PB b;
+        b.kpad = pad64((int)k);
+        b.ld = b.kpad;
+        b.p = c.take<unsigned short>(rows64(rows) * (size_t)b.ld);
+        return b;
+    };
+    w.wt = mk((size_t)H, (size_t)4 * H);
+    w.dgb = mk((size_t)T * B, (size_t)4 * H);
+    w.dc = c.take<float>((size_t)B * H);
+    w.bytes = align_up(c.off, 256);
+    return w;
+}
+size_t s2vt_lstm_seq_bwd_bf16_workspace_bytes(int32_t T, int32_t B, int32_t H) {
+    if (T <= 0 || B <= 0 || H <= 0) return 0;
+    return carve_seq_bwd_bf16(T, B, H, nullptr).bytes;
+}
+static int seq_bwd_bf16_prepare(hipStream_t st, const SeqBwdBf16WS& w, int T, int B, int H, const float* w_hh) {
+    int rc;
+    if ((rc = fill_zero(st, w.err, 64 * sizeof(int)))) return rc;
+    if ((rc = split_planes(st, 1, true, w_hh, H, ID, 4 * H, H, w.wt.p, w.wt.ld, w.wt.kpad, (int)rows64((size_t)H)))) return rc;
+    return zero_pad_cols_u16(st, w.dgb.p, (int64_t)T * B, w.dgb.ld, 4 * H, w.dgb.kpad);
+}
+// persistent: 0 = one launch per timestep, 1 = one persistent launch per `block` steps (0 = all T).
+// stash_dg [T*B,4H]: activated gates in, fp32 dG out; dh_out rows for steps >= dh_first (nullable).
+int s2vt_lstm_seq_bwd_bf16(int32_t T, int32_t B, int32_t H, const float* w_hh, const float* dh_out, int32_t dh_first,
+                           const float* c_all, float* stash_dg, void* workspace, size_t workspace_bytes,
+                           int32_t persistent, int32_t block, void* stream) {
+    S2VT_REQUIRE(T > 0 && B > 0 && H > 0 && w_hh && c_all && stash_dg && workspace && dh_first >= 0, "s2vt_lstm_seq_bwd_bf16: bad arguments");
+    const SeqBwdBf16WS w = carve_seq_bwd_bf16(T, B, H, workspace);
+    S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_lstm_seq_bwd_bf16: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = seq_bwd_bf16_prepare(st, w, T, B, H, w_hh))) return rc;
+    if (!persistent) return seq_bwd_bf16(st, T, 0, T, B, H, w.wt, dh_out, dh_first, c_all, stash_dg, w.dgb, w.dc);
+    S2VT_REQUIRE(lstm_seq_bwd_bf16_persist_supported(B, H, w.dgb.kpad), "s2vt_lstm_seq_bwd_bf16: shape not supported by the persistent kernel");
+    const int blk = block > 0 ? block : T;
+    for (int t1 = T; t1 > 0; t1 -= blk) {
+        const int t0 = (t1 - blk > 0) ? t1 - blk : 0;
+        ProfScope ps(st, K_STEP_BWD, t1 - t0);
+        if ((rc = lstm_seq_bwd_bf16_persist2(st, seq_bwd_bf16_args(T, t0, t1, B, H, w.wt, w.dgb, dh_out, dh_first, c_all, stash_dg,
+                                                                  w.dc, w.sync, w.err), nullptr)))
+            return rc;
+    }
+    return 0;
+}
+// two independent layers of one shape, every block of both in ONE persistent launch; workspace = 2 x the single-layer size
+int s2vt_lstm_seq_bwd_bf16_pair(int32_t T, int32_t B, int32_t H, const float* w_hh0, const float* w_hh1, const float* dh_out0,
+                                const float* dh_out1, int32_t dh_first, const float* c_all0, const float* c_all1,
+                                float* stash_dg0, float* stash_dg1, void* workspace, size_t workspace_bytes, int32_t block,
+                                void* stream) {
+    S2VT_REQUIRE(T > 0 && B > 0 && H > 0 && w_hh0 && w_hh1 && c_all0 && c_all1 && stash_dg0 && stash_dg1 && workspace && dh_first >= 0,
+                 "s2vt_lstm_seq_bwd_bf16_pair: bad arguments");
+    const size_t one = carve_seq_bwd_bf16(T, B, H, nullptr).bytes;
+    S2VT_REQUIRE(workspace_bytes >= 2 * one, "s2vt_lstm_seq_bwd_bf16_pair: workspace %zu < %zu bytes", workspace_bytes, 2 * one);
+    const SeqBwdBf16WS w0 = carve_seq_bwd_bf16(T, B, H, workspace);
+    const SeqBwdBf16WS w1 = carve_seq_bwd_bf16(T, B, H, reinterpret_cast<char*>(workspace) + one);
+    S2VT_REQUIRE(lstm_seq_bwd_bf16_persist_supported(B, H, w0.dgb.kpad), "s2vt_lstm_seq_bwd_bf16_pair: shape not supported by the persistent kernel");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = seq_bwd_bf16_prepare(st, w0, T, B, H, w_hh0))) return rc;
+    if ((rc = seq_bwd_bf16_prepare(st, w1, T, B, H, w_hh1))) return rc;
+    const int blk = block > 0 ? block : T;
+    for (int t1 = T; t1 > 0; t1 -= blk) {
+        const int t0 = (t1 - blk > 0) ? t1 - blk : 0;
+        ProfScope ps(st, K_STEP_BWD, 2 * (t1 - t0));
+        const SeqBwdBf16Args a1 = seq_bwd_bf16_args(T, t0, t1, B, H, w1.wt, w1.dgb, dh_out1, dh_first, c_all1, stash_dg1, w1.dc, w1.sync, w0.err);
+        if ((rc = lstm_seq_bwd_bf16_persist2(st, seq_bwd_bf16_args(T, t0, t1, B, H, w0.wt, w0.dgb, dh_out0, dh_first, c_all0, stash_dg0,
+                                                                  w0.dc, w0.sync, w0.err), &a1)))
             return rc;
     }
     return 0;

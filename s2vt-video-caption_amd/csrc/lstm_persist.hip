@@ -372,12 +372,12 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
     }
 
     // ---- loader role (each wave for itself): piece i of a chunk = rows 8i..8i+7; lane -> (row, 16-B position)
-    int lrow[4], lsrc[4];
+    // byte offset of this lane's 16 B inside the 32-row image of a chunk, relative to the chunk's first row:
+    // row (8i + lane/8) * row pitch + swizzled piece; (row >> 1) & 7 = (4i + lane/16) & 7, i.e. pieces of odd i differ by ^4
+    unsigned voff[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        lrow[i] = 8 * i + (lane >> 3);
-        lsrc[i] = ((lane & 7) ^ ((lrow[i] >> 1) & 7)) * 16;
-    }
+    for (int i = 0; i < 4; ++i)
+        voff[i] = (unsigned)((8 * i + (lane >> 3)) * (int)(p.lddgb * 2) + ((((lane & 7) ^ (lane >> 4)) ^ (4 * (i & 1))) * 16));
     unsigned char* ring = smem + wave * Q_RING;
     // ---- A-fragment read addresses: row tile rt, k half ks of a chunk: lane (m, kq) reads piece ks*4 + kq of row rt*16 + m
     unsigned fa[2][2];
@@ -440,15 +440,14 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
             acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (t < p.T - 1) {
                 const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.dgb + ((int64_t)(t + 1) * B + rbase) * p.lddgb);
-                const unsigned char* src[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) src[i] = abase + (int64_t)lrow[i] * p.lddgb * 2 + lsrc[i];
-                const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(zero);
+                // a chunk index past the end (the 64th of 63) re-reads the last chunk: its W registers are zero, and every
+                // wave issues the same number of requests, so the counted waits below are exact
 #define Q_ISSUE(J)                                                                                           \
                 {                                                                                             \
-                    const bool in = (c0 + (J)) < nch;                                                         \
+                    const int cj = (c0 + (J) < nch) ? c0 + (J) : nch - 1;                                     \
+                    const unsigned char* sb = abase + cj * 128;                                               \
                     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
-                        glds16_sc1(in ? src[i] + (c0 + (J)) * 128 : zsrc, ring + ((J) % Q_NSLOT) * 4096 + i * 1024); \
+                        glds16_sc1(sb + voff[i], ring + ((J) % Q_NSLOT) * 4096 + i * 1024);                   \
                 }
 #define Q_STEP(J, VM)                                                                                        \
                 if ((J) + 3 < 16) Q_ISSUE((J) + 3)                                                            \

@@ -238,3 +238,37 @@ def lstm_seq_fwd_bf16_pair(gx0, gx1, n_gx, bias0, bias1, w0, w1, T, B, H, block=
         if int(ws[:4].view(torch.int32)[0].item()) != 0:
             raise capi.S2VTHipError("persistent recurrence: a hand-off wait timed out (workgroups not co-resident?)")
     return (outs[0], outs[2], st0), (outs[1], outs[3], st1)
+
+
+def _check_persist_err(ws):
+    if int(ws[:4].view(torch.int32)[0].item()) != 0:
+        raise capi.S2VTHipError("persistent recurrence: a hand-off wait timed out (workgroups not co-resident?)")
+
+
+def lstm_seq_bwd_bf16(w_hh, dh_out, dh_first, c_all, gates, T, B, H, persistent=False, block=0):
+    """Config-3 arithmetic of one layer's BPTT: returns fp32 dG [T*B,4H] (`gates` is left untouched)."""
+    lib = capi.load()
+    dev = w_hh.device
+    dg = _f32c(gates, "gates").clone()
+    with torch.cuda.device(dev):
+        nbytes = lib.s2vt_lstm_seq_bwd_bf16_workspace_bytes(T, B, H)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        capi.check(lib.s2vt_lstm_seq_bwd_bf16(T, B, H, _ptr(_f32c(w_hh, "w_hh")), _ptr(dh_out), int(dh_first), _ptr(_f32c(c_all, "c_all")),
+                                              _ptr(dg), _ptr(ws), nbytes, int(persistent), int(block), _stream(dev)),
+                   "s2vt_lstm_seq_bwd_bf16")
+        _check_persist_err(ws)
+    return dg
+
+
+def lstm_seq_bwd_bf16_pair(w0, w1, dh0, dh1, dh_first, c0, c1, gates0, gates1, T, B, H, block=0):
+    lib = capi.load()
+    dev = w0.device
+    dg0, dg1 = _f32c(gates0, "gates0").clone(), _f32c(gates1, "gates1").clone()
+    with torch.cuda.device(dev):
+        nbytes = 2 * lib.s2vt_lstm_seq_bwd_bf16_workspace_bytes(T, B, H)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+        capi.check(lib.s2vt_lstm_seq_bwd_bf16_pair(T, B, H, _ptr(_f32c(w0, "w0")), _ptr(_f32c(w1, "w1")), _ptr(dh0), _ptr(dh1),
+                                                   int(dh_first), _ptr(_f32c(c0, "c0")), _ptr(_f32c(c1, "c1")), _ptr(dg0), _ptr(dg1),
+                                                   _ptr(ws), nbytes, int(block), _stream(dev)), "s2vt_lstm_seq_bwd_bf16_pair")
+        _check_persist_err(ws)
+    return dg0, dg1

@@ -340,3 +340,88 @@ def test_persistent_bf16_recurrence_two_layers_one_launch(lib):
         for x, y in zip(got, solo):
             assert torch.equal(x, y)
         _check_seq_bf16_teacher_forced(*got, gx, n_gx, b, w, T, B, H)
+
+
+def _bptt_bf16_reference(w_hh, dh_out, dh_first, c_all, gates, T, B, H):
+    """fp64 BPTT with the kernels' operand rounding: W_hh and the dG fed to the next (earlier) step rounded to bf16."""
+    wb = _bf16r(w_hh.cpu())                       # [4H, H]
+    c_all, gates = c_all.cpu().double(), gates.cpu().double()
+    dh_out = dh_out.cpu().double() if dh_out is not None else None
+    dG = torch.zeros(T * B, 4 * H, dtype=torch.float64)
+    dc = torch.zeros(B, H, dtype=torch.float64)
+    nxt = None
+    for t in range(T - 1, -1, -1):
+        dh = torch.zeros(B, H, dtype=torch.float64)
+        if nxt is not None:
+            dh += _bf16r(nxt.float()) @ wb
+        if dh_out is not None and t >= dh_first:
+            dh += dh_out[(t - dh_first) * B:(t - dh_first + 1) * B]
+        i, f, g, o = gates[t * B:(t + 1) * B].chunk(4, dim=1)
+        c = c_all[t * B:(t + 1) * B]
+        cp = c_all[(t - 1) * B:t * B] if t else torch.zeros_like(c)
+        tc = torch.tanh(c)
+        dct = dh * o * (1 - tc * tc) + dc
+        nxt = torch.cat([dct * g * i * (1 - i), dct * cp * f * (1 - f), dct * i * (1 - g * g), dh * tc * o * (1 - o)], dim=1)
+        dG[t * B:(t + 1) * B] = nxt
+        dc = dct * f
+    return dG
+
+
+def _bptt_inputs(T, B, H, seed):
+    w = _r(4 * H, H, seed=seed, scale=H ** -0.5)
+    gates = torch.sigmoid(_r(T * B, 4 * H, seed=seed + 1))
+    gates[:, 2 * H:3 * H] = torch.tanh(_r(T * B, H, seed=seed + 2))
+    c_all = _r(T * B, H, seed=seed + 3, scale=0.7)
+    return w, gates, c_all
+
+
+@pytest.mark.parametrize("T,B,H,dh_first", [(3, 37, 1000, 1), (4, 129, 1000, 0), (5, 5, 72, 2)])
+def test_bf16_bptt_step_kernels_h1000_odd_batch(lib, T, B, H, dh_first):
+    """lstm_step_bwd_bf16_kernel at H = 1000 (k = 4000 padded to 4032) and ragged batches against fp64 math on
+    bf16-rounded operands.  Bound: a bf16 re-rounding flip of one dG element (2^-9 relative) seen through W (|w| ~ 0.03)."""
+    from s2vt_video_caption_amd import ops
+    w, gates, c_all = _bptt_inputs(T, B, H, 50)
+    dh = _r((T - dh_first) * B, H, seed=59, scale=0.1)
+    got = ops.lstm_seq_bwd_bf16(w.to(DEV), dh.to(DEV), dh_first, c_all.to(DEV), gates.to(DEV), T, B, H).cpu().double()
+    ref = _bptt_bf16_reference(w, dh, dh_first, c_all, gates, T, B, H)
+    assert (got - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-7
+
+
+@pytest.mark.parametrize("T,B,H,dh_first,block", [(6, 32, 128, 2, 0), (7, 128, 1000, 0, 3), (5, 256, 1000, 1, 0), (9, 96, 520, 3, 4)])
+def test_persistent_bf16_bptt(lib, T, B, H, dh_first, block):
+    """lstm_seq_bwd_bf16_persist_kernel against the fp64 reference, the launch-per-timestep kernels, and itself (bitwise)."""
+    from s2vt_video_caption_amd import ops
+    w, gates, c_all = _bptt_inputs(T, B, H, 60)
+    dh = _r((T - dh_first) * B, H, seed=69, scale=0.1)
+    args = (w.to(DEV), dh.to(DEV), dh_first, c_all.to(DEV), gates.to(DEV), T, B, H)
+    got = ops.lstm_seq_bwd_bf16(*args, persistent=True, block=block)
+    again = ops.lstm_seq_bwd_bf16(*args, persistent=True, block=block)
+    assert torch.equal(got, again)
+    ref = _bptt_bf16_reference(w, dh, dh_first, c_all, gates, T, B, H)
+    scale = ref.abs().max().item()
+    assert (got.cpu().double() - ref).abs().max().item() < 2e-3 * scale + 1e-7
+    per_step = ops.lstm_seq_bwd_bf16(*args, persistent=False)
+    assert (got - per_step).abs().max().item() < 2e-3 * scale + 1e-7
+
+
+def test_persistent_bf16_bptt_two_layers_one_launch_under_load(lib):
+    from s2vt_video_caption_amd import ops
+    T, B, H, dh_first = 24, 256, 1000, 4
+    ins = [_bptt_inputs(T, B, H, 70 + 10 * k) for k in range(2)]
+    dhs = [_r((T - dh_first) * B, H, seed=79 + k, scale=0.1) for k in range(2)]
+    dev = [tuple(x.to(DEV) for x in i) for i in ins]
+    ddh = [d.to(DEV) for d in dhs]
+    solo = [ops.lstm_seq_bwd_bf16(dev[k][0], ddh[k], dh_first, dev[k][2], dev[k][1], T, B, H, persistent=True, block=8) for k in range(2)]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.randn(32 * 1024 * 1024, device=DEV)
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            big = big * 1.0001 + 1.0
+    pair = ops.lstm_seq_bwd_bf16_pair(dev[0][0], dev[1][0], ddh[0], ddh[1], dh_first, dev[0][2], dev[1][2], dev[0][1], dev[1][1],
+                                      T, B, H, block=8)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(pair[k], solo[k])
+        ref = _bptt_bf16_reference(ins[k][0], dhs[k], dh_first, ins[k][2], ins[k][1], T, B, H)
+        assert (pair[k].cpu().double() - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-7

@@ -42,3 +42,25 @@ for B in (256, 128, 64):
                   (B, block, ms2, ms2 / T * 1e3, (by + s * 4 * H * H + s * B * H) / (ms2 * 1e-3 / T) / 1e12), flush=True)
         print("B=%d persistent=%s block=%d: %.3f ms per layer pass (HIP events), %.2f us/step, %.2f TB/s (8d bytes)" %
               (B, persistent, block, dt * 1e3, dt / T * 1e6, by / (dt / T) / 1e12), flush=True)
+
+# ---- BPTT: one launch per timestep vs persistent (single layer, and two layers in one launch)
+print("---- BPTT", flush=True)
+for B in (256, 64):
+    g = torch.Generator().manual_seed(2)
+    w = (torch.randn(4 * H, H, generator=g) * H ** -0.5).to(DEV)
+    gates = torch.sigmoid(torch.randn(T * B, 4 * H, generator=g)).to(DEV)
+    c_all = (torch.randn(T * B, H, generator=g) * 0.7).to(DEV)
+    dh = (torch.randn(T * B, H, generator=g) * 0.1).to(DEV)
+    lib = capi.load()
+    for name, fn in (("per-step launches", lambda: ops.lstm_seq_bwd_bf16(w, dh, 0, c_all, gates, T, B, H, persistent=False)),
+                     ("persistent block=32", lambda: ops.lstm_seq_bwd_bf16(w, dh, 0, c_all, gates, T, B, H, persistent=True, block=32)),
+                     ("persistent two layers one launch block=32",
+                      lambda: ops.lstm_seq_bwd_bf16_pair(w, w, dh, dh, 0, c_all, c_all, gates, gates, T, B, H, block=32))):
+        for rep in range(3):
+            lib.s2vt_prof_reset()
+            lib.s2vt_prof_enable(1)
+            fn()
+            torch.cuda.synchronize()
+            lib.s2vt_prof_enable(0)
+            ms, n = capi.prof_read(2)
+        print("B=%d BPTT %s: %.3f ms, %.2f us per layer step (%d layer steps)" % (B, name, ms, ms * 1e3 / max(n, 1), n), flush=True)
