@@ -296,9 +296,11 @@ def main():
             e = pmc.get(kernel)
             return int(e["hbm_bytes_per_launch"]) if e and "hbm_bytes_per_launch" in e else None
 
-        persist = bf and bool(lib.s2vt_set_recurrence_mode(-1))
+        rmode = lib.s2vt_set_recurrence_mode(-1)
+        persist_bf16 = bf and rmode >= 1           # the timed configuration runs the persistent bf16 recurrence kernels
+        persist_f32 = (not bf) and x3 and rmode >= 2
 
-        def rooflines(pr, how):
+        def rooflines(pr, how, persist):
             gemm_ms, gemm_n = pr["gemm"]
             sf_ms, sb_ms = pr["step_fwd"][0], pr["step_bwd"][0]
             gemm_tf = gflop / gemm_ms                 # GFLOP / ms = TFLOP/s
@@ -320,7 +322,7 @@ def main():
                   "algorithmic_bytes_or_flops_per_launch": round(gflop * 1e9 / max(gemm_n, 1)),
                   "algorithmic_gflop_per_step": round(gflop, 1), "timing": how, "note": gnote}
             if persist:
-                fk = "lstm_seq_fwd_bf16_persist_kernel"
+                fk = "lstm_seq_fwd_bf16_persist_kernel" if bf else "lstm_seq_fwd_f32_persist_kernel"
                 fnote = ("PERSISTENT-WEIGHTS kernel: one launch runs a block of timesteps of BOTH layers with every W_hh slice "
                          "resident in registers, so W is not re-streamed and the fraction may exceed 1 (SURVEY.md §8(d)); "
                          "achieved = §8(d) bytes of a (vid, word) timestep pair / 2 over the average per-layer timestep = launch "
@@ -329,7 +331,10 @@ def main():
                 fk = "lstm_step_fwd_bf16_kernel" if bf else "lstm_step_fwd_kernel"
                 fnote = ("bytes per SURVEY.md §8(d) incl. W_ih although the x-part is hoisted into a batched GEMM; avg over vid+word "
                          "launches, loop-bracketed events (includes launch gaps)")
-            bk = "lstm_step_bwd_bf16_kernel" if bf else "lstm_step_bwd_kernel"
+            if persist:
+                bk = "lstm_seq_bwd_bf16_persist_kernel" if bf else "lstm_seq_bwd_f32_persist_kernel"
+            else:
+                bk = "lstm_step_bwd_bf16_kernel" if bf else "lstm_step_bwd_kernel"
             rs = {"kernel": fk, "bound": "hbm", "achieved": round(step_gbs, 1),
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
                   "traffic": traffic(fk), "avg_launch_us": round(step_us, 3), "launches_per_step": 2 * T,
@@ -346,18 +351,19 @@ def main():
         alone = profile()
         lib.s2vt_set_pipeline_block(prev_blk)
         log("profiled steps done (pipeline block %d)" % prev_blk)
-        roof_gemm, roof_step, roof_bstep = rooflines(live, "live, layers pipelined (block %d)" % prev_blk)
-        roof_gemm_alone, roof_step_alone, roof_bstep_alone = rooflines(alone, "pipeline off: every kernel alone on the GPU")
+        roof_gemm, roof_step, roof_bstep = rooflines(live, "live, layers pipelined (block %d)" % prev_blk, persist_bf16 or persist_f32)
+        # pipeline off = one launch per timestep, every kernel alone on the GPU (the persistent kernels need the block schedule)
+        roof_gemm_alone, roof_step_alone, roof_bstep_alone = rooflines(alone, "pipeline off: launch per timestep, every kernel alone on the GPU", False)
         gname = roof_gemm["kernel"]
         fam = {gname: live["gemm"][0], roof_step["kernel"]: live["step_fwd"][0],
                roof_bstep["kernel"]: live["step_bwd"][0], "ce": live["ce"][0]}
-        fam_alone = {gname: alone["gemm"][0], roof_step["kernel"]: alone["step_fwd"][0],
-                     roof_bstep["kernel"]: alone["step_bwd"][0], "ce": alone["ce"][0]}
+        fam_alone = {gname: alone["gemm"][0], roof_step_alone["kernel"]: alone["step_fwd"][0],
+                     roof_bstep_alone["kernel"]: alone["step_bwd"][0], "ce": alone["ce"][0]}
         # The headline roofline is the fused LSTM TIMESTEP (forward): it is the kernel north_star puts its target on, and the
         # timestep family (forward + BPTT) is the largest share of the kernel time of a step (the batched GEMMs are second).
         roofline = dict(roof_step)
-        roofline["family_ms_per_step"] = {"timestep_fwd+bwd": round(fam_alone[roof_step["kernel"]] + fam_alone[roof_bstep["kernel"]], 3),
-                                          "batched_gemm": round(fam_alone[gname], 3)}
+        roofline["family_ms_per_step"] = {"timestep_fwd+bwd": round(fam[roof_step["kernel"]] + fam[roof_bstep["kernel"]], 3),
+                                          "batched_gemm": round(fam[gname], 3)}
 
         # ---- greedy decode captions/s (one mode='test' call per measurement) + its out_linear/argmax kernel
         Bd = args.decode_batch or 128        # BASELINE configs[4]: inference at B=128

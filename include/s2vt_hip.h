@@ -223,9 +223,26 @@ int s2vt_lstm_seq_bwd_bf16_pair(int32_t T, int32_t B, int32_t H, const float* w_
                                 const float* dh_out1, int32_t dh_first, const float* c_all0, const float* c_all1,
                                 float* stash_dg0, float* stash_dg1, void* workspace, size_t workspace_bytes, int32_t block,
                                 void* stream);
-/* Recurrence schedule inside the whole-path drivers (bf16 mode): 1 = persistent kernels where the shape allows
- * (default), 0 = one launch per timestep; negative: query.  Returns the previous value. */
-int s2vt_set_recurrence_mode(int32_t persistent);
+/* Recurrence schedule inside the whole-path train drivers: 0 = one launch per timestep; 1 (default) = persistent
+ * kernels for the bf16 configuration (gemm mode 1) where the shape allows, launch per timestep for fp32; 2 = persistent
+ * kernels for fp32 as well (measured slower at B = 64, see lstm_persist_f32.hip).  Negative: query.  Returns the
+ * previous mode. */
+int s2vt_set_recurrence_mode(int32_t mode);
+
+/* fp32 persistent recurrence (lstm_persist_f32.hip): the same computation as s2vt_lstm_seq_fwd / s2vt_lstm_seq_bwd (exact
+ * fp32 products on the matrix cores) with ONE launch per `block` timesteps (0 = all T) and each compute unit's slice of
+ * W_hh / W_hh^T resident in registers.  Layer 1 pointers may all be null (one layer); otherwise both layers share every
+ * launch.  gx_stash: gate input in, activated gates out (in place); stash_dg: activated gates in, dG out (in place).
+ * workspace (s2vt_lstm_persist_workspace_bytes): word 0 (int32) is set to 1 if a hand-off wait timed out. */
+size_t s2vt_lstm_persist_workspace_bytes(void);
+int s2vt_lstm_seq_fwd_persist(int32_t T, int32_t B, int32_t H, float* gx_stash0, float* gx_stash1, int32_t n_gx,
+                              const float* bias0, const float* bias1, const float* w_hh0, const float* w_hh1, float* h_all0,
+                              float* h_all1, float* c_all0, float* c_all1, int32_t block, void* workspace,
+                              size_t workspace_bytes, void* stream);
+int s2vt_lstm_seq_bwd_persist(int32_t T, int32_t B, int32_t H, const float* w_hh0, const float* w_hh1, const float* dh_out0,
+                              const float* dh_out1, int32_t dh_first, const float* c_all0, const float* c_all1, float* stash_dg0,
+                              float* stash_dg1, float* w_hh_t0, float* w_hh_t1, float* dc0, float* dc1, int32_t block,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* One greedy decode step's out_linear + argmax (S2VTModel.py:95-96,105-106): packed[b] (zeroed by the caller)
  * receives max over v of (ordered(logit) << 32 | (0xFFFFFFFF - v)); token = 0xFFFFFFFF - low 32 bits. */

@@ -80,6 +80,11 @@ SIGNATURES = {
                                          c_size_t, c_int32, c_int32, c_void_p]),
     "s2vt_lstm_seq_bwd_bf16_pair": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
+    "s2vt_lstm_persist_workspace_bytes": (c_size_t, []),
+    "s2vt_lstm_seq_fwd_persist": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 8 +
+                                  [c_int32, c_void_p, c_size_t, c_void_p]),
+    "s2vt_lstm_seq_bwd_persist": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32] +
+                                  [c_void_p] * 8 + [c_int32, c_void_p, c_size_t, c_void_p]),
     "s2vt_set_recurrence_mode": (c_int32, [c_int32]),
     "s2vt_decode_step_argmax": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5),
     "s2vt_set_gemm_mode": (c_int32, [c_int32]),

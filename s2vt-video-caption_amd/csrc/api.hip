@@ -15,6 +15,10 @@
 namespace s2vt {
 
 static thread_local char g_err[512] = "";
+#ifdef S2VT_EXPERIMENT_STAMPS
+static unsigned long long* g_xstamps = nullptr;     // timing experiments only (experiment.h)
+static int g_xstamp_block = 0;
+#endif
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -514,13 +518,20 @@ static int seq_bwd_bf16(hipStream_t st, int T, int t0, int t1, int B, int H, con
     return 0;
 }
 
-// Recurrence schedule of the bf16 timestep kernels: 1 = one persistent launch per block of timesteps (lstm_persist.hip,
-// W_hh slice resident per CU) where the shape allows it, 0 = one launch per timestep (lstm_bf16.hip).
+// Recurrence schedule of the train drivers: 0 = one launch per timestep (lstm.hip / lstm_bf16.hip); 1 (default) = one
+// persistent launch per block of timesteps with the W_hh slices resident per CU (lstm_persist.hip) for the bf16
+// configuration, launch per timestep for fp32; 2 = persistent kernels for fp32 as well (lstm_persist_f32.hip).
+// Why fp32 is not the default: its contraction runs on the exact-fp32 MFMA (1/16 of the bf16 rate) and is MFMA-bound
+// inside the persistent kernel (4.6 us of a 8.6-us timestep at B = 64), two co-resident layers share that pipe, and the
+// one-stream persistent schedule gives up the overlap of the batched GEMMs with the recurrence: measured at config 2
+// 13.4 ms per step against 12.8 with launches per timestep (22.0 against 22.7 at B = 128).
 static int g_persist = -1;
-static bool persist_on() {
-    if (g_persist < 0) { const char* e = getenv("S2VT_PERSIST"); g_persist = e ? (atoi(e) != 0) : 1; }
-    return g_persist != 0;
+static int persist_mode() {
+    if (g_persist < 0) { const char* e = getenv("S2VT_PERSIST"); g_persist = e ? atoi(e) : 1; if (g_persist < 0 || g_persist > 2) g_persist = 1; }
+    return g_persist;
 }
+static bool persist_on() { return persist_mode() >= 1; }
+static bool persist_f32_on() { return persist_mode() >= 2; }
 static bool persist_fwd_ok(int B, int H, const PB& wb, const PB& hb) {
     return persist_on() && lstm_seq_fwd_bf16_persist_supported(B, H, hb.kpad) && hb.kpad == wb.kpad;
 }
@@ -551,6 +562,31 @@ static SeqBwdBf16Args seq_bwd_bf16_args(int T, int t0, int t1, int B, int H, con
     a.sync = sync; a.err = err;
     return a;
 }
+static SeqFwdF32Args persist_fwd_f32_args(int t0, int t1, int B, int H, float* gx_stash, int n_gx, const float* bias,
+                                          const float* w_hh, float* h_all, float* c_all, unsigned int* sync, int* err) {
+    SeqFwdF32Args a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.H = H; a.t0 = t0; a.t1 = t1; a.n_gx = n_gx;
+    a.w_hh = w_hh; a.ldw = H;
+    a.h_all = h_all; a.gx_stash = gx_stash; a.bias = bias; a.c_all = c_all;
+    a.sync = sync; a.err = err;
+#ifdef S2VT_EXPERIMENT_STAMPS
+    a.stamps = g_xstamps; a.stamp_block = g_xstamp_block;
+#endif
+    return a;
+}
+static SeqBwdF32Args persist_bwd_f32_args(int T, int t0, int t1, int B, int H, const float* w_hh_t, const float* dh_out,
+                                          int dh_first, const float* c_all, float* stash_dg, float* dc, unsigned int* sync, int* err) {
+    SeqBwdF32Args a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.H = H; a.T = T; a.t0 = t0; a.t1 = t1;
+    a.w_hh_t = w_hh_t; a.ldwt = 4 * (int64_t)H;
+    a.dh_out = dh_out; a.dh_first = dh_first;
+    a.stash_dg = stash_dg; a.c_all = c_all; a.dc = dc;
+    a.sync = sync; a.err = err;
+    return a;
+}
+
 // What a forward was run with, keyed by its workspace: s2vt_train_backward must find the same arithmetic mode and
 // recurrence schedule (they decide how the workspace is carved and which images the forward left in it), otherwise it
 // refuses instead of reading a differently carved workspace.  Host-side only.
@@ -558,7 +594,7 @@ struct FwdRecord { s2vt_dims d; int gemm_mode, planes, persist; };
 static std::map<const void*, FwdRecord> g_fwd_records;
 static void record_forward(const void* ws, const s2vt_dims& d, bool planes) {
     if (g_fwd_records.size() >= 64) g_fwd_records.erase(g_fwd_records.begin());     // forwards that never ran a backward
-    g_fwd_records[ws] = FwdRecord{d, gemm_mode(), planes ? ((gemm_mode() == 1) ? 1 : 3) : 0, persist_on() ? 1 : 0};
+    g_fwd_records[ws] = FwdRecord{d, gemm_mode(), planes ? ((gemm_mode() == 1) ? 1 : 3) : 0, persist_mode()};
 }
 static int check_forward_record(const void* ws, const s2vt_dims& d, bool planes) {
     auto it = g_fwd_records.find(ws);
@@ -567,10 +603,10 @@ static int check_forward_record(const void* ws, const s2vt_dims& d, bool planes)
     g_fwd_records.erase(it);
     S2VT_REQUIRE(memcmp(&r.d, &d, sizeof(d)) == 0, "s2vt_train_backward: dims differ from the forward that filled this workspace");
     const int planes_now = planes ? ((gemm_mode() == 1) ? 1 : 3) : 0;
-    S2VT_REQUIRE(r.gemm_mode == gemm_mode() && r.planes == planes_now && r.persist == (persist_on() ? 1 : 0),
+    S2VT_REQUIRE(r.gemm_mode == gemm_mode() && r.planes == planes_now && r.persist == persist_mode(),
                  "s2vt_train_backward: the forward ran with gemm mode %d / recurrence mode %d, now %d / %d: the workspace "
                  "layout differs (do not change s2vt_set_gemm_mode / s2vt_set_recurrence_mode between a forward and its backward)",
-                 r.gemm_mode, r.persist, gemm_mode(), persist_on() ? 1 : 0);
+                 r.gemm_mode, r.persist, gemm_mode(), persist_mode());
     return 0;
 }
 
@@ -695,6 +731,38 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
         if ((rc = handoff(sx, st, ev++))) return rc;
         return pgemm(la, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
     }
+    if (!bf && blk > 0 && persist_f32_on() && lstm_seq_fwd_f32_persist_supported(B, H)) {
+        // fp32 persistent schedule (lstm_persist_f32.hip), ONE stream: stage k = vid_rnn block k next to word_rnn block k-1
+        if ((rc = handoff(sx, st, ev++))) return rc;
+        const int nb = (int)bd.size() - 1;
+        for (int k = 0; k <= nb; ++k) {
+            const bool hv = k < nb, hw = k >= 1;
+            SeqFwdF32Args av, aw;
+            if (hv) av = persist_fwd_f32_args(bd[k], bd[k + 1], B, H, w.s1, L, w.bsum1, p->vid_w_hh, w.h1, w.c1, w.psync_a, w.err + 1);
+            if (hw) aw = persist_fwd_f32_args(bd[k - 1], bd[k], B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, w.psync_b, w.err + 1);
+            {
+                ProfScope ps(st, K_STEP_FWD, (hv ? bd[k + 1] - bd[k] : 0) + (hw ? bd[k] - bd[k - 1] : 0));
+                if (hv && hw) rc = lstm_seq_fwd_f32_persist2(st, av, &aw);
+                else rc = lstm_seq_fwd_f32_persist2(st, hv ? av : aw, nullptr);
+                if (rc) return rc;
+            }
+            if (hw) {
+                const int t0 = bd[k - 1], t1 = bd[k];
+                const bool cap = t0 >= L;
+                if ((rc = pdual(la, w.h2 + t0 * BH, H, ID, (t1 - t0) * B, H, cap ? &q.h2r : nullptr, t0 * B, &q.h2T, t0 * B, nullptr)))
+                    return rc;
+            }
+            if (hv) {
+                const int t0 = bd[k], t1 = bd[k + 1];
+                const bool cap = t0 >= L;
+                if ((rc = pdual(la, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H, &q.h1, t0 * B, &q.h1T, t0 * B, nullptr))) return rc;
+                if ((rc = pgemm(la, (t1 - t0) * B, 4 * H, H, q.h1, t0 * B, 0, q.wv, 0, 0, w.s2 + t0 * B4H, 4 * H, ID,
+                                cap ? nullptr : w.bsum2, cap)))
+                    return rc;
+            }
+        }
+        return pgemm(la, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
+    }
     if (bf && persist_fwd_ok(B, H, q.whh1, q.h1) && blk > 0) {
         // Persistent schedule, ONE stream: the launch of pipeline stage k runs vid_rnn block k next to word_rnn block k-1
         // (lstm_persist.hip: two workgroups per CU, each layer's W_hh slices resident in registers); between two
@@ -787,7 +855,38 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = grads_ready(0, sx))) return rc;
     if (!paired && (rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     const std::vector<int> bd = pipe_bounds(T, L, blk);
-    if (bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad) {
+    if (!bf && blk > 0 && persist_f32_on() && lstm_seq_bwd_f32_persist_supported(B, H)) {
+        // fp32 persistent schedule, ONE stream: stage k = word_rnn BPTT of block k next to vid_rnn BPTT of block k+1
+        if ((rc = handoff(sx, st, ev++))) return rc;               // W_hh1^T and the out_linear gradients of lane B
+        const int nb = (int)bd.size() - 1;
+        for (int k = nb - 1; k >= -1; --k) {
+            const bool hw = k >= 0, hv = k + 1 <= nb - 1;
+            SeqBwdF32Args aw, av;
+            if (hw) aw = persist_bwd_f32_args(T, bd[k], bd[k + 1], B, H, w.wt2, w.dh2dec, L, w.c2, w.s2, w.dc2, w.psync_a, w.err + 1);
+            if (hv) av = persist_bwd_f32_args(T, bd[k + 1], bd[k + 2], B, H, w.wt1, w.dh1, 0, w.c1, w.s1, w.dc1, w.psync_b, w.err + 1);
+            {
+                ProfScope ps(st, K_STEP_BWD, (hw ? bd[k + 1] - bd[k] : 0) + (hv ? bd[k + 2] - bd[k + 1] : 0));
+                if (hw && hv) rc = lstm_seq_bwd_f32_persist2(st, aw, &av);
+                else rc = lstm_seq_bwd_f32_persist2(st, hw ? aw : av, nullptr);
+                if (rc) return rc;
+            }
+            if (hw) {
+                const int t0 = bd[k], t1 = bd[k + 1];
+                if ((rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, &q.dg2, t0 * B, &q.dg2T, t0 * B,
+                                w.colsum_a + (int64_t)(t0 * B / 64) * 4 * H)))
+                    return rc;
+                if ((rc = pgemm(la, (t1 - t0) * B, H, 4 * H, q.dg2, t0 * B, 0, q.wvT, 0, 0, w.dh1 + t0 * BH, H, ID, nullptr, false)))
+                    return rc;
+            }
+            if (hv) {
+                const int t0 = bd[k + 1], t1 = bd[k + 2];
+                if ((rc = pdual(la, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, (t0 < L) ? &q.dg1 : nullptr, t0 * B, &q.dg1T,
+                                t0 * B, w.colsum_b + (int64_t)(t0 * B / 64) * 4 * H)))
+                    return rc;
+            }
+        }
+        if ((rc = handoff(st, sx, ev++))) return rc;
+    } else if (bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad) {
         // Persistent schedule, ONE stream (mirror of the forward): the launch of stage k runs the word_rnn BPTT of block k
         // next to the vid_rnn BPTT of block k+1 (lstm_persist.hip); between two launches the dG planes / partial column sums
         // of the blocks just finished and the dh1 GEMM of the word block run alone on the chip.
@@ -1434,10 +1533,6 @@ int s2vt_lstm_seq_bwd(int32_t T, int32_t B, int32_t H, const float* w_hh, const 
     return seq_bwd(st, T, 0, T, B, H, w_hh_t, dh_out, dh_first, c_all, stash_dg, dc);
 }
 
-#ifdef S2VT_EXPERIMENT_STAMPS
-static unsigned long long* g_xstamps = nullptr;
-static int g_xstamp_block = 0;
-#endif
 // bf16-operand layer forward (config 3 arithmetic) as its own entry point: kernel-level parity tests and benchmarks.
 // workspace: [err int x64][sync][W_hh bf16 rows][h bf16 rows]
 struct SeqBf16WS { int* err; unsigned int* sync; PB wb, hb; size_t bytes; };
@@ -1623,10 +1718,71 @@ int s2vt_lstm_seq_bwd_bf16_pair(int32_t T, int32_t B, int32_t H, const float* w_
 extern "C" int s2vt_experiment_set_stamps(unsigned long long* buf, int block) { g_xstamps = buf; g_xstamp_block = block; return 0; }
 #endif
 
-int s2vt_set_recurrence_mode(int32_t persistent) {
-    const int prev = persist_on() ? 1 : 0;
-    if (persistent >= 0) g_persist = persistent ? 1 : 0;
+int s2vt_set_recurrence_mode(int32_t mode) {
+    const int prev = persist_mode();
+    if (mode >= 0) g_persist = mode > 2 ? 2 : mode;
     return prev;
+}
+
+// fp32 persistent recurrence as its own entry points (kernel-level parity tests and benchmarks).
+// workspace: [err int x64][sync A][sync B]
+size_t s2vt_lstm_persist_workspace_bytes(void) { return 256 + 2 * lstm_persist_sync_bytes(); }
+int s2vt_lstm_seq_fwd_persist(int32_t T, int32_t B, int32_t H, float* gx_stash0, float* gx_stash1, int32_t n_gx,
+                              const float* bias0, const float* bias1, const float* w_hh0, const float* w_hh1, float* h_all0,
+                              float* h_all1, float* c_all0, float* c_all1, int32_t block, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    S2VT_REQUIRE(T > 0 && B > 0 && H > 0 && gx_stash0 && w_hh0 && h_all0 && c_all0 && workspace && n_gx >= 0 && n_gx <= T &&
+                     (n_gx == T || bias0), "s2vt_lstm_seq_fwd_persist: bad arguments");
+    S2VT_REQUIRE(workspace_bytes >= s2vt_lstm_persist_workspace_bytes(), "s2vt_lstm_seq_fwd_persist: workspace too small");
+    S2VT_REQUIRE(lstm_seq_fwd_f32_persist_supported(B, H), "s2vt_lstm_seq_fwd_persist: shape not supported");
+    const bool two = gx_stash1 != nullptr;
+    S2VT_REQUIRE(!two || (w_hh1 && h_all1 && c_all1 && (n_gx == T || bias1)), "s2vt_lstm_seq_fwd_persist: second layer incomplete");
+    int* err = reinterpret_cast<int*>(workspace);
+    unsigned int* sa = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(workspace) + 256);
+    unsigned int* sb = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(workspace) + 256 + lstm_persist_sync_bytes());
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = fill_zero(st, err, 256))) return rc;
+    const int blk = block > 0 ? block : T;
+    for (int t0 = 0; t0 < T; t0 += blk) {
+        const int t1 = (t0 + blk < T) ? t0 + blk : T;
+        ProfScope ps(st, K_STEP_FWD, (two ? 2 : 1) * (t1 - t0));
+        const SeqFwdF32Args a0 = persist_fwd_f32_args(t0, t1, B, H, gx_stash0, n_gx, bias0, w_hh0, h_all0, c_all0, sa, err);
+        SeqFwdF32Args a1;
+        if (two) a1 = persist_fwd_f32_args(t0, t1, B, H, gx_stash1, n_gx, bias1, w_hh1, h_all1, c_all1, sb, err);
+        if ((rc = lstm_seq_fwd_f32_persist2(st, a0, two ? &a1 : nullptr))) return rc;
+    }
+    return 0;
+}
+// w_hh_t0/1 [H,4H] and dc0/1 [B,H]: scratch provided by the caller
+int s2vt_lstm_seq_bwd_persist(int32_t T, int32_t B, int32_t H, const float* w_hh0, const float* w_hh1, const float* dh_out0,
+                              const float* dh_out1, int32_t dh_first, const float* c_all0, const float* c_all1, float* stash_dg0,
+                              float* stash_dg1, float* w_hh_t0, float* w_hh_t1, float* dc0, float* dc1, int32_t block,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    S2VT_REQUIRE(T > 0 && B > 0 && H > 0 && w_hh0 && c_all0 && stash_dg0 && w_hh_t0 && dc0 && workspace && dh_first >= 0,
+                 "s2vt_lstm_seq_bwd_persist: bad arguments");
+    S2VT_REQUIRE(workspace_bytes >= s2vt_lstm_persist_workspace_bytes(), "s2vt_lstm_seq_bwd_persist: workspace too small");
+    S2VT_REQUIRE(lstm_seq_bwd_f32_persist_supported(B, H), "s2vt_lstm_seq_bwd_persist: shape not supported");
+    const bool two = stash_dg1 != nullptr;
+    S2VT_REQUIRE(!two || (w_hh1 && c_all1 && w_hh_t1 && dc1), "s2vt_lstm_seq_bwd_persist: second layer incomplete");
+    int* err = reinterpret_cast<int*>(workspace);
+    unsigned int* sa = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(workspace) + 256);
+    unsigned int* sb = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(workspace) + 256 + lstm_persist_sync_bytes());
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = fill_zero(st, err, 256))) return rc;
+    if ((rc = transpose_f32(st, w_hh0, 4 * H, H, w_hh_t0))) return rc;
+    if (two && (rc = transpose_f32(st, w_hh1, 4 * H, H, w_hh_t1))) return rc;
+    const int blk = block > 0 ? block : T;
+    for (int t1 = T; t1 > 0; t1 -= blk) {
+        const int t0 = (t1 - blk > 0) ? t1 - blk : 0;
+        ProfScope ps(st, K_STEP_BWD, (two ? 2 : 1) * (t1 - t0));
+        const SeqBwdF32Args a0 = persist_bwd_f32_args(T, t0, t1, B, H, w_hh_t0, dh_out0, dh_first, c_all0, stash_dg0, dc0, sa, err);
+        SeqBwdF32Args a1;
+        if (two) a1 = persist_bwd_f32_args(T, t0, t1, B, H, w_hh_t1, dh_out1, dh_first, c_all1, stash_dg1, dc1, sb, err);
+        if ((rc = lstm_seq_bwd_f32_persist2(st, a0, two ? &a1 : nullptr))) return rc;
+    }
+    return 0;
 }
 
 int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, const float* w_out, const float* b_out,

@@ -56,10 +56,6 @@ __device__ __forceinline__ f32x4 load4_guard(const float* base, const float* row
     // then has NO consumer before the LDS staging store, so the loads stay in flight across the MFMA phase
     // (a select on the result would pull the vmcnt wait in front of the MFMAs).
     f32x4 v;
-#if defined(S2VT_GEMM_ABLATE) && S2VT_GEMM_ABLATE == 1   // timing experiment: no global traffic
-    v = f32x4{1.f, 0.f, 0.f, 0.f};
-    return v;
-#endif
     if (VEC) {
         const bool ok = (row != nullptr) && (c < limit);
         const float* q = ok ? row + c : g_zero4;
@@ -211,11 +207,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs p) {
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
-#if defined(S2VT_GEMM_ABLATE) && S2VT_GEMM_ABLATE == 2   // timing experiment: operands read, no MFMA
-                        asm volatile("" ::"v"(a[mi][j]), "v"(b[ni][j]));
-#else
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi][j], b[ni][j], acc[mi][ni], 0, 0, 0);
-#endif
         }
     };
 

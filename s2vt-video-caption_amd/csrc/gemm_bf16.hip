@@ -97,11 +97,6 @@ __global__ __launch_bounds__(128 * WM) void gemm_bf16_nt_kernel(GemmBfArgs p) {
 
     u32x4 ra0[NPA], rb0[NPB], ra1[NPA], rb1[NPB];   // two staging sets: tiles kt+1 and kt+2 in flight
     auto load_tile = [&](int k0, u32x4 (&ra)[NPA], u32x4 (&rb)[NPB]) {
-#if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE == 1     // timing experiment: no global traffic
-        for (int i = 0; i < NPA; ++i) ra[i] = u32x4{0x3f803f80u, 0, 0, 0};
-        for (int i = 0; i < NPB; ++i) rb[i] = u32x4{0x3f803f80u, 0, 0, 0};
-        return;
-#endif
         const bool kin = k0 < kend;
 #pragma unroll
         for (int i = 0; i < NPA; ++i) {
@@ -151,13 +146,6 @@ __global__ __launch_bounds__(128 * WM) void gemm_bf16_nt_kernel(GemmBfArgs p) {
                 for (int ni = 0; ni < 2; ++ni)
                     b[pl][ni] = *reinterpret_cast<const bf16x8*>(sB + (wn * 64 + ni * 32 + li) * HROW + koff);
             }
-#if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE == 2     // timing experiment: operands staged and read, no MFMA
-#pragma unroll
-            for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi) asm volatile("" ::"v"(a[pl][mi]), "v"(b[pl][mi]));
-            if (true) continue;
-#endif
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll

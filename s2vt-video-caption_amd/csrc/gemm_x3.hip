@@ -88,9 +88,6 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
     auto request = [&](int s) {                        // stage s of this tile's k range -> ring slot s % 3
         const unsigned char* g = src + (int64_t)s * X_REC;
         unsigned char* l = ldst + (s % X_NS) * X_STAGE;
-#if defined(S2VT_X3_ABLATE) && (S2VT_X3_ABLATE == 1 || S2VT_X3_ABLATE >= 3)   // timing experiment: no global traffic
-        if (p.K > 0) return;
-#endif
         if (!loader) return;
 #pragma unroll
         for (int j = 0; j < 6; ++j) glds16(g + j * 1024, l + j * 1024);
@@ -117,17 +114,13 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
         constexpr bool MORE = decltype(more_tag)::value;
         // stage s has landed for this wave once at most the 6 requests of stage s+1 are outstanding; the barrier makes
         // that true for every wave's pieces and also says everyone is done reading slot (s+2)%3 (= stage s-1)
-#if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE == 4     // timing experiment: MFMAs only, no barrier
-#else
         if (MORE || s + 1 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
         const unsigned char* g2 = src + (int64_t)(s + 2) * X_REC;
         unsigned char* l2 = ldst + ((s + 2) % X_NS) * X_STAGE;
         if (MORE && !S2VT_X3_SPREAD) request(s + 2);
         const unsigned char* st = smem + (s % X_NS) * X_STAGE;
         bf16x8 a[3][MI], b[3][2];
-#if !defined(S2VT_X3_ABLATE) || S2VT_X3_ABLATE < 3
         // Fragment reads are issued in the order the products consume them - (a1 b1) (a0 b2) (a2 b0) - as inline asm
         // with hand-counted lgkmcnt waits: all 8 waves read right after the barrier, so the 18th read of a wave returns
         // ~1150 cycles later (144 KB through a 128 B/clk LDS) but its 6th after ~400; hipcc would wait for all 18
@@ -144,42 +137,13 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
                                         "+v"(a[PA][MI - 1]), "+v"(b[PB][0]), "+v"(b[PB][1]));                                  \
     else asm volatile("s_waitcnt lgkmcnt(" #N2 ")" : "+v"(a[PA][0]), "+v"(a[PA][1]), "+v"(b[PB][0]), "+v"(b[PB][1]));
         X3_LDA(1) X3_LDB(1) X3_LDA(0) X3_LDB(2) X3_LDA(2) X3_LDB(0)
-#endif
-#if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE >= 3     // timing experiment: MFMAs on register constants only (+ barriers)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) { a[pl][mi] = bf16x8{(short)(0x3f80 + lane + s), 1, 2, 3, 4, 5, 6, 7}; asm volatile("" : "+v"(a[pl][mi])); }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) { b[pl][ni] = bf16x8{(short)(0x3f80 + lane), 1, 2, 3, 4, 5, 6, 7}; asm volatile("" : "+v"(b[pl][ni])); }
-        }
-#endif
-#if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE == 2     // timing experiment: operands staged and read, no MFMA
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) asm volatile("" ::"v"(a[pl][mi]));
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) asm volatile("" ::"v"(b[pl][ni]));
-        }
-        if (MORE && S2VT_X3_SPREAD) request(s + 2);
-        if (p.K > 0) return;
-#endif
         // six plane products, smallest terms first; product-major order keeps 8 independent MFMAs between two
         // updates of the same accumulator.  The DMA requests of stage s+2 are spread over the MFMA groups: issuing
         // one costs the wave ~100 cycles, which a running MFMA group hides
 #define X3_PROD(PA, PB)                                                                                          \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)           \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][mi], b[PB][ni], acc[mi][ni], 0, 0, 0);
-#if defined(S2VT_X3_ABLATE) && (S2VT_X3_ABLATE == 1 || S2VT_X3_ABLATE >= 3)   // timing experiment: no global traffic
-#define X3_REQ(J)
-#else
 #define X3_REQ(J) if (MORE && S2VT_X3_SPREAD && loader) glds16(g2 + (J) * 1024, l2 + (J) * 1024);
-#endif
-#if defined(S2VT_X3_ABLATE) && S2VT_X3_ABLATE >= 3
-#define X3_WAIT(N4, N2, PA, PB)
-#endif
         X3_WAIT(12, 8, 1, 1) X3_PROD(1, 1) X3_REQ(0) X3_WAIT(6, 4, 0, 2) X3_PROD(0, 2) X3_REQ(1) X3_WAIT(0, 0, 2, 0) X3_PROD(2, 0) X3_REQ(2)
         X3_PROD(0, 1) X3_REQ(3) X3_PROD(1, 0) X3_REQ(4) X3_PROD(0, 0) X3_REQ(5)
 #undef X3_WAIT
@@ -189,7 +153,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
 #ifndef S2VT_X3_PIN
 #define S2VT_X3_PIN 1         // pin the issue order: 18 fragment reads, then 6 x (8 MFMAs, 1 DMA request)
 #endif
-#if S2VT_X3_PIN && (!defined(S2VT_X3_ABLATE) || S2VT_X3_ABLATE == 0)
+#if S2VT_X3_PIN
         __builtin_amdgcn_sched_group_barrier(0x100, 3 * (MI + 2), 0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {

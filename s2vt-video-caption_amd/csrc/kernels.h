@@ -136,6 +136,32 @@ struct SeqBwdBf16Args {
 int lstm_seq_bwd_bf16_persist_supported(int B, int H, int Kp4);
 int lstm_seq_bwd_bf16_persist2(hipStream_t stream, SeqBwdBf16Args a, const SeqBwdBf16Args* b);
 
+// ---- lstm_persist_f32.hip: persistent fp32 recurrence (config 2 arithmetic: exact-fp32 MFMA)
+struct SeqFwdF32Args {
+    int B, H;                                       // H % 8 == 0, H <= 1024
+    int t0, t1, n_gx;
+    const float* w_hh; int64_t ldw;                 // [4H][H]
+    float* h_all;                                   // [T*B][H] time-major: h_{t-1} in, h_t out (the hand-off payload)
+    float* gx_stash; const float* bias; float* c_all;
+    unsigned int* sync; int* err;
+    int RB, NS;                                     // set by the launcher
+    unsigned long long* stamps; int stamp_block;    // timing experiments only (experiment.h); null in the product
+};
+int lstm_seq_fwd_f32_persist_supported(int B, int H);
+int lstm_seq_fwd_f32_persist2(hipStream_t stream, SeqFwdF32Args a, const SeqFwdF32Args* b);
+struct SeqBwdF32Args {
+    int B, H;                                       // H % 4 == 0, H <= 1024
+    int T, t0, t1;
+    const float* w_hh_t; int64_t ldwt;              // W_hh^T [H][4H]
+    const float* dh_out; int dh_first;
+    float* stash_dg;                                // [T*B][4H]: activated gates in, dG out (in place; dG_{t+1} is the operand)
+    const float* c_all; float* dc;
+    unsigned int* sync; int* err;
+    int RB, NS;
+};
+int lstm_seq_bwd_f32_persist_supported(int B, int H);
+int lstm_seq_bwd_f32_persist2(hipStream_t stream, SeqBwdF32Args a, const SeqBwdF32Args* b);
+
 struct LogitsArgmaxArgs {
     int B, H, V;
     const float* h; int64_t ldh;

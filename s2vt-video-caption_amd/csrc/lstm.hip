@@ -9,12 +9,14 @@
 //            derivatives -> dG_t, dc_{t-1};
 //   decode   (S2VTModel.py:95-96,105-106): logits tile + first-max argmax folded into one 64-bit
 //            atomicMax per (row, tile).
-// The 4 waves of a workgroup split K in 64-wide chunks (wave w takes chunks w, w+4, ...), each
-// staging its operands through a wave-private LDS image with full-line coalesced 16-B loads and a
-// register prefetch of its next chunk, and the 4 partial tiles are summed through LDS.
-// Both operands are k-contiguous (h/dG rows, W_hh rows / W_hh^T rows), LDS row stride 68 floats:
+// The 8 waves of a workgroup split K in 32-wide chunks (wave w takes chunks w, w+8, ...), each
+// staging its operands through a wave-private LDS image with coalesced 16-B loads and a register
+// prefetch of its next two chunks, and the 8 partial tiles are summed through LDS.
+// Both operands are k-contiguous (h/dG rows, W_hh rows / W_hh^T rows), LDS row stride 36 floats:
 // 16-B aligned staging writes and conflict-free ds_read_b128 operand reads.  Within each 16-wide
 // k block lane quarter q owns k = 4q..4q+3 for both operands (fixed summation order).
+// (These are the launch-per-timestep kernels: decode, beam search, shapes the persistent kernels of
+// lstm_persist_f32.hip do not take.)
 #include "common.h"
 #include "kernels.h"
 
@@ -43,13 +45,6 @@ constexpr int NW_FWD = S2VT_NWAVE_FWD;
 constexpr int NW_BWD = S2VT_NWAVE_BWD;
 constexpr int PF = S2VT_PF;            // staging chunks in flight per wave (register prefetch depth)
 
-#ifdef S2VT_STAMPS   // timing experiment (tools/bench_step_stamps.py): 100-MHz wall-clock stamps of one wave per launch
-__device__ unsigned long long g_stamps[8192][8];
-__device__ unsigned int g_stamp_n;
-#define STAMP(i) do { if (stamp_slot >= 0) g_stamps[stamp_slot][i] = wall_clock64(); } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
 
 // Branch-free guarded 4-float load (see gemm.hip load4_guard): out-of-range accesses read a safe address and
 // are zeroed by a select, so the staging burst stays a run of independent loads.
@@ -59,10 +54,6 @@ __device__ __forceinline__ f32x4 ld4(const float* base, const float* row, int c,
     // then has NO consumer before the LDS staging store, so the loads stay in flight across the MFMA phase
     // (a select on the result would pull the vmcnt wait in front of the MFMAs).
     f32x4 v;
-#if defined(S2VT_ABLATE) && S2VT_ABLATE == 1   // timing experiment: no global traffic
-    v = f32x4{0.f, 0.f, 0.f, 0.f};
-    return v;
-#endif
     if (VEC) {
         const bool ok = (row != nullptr) && (c < limit);
         const float* q = ok ? row + c : g_zero4;
@@ -83,7 +74,7 @@ __device__ __forceinline__ f32x4 ld4(const float* base, const float* row, int c,
 template <int MT, int NT, int NA, bool VEC, int NWAVE>
 __device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const float* abase, const float* bbase,
                                              const float* const (&arow)[MT * LPT], const float* const (&brow)[NT * LPT],
-                                             int K, float* sA, float* sB, int wave, int lane, int stamp_slot = -1) {
+                                             int K, float* sA, float* sB, int wave, int lane) {
     // Wave w owns chunks w, w+NWAVE, ...; PF of them are in flight (registers) at any time.  Loads are issued
     // unconditionally (chunks past K read the zero block), so the body is straight-line code and the compiler's
     // counted vmcnt leaves the younger chunks in flight while the oldest is staged and multiplied.
@@ -101,10 +92,6 @@ __device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const flo
 #pragma unroll
         for (int i = 0; i < NT * LPT; ++i) rb[d][i] = ld4<VEC>(bbase, brow[i], k0, K);
     }
-#if defined(S2VT_ABLATE) && S2VT_ABLATE == 3   // timing experiment: launch + epilogue only
-    return;
-#endif
-    STAMP(1);
     for (int r = 0; r < n_round; ++r) {
 #pragma unroll
         for (int d = 0; d < PF; ++d) {
@@ -114,9 +101,6 @@ __device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const flo
 #pragma unroll
             for (int i = 0; i < NT * LPT; ++i) *reinterpret_cast<f32x4*>(&sB[(lrow + RPL * i) * SLD + kq]) = rb[d][i];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#ifdef S2VT_STAMPS
-            if (r == 0 && d == 0) STAMP(2);      // first chunk has arrived and is staged
-#endif
             __builtin_amdgcn_wave_barrier();
             {   // refill this stage with the chunk PF rounds ahead
                 const int k0 = (wave + ((r + 1) * PF + d) * NWAVE) * KC + kq;
@@ -140,12 +124,8 @@ __device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const flo
                     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < NT; ++ni)
-#if defined(S2VT_ABLATE) && S2VT_ABLATE == 2   // timing experiment: operands staged and read, no MFMA
-                            asm volatile("" ::"v"(a[mi][j]), "v"(b[ni][j]));
-#else
                             acc[mi][ni][j & (NA - 1)] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                 a[mi][j], b[ni][j], acc[mi][ni][j & (NA - 1)], 0, 0, 0);
-#endif
             }
         }
     }
@@ -221,18 +201,6 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
     if (!xcd_tile((p.H + UN - 1) / UN, (p.B + TM - 1) / TM, tx, ty, bid)) return;
     const int b0 = ty * TM, u0 = tx * UN;
     const int lrow = lane / LPR;
-#ifdef S2VT_STAMPS
-    int stamp_slot = -1;
-    if (bid == 8 && tid == 0) {      // entry time is taken BEFORE the slot atomic (its round trip is ~1-2 us)
-        const unsigned long long t_entry = wall_clock64();
-        stamp_slot = (int)atomicAdd(&g_stamp_n, 1u);
-        if (stamp_slot >= 8192) stamp_slot = -1;
-        if (stamp_slot >= 0) g_stamps[stamp_slot][0] = t_entry;
-        if (stamp_slot >= 0) g_stamps[stamp_slot][7] = wall_clock64();     // after the atomic returned
-    }
-#else
-    constexpr int stamp_slot = -1;
-#endif
 
     f32x4 acc[MT][NT][NA];
 #pragma unroll
@@ -273,9 +241,8 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
             const int r = lrow + RPL * i, g = r / UN, u = u0 + r % UN;
             brow[i] = (u < p.H) ? p.w_hh + ((int64_t)g * p.H + u) * p.ldw : nullptr;
         }
-        wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.h_prev, p.w_hh, arow, brow, p.H, sA, sB, wave, lane, stamp_slot);
+        wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.h_prev, p.w_hh, arow, brow, p.H, sA, sB, wave, lane);
     }
-    STAMP(3);
     if (p.x2) {
         const float* arow[MT * LPT];
         const float* brow[NT * LPT];
@@ -301,11 +268,9 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
     }
 
     __syncthreads();
-    STAMP(4);
     float* red = smem;
     write_partials<MT, NT, NA>(acc, red, wave, lane);
     __syncthreads();
-    STAMP(5);
 
     if (evalid) {
         const int bl = ebl, u = eu, b = eb, unit = eunit;
@@ -329,24 +294,8 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
             st[(int64_t)3 * p.H] = og;
         }
     }
-#ifdef S2VT_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(6);
-#endif
 }
 
-#ifdef S2VT_STAMPS
-extern "C" int s2vt_debug_stamps(unsigned long long* out, int max_slots, int reset) {
-    unsigned int n = 0;
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_stamp_n), sizeof(n));
-    if ((int)n > max_slots) n = max_slots;
-    if (n > 8192) n = 8192;
-    if (out && n) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * 8 * sizeof(unsigned long long));
-    if (reset) { unsigned int z = 0; hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_n), &z, sizeof(z)); }
-    return (int)n;
-}
-#endif
 
 static bool step_fwd_vec(const StepFwdArgs& a) {
     // vector path: 16-B aligned rows whose length is a multiple of 4 floats, for every operand in use

@@ -272,3 +272,55 @@ def lstm_seq_bwd_bf16_pair(w0, w1, dh0, dh1, dh_first, c0, c1, gates0, gates1, T
                                                    _ptr(ws), nbytes, int(block), _stream(dev)), "s2vt_lstm_seq_bwd_bf16_pair")
         _check_persist_err(ws)
     return dg0, dg1
+
+
+def _persist_ws(dev):
+    lib = capi.load()
+    n = lib.s2vt_lstm_persist_workspace_bytes()
+    return torch.zeros(n, dtype=torch.uint8, device=dev), n
+
+
+def lstm_seq_fwd_persist(T, B, gx, n_gx, bias, w_hh, block=0, second=None):
+    """fp32 layer forward with the persistent kernel: returns (h_all, c_all, gates).  `second` = (gx, bias, w_hh) of another
+    layer of the same shape that shares every launch: then a pair of result tuples is returned."""
+    lib = capi.load()
+    w_hh = _f32c(w_hh, "w_hh")
+    H = w_hh.shape[1]
+    dev = w_hh.device
+    with torch.cuda.device(dev):
+        ws, n = _persist_ws(dev)
+        sets = []
+        for g, b, w in [(gx, bias, w_hh)] + ([second] if second is not None else []):
+            stash = torch.empty(T * B, 4 * H, dtype=torch.float32, device=dev)
+            if n_gx:
+                stash[:n_gx * B].copy_(g)
+            sets.append((stash, b, _f32c(w, "w_hh"), torch.empty(T * B, H, dtype=torch.float32, device=dev),
+                         torch.empty(T * B, H, dtype=torch.float32, device=dev)))
+        a, b2 = sets[0], (sets[1] if len(sets) > 1 else (None,) * 5)
+        capi.check(lib.s2vt_lstm_seq_fwd_persist(T, B, H, _ptr(a[0]), _ptr(b2[0]), int(n_gx), _ptr(a[1]), _ptr(b2[1]), _ptr(a[2]),
+                                                 _ptr(b2[2]), _ptr(a[3]), _ptr(b2[3]), _ptr(a[4]), _ptr(b2[4]), int(block),
+                                                 _ptr(ws), n, _stream(dev)), "s2vt_lstm_seq_fwd_persist")
+        _check_persist_err(ws)
+    outs = [(x[3], x[4], x[0]) for x in sets]
+    return outs[0] if second is None else tuple(outs)
+
+
+def lstm_seq_bwd_persist(T, B, w_hh, dh_out, dh_first, c_all, gates, block=0, second=None):
+    """fp32 BPTT with the persistent kernel: returns dG (`gates` untouched).  `second` = (w_hh, dh_out, c_all, gates)."""
+    lib = capi.load()
+    w_hh = _f32c(w_hh, "w_hh")
+    H = w_hh.shape[1]
+    dev = w_hh.device
+    with torch.cuda.device(dev):
+        ws, n = _persist_ws(dev)
+        sets = []
+        for w, dh, c, g in [(w_hh, dh_out, c_all, gates)] + ([second] if second is not None else []):
+            sets.append((_f32c(w, "w_hh"), dh, _f32c(c, "c_all"), _f32c(g, "gates").clone(),
+                         torch.empty(H, 4 * H, dtype=torch.float32, device=dev), torch.empty(B, H, dtype=torch.float32, device=dev)))
+        a, b2 = sets[0], (sets[1] if len(sets) > 1 else (None,) * 6)
+        capi.check(lib.s2vt_lstm_seq_bwd_persist(T, B, H, _ptr(a[0]), _ptr(b2[0]), _ptr(a[1]), _ptr(b2[1]), int(dh_first), _ptr(a[2]),
+                                                 _ptr(b2[2]), _ptr(a[3]), _ptr(b2[3]), _ptr(a[4]), _ptr(b2[4]), _ptr(a[5]), _ptr(b2[5]),
+                                                 int(block), _ptr(ws), n, _stream(dev)), "s2vt_lstm_seq_bwd_persist")
+        _check_persist_err(ws)
+    outs = [x[3] for x in sets]
+    return outs[0] if second is None else tuple(outs)

@@ -425,3 +425,105 @@ def test_persistent_bf16_bptt_two_layers_one_launch_under_load(lib):
         assert torch.equal(pair[k], solo[k])
         ref = _bptt_bf16_reference(ins[k][0], dhs[k], dh_first, ins[k][2], ins[k][1], T, B, H)
         assert (pair[k].cpu().double() - ref).abs().max().item() < 2e-3 * ref.abs().max().item() + 1e-7
+
+
+# ------------------------------------------------------------------------------------- fp32 persistent recurrence
+def _cell_seq_fp64(gx, n_gx, bias, w, T, B, H):
+    gx, bias, w = gx.double(), bias.double(), w.double()
+    h = torch.zeros(B, H, dtype=torch.float64)
+    c = torch.zeros(B, H, dtype=torch.float64)
+    hs, cs, gs = [], [], []
+    for t in range(T):
+        pre = (gx[t * B:(t + 1) * B] if t < n_gx else bias[None, :]) + h @ w.t()
+        i, f, g, o = pre.chunk(4, dim=1)
+        i, f, g, o = torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)
+        c = f * c + i * g
+        h = o * torch.tanh(c)
+        hs.append(h); cs.append(c); gs.append(torch.cat([i, f, g, o], dim=1))
+    return torch.cat(hs), torch.cat(cs), torch.cat(gs)
+
+
+@pytest.mark.parametrize("T,B,H,n_gx,block", [(6, 32, 128, 4, 0), (7, 64, 1000, 4, 3), (5, 128, 1000, 3, 0), (9, 96, 520, 9, 4),
+                                              (4, 256, 1000, 2, 0), (5, 32, 8, 5, 2)])
+def test_persistent_fp32_recurrence(lib, T, B, H, n_gx, block):
+    """lstm_seq_fwd_f32_persist_kernel: exact-fp32 MFMA, W_hh slice resident per CU, cross-workgroup hand-off of fp32 h_t.
+    Against fp64 cell math (fp32 rounding only: 2e-6 as for the launch-per-timestep kernel), the launch-per-timestep
+    kernels, and itself bit for bit."""
+    from s2vt_video_caption_amd import ops
+    gx, bias, w = _r(n_gx * B, 4 * H, seed=81), _r(4 * H, seed=82, scale=0.3), _r(4 * H, H, seed=83, scale=H ** -0.5)
+    args = (T, B, gx.to(DEV), n_gx, bias.to(DEV), w.to(DEV))
+    h1, c1, g1 = ops.lstm_seq_fwd_persist(*args, block=block)
+    h2, c2, g2 = ops.lstm_seq_fwd_persist(*args, block=block)
+    assert torch.equal(h1, h2) and torch.equal(c1, c2) and torch.equal(g1, g2)
+    rh, rc, rg = _cell_seq_fp64(gx, n_gx, bias, w, T, B, H)
+    assert (h1.cpu().double() - rh).abs().max().item() < 2e-6
+    assert (c1.cpu().double() - rc).abs().max().item() < 4e-6
+    assert (g1.cpu().double() - rg).abs().max().item() < 2e-6
+    h0, c0, g0 = ops.lstm_seq_fwd(*args, want_stash=True)
+    assert (h1 - h0).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("T,B,H,dh_first,block", [(6, 32, 128, 2, 0), (7, 64, 1000, 0, 3), (5, 128, 1000, 1, 0), (9, 96, 520, 3, 4),
+                                                  (4, 256, 1000, 0, 0), (5, 32, 4, 0, 2)])
+def test_persistent_fp32_bptt(lib, T, B, H, dh_first, block):
+    """lstm_seq_bwd_f32_persist_kernel against fp64 BPTT (fp32 rounding only) and the launch-per-timestep kernels; the dG
+    hand-off overwrites the gate stash in place, so the run is repeated bit for bit as well."""
+    from s2vt_video_caption_amd import ops
+    w, gates, c_all = _bptt_inputs(T, B, H, 90)
+    dh = _r((T - dh_first) * B, H, seed=99, scale=0.1)
+    args = (T, B, w.to(DEV), dh.to(DEV), dh_first, c_all.to(DEV), gates.to(DEV))
+    got = ops.lstm_seq_bwd_persist(*args, block=block)
+    again = ops.lstm_seq_bwd_persist(*args, block=block)
+    assert torch.equal(got, again)
+    # fp64 reference without operand rounding
+    wd, cd, gd, dhd = w.double(), c_all.double(), gates.double(), dh.double()
+    ref = torch.zeros(T * B, 4 * H, dtype=torch.float64)
+    dc = torch.zeros(B, H, dtype=torch.float64)
+    nxt = None
+    for t in range(T - 1, -1, -1):
+        d = torch.zeros(B, H, dtype=torch.float64)
+        if nxt is not None:
+            d += nxt @ wd
+        if t >= dh_first:
+            d += dhd[(t - dh_first) * B:(t - dh_first + 1) * B]
+        i, f, g, o = gd[t * B:(t + 1) * B].chunk(4, dim=1)
+        c = cd[t * B:(t + 1) * B]
+        cp = cd[(t - 1) * B:t * B] if t else torch.zeros_like(c)
+        tc = torch.tanh(c)
+        dct = d * o * (1 - tc * tc) + dc
+        nxt = torch.cat([dct * g * i * (1 - i), dct * cp * f * (1 - f), dct * i * (1 - g * g), d * tc * o * (1 - o)], dim=1)
+        ref[t * B:(t + 1) * B] = nxt
+        dc = dct * f
+    scale = ref.abs().max().item()
+    assert (got.cpu().double() - ref).abs().max().item() < 4e-6 * scale + 1e-9
+    per_step = ops.lstm_seq_bwd(T, B, w.to(DEV), dh.to(DEV), dh_first, c_all.to(DEV), gates.to(DEV).clone())
+    assert (got - per_step).abs().max().item() < 4e-6 * scale + 1e-9
+
+
+def test_persistent_fp32_two_layers_one_launch_under_load(lib):
+    """Both fp32 persistent kernels with two layers per launch at the config-2 shape while another stream loads the chip:
+    each layer equals its solo run bit for bit (a stale hand-off is timing dependent)."""
+    from s2vt_video_caption_amd import ops
+    T, B, H, n_gx = 24, 64, 1000, 12
+    ins = [(_r(n_gx * B, 4 * H, seed=101 + k), _r(4 * H, seed=103 + k, scale=0.3), _r(4 * H, H, seed=105 + k, scale=H ** -0.5))
+           for k in range(2)]
+    dev = [tuple(x.to(DEV) for x in i) for i in ins]
+    solo = [ops.lstm_seq_fwd_persist(T, B, d[0], n_gx, d[1], d[2], block=8) for d in dev]
+    bw_in = [_bptt_inputs(T, B, H, 110 + 10 * k) for k in range(2)]
+    dhs = [_r(T * B, H, seed=119 + k, scale=0.1).to(DEV) for k in range(2)]
+    bdev = [tuple(x.to(DEV) for x in i) for i in bw_in]
+    bsolo = [ops.lstm_seq_bwd_persist(T, B, bdev[k][0], dhs[k], 0, bdev[k][2], bdev[k][1], block=8) for k in range(2)]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.randn(32 * 1024 * 1024, device=DEV)
+    with torch.cuda.stream(side):
+        for _ in range(30):
+            big = big * 1.0001 + 1.0
+    pair = ops.lstm_seq_fwd_persist(T, B, dev[0][0], n_gx, dev[0][1], dev[0][2], block=8, second=dev[1])
+    bpair = ops.lstm_seq_bwd_persist(T, B, bdev[0][0], dhs[0], 0, bdev[0][2], bdev[0][1], block=8,
+                                     second=(bdev[1][0], dhs[1], bdev[1][2], bdev[1][1]))
+    torch.cuda.synchronize()
+    for k in range(2):
+        for x, y in zip(pair[k], solo[k]):
+            assert torch.equal(x, y)
+        assert torch.equal(bpair[k], bsolo[k])

@@ -129,6 +129,20 @@ def test_c2_full_size_against_reference_golden(lib, golden, gemm_mode):
         lib.s2vt_set_gemm_mode(prev)
 
 
+def test_c2_train_with_fp32_persistent_recurrence(lib, golden):
+    """The same config-2 train step with s2vt_set_recurrence_mode(2): both layers' fp32 recurrences (forward and BPTT) run
+    in the persistent kernels of lstm_persist_f32.hip, one launch per block of timesteps for both layers."""
+    g = golden("c2")
+    d, sd, feats, caps, mask = _setup(g, "c2")
+    prev = lib.s2vt_set_recurrence_mode(2)
+    try:
+        _c2_body(g, d, sd, feats, caps, mask)
+        from s2vt_video_caption_amd import capi
+        capi.check_async_error()
+    finally:
+        lib.s2vt_set_recurrence_mode(prev)
+
+
 def _c2_body(g, d, sd, feats, caps, mask):
     m = _model(d, sd)
     m.eval()

@@ -64,3 +64,31 @@ for B in (256, 64):
             lib.s2vt_prof_enable(0)
             ms, n = capi.prof_read(2)
         print("B=%d BPTT %s: %.3f ms, %.2f us per layer step (%d layer steps)" % (B, name, ms, ms * 1e3 / max(n, 1), n), flush=True)
+
+# ---- fp32 (config 2 arithmetic): launch per timestep vs persistent
+print("---- fp32", flush=True)
+for B in (64, 128):
+    g = torch.Generator().manual_seed(3)
+    gx = torch.randn(80 * B, 4 * H, generator=g).to(DEV)
+    bias = (torch.randn(4 * H, generator=g) * 0.3).to(DEV)
+    w = (torch.randn(4 * H, H, generator=g) * H ** -0.5).to(DEV)
+    gates = torch.sigmoid(torch.randn(T * B, 4 * H, generator=g)).to(DEV)
+    c_all = (torch.randn(T * B, H, generator=g) * 0.7).to(DEV)
+    dh = (torch.randn(T * B, H, generator=g) * 0.1).to(DEV)
+    lib = capi.load()
+    runs = (("fwd per-step launches", 1, lambda: ops.lstm_seq_fwd(T, B, gx, 80, bias, w, want_stash=True)),
+            ("fwd persistent block=32", 1, lambda: ops.lstm_seq_fwd_persist(T, B, gx, 80, bias, w, block=32)),
+            ("fwd persistent two layers one launch", 1, lambda: ops.lstm_seq_fwd_persist(T, B, gx, 80, bias, w, block=32, second=(gx, bias, w))),
+            ("bwd per-step launches", 2, lambda: ops.lstm_seq_bwd(T, B, w, dh, 0, c_all, gates.clone())),
+            ("bwd persistent block=32", 2, lambda: ops.lstm_seq_bwd_persist(T, B, w, dh, 0, c_all, gates, block=32)),
+            ("bwd persistent two layers one launch", 2, lambda: ops.lstm_seq_bwd_persist(T, B, w, dh, 0, c_all, gates, block=32,
+                                                                                       second=(w, dh, c_all, gates))))
+    for name, kind, fn in runs:
+        for rep in range(3):
+            lib.s2vt_prof_reset()
+            lib.s2vt_prof_enable(1)
+            fn()
+            torch.cuda.synchronize()
+            lib.s2vt_prof_enable(0)
+            ms, n = capi.prof_read(kind)
+        print("B=%d fp32 %s: %.3f ms, %.2f us per layer step (%d layer steps)" % (B, name, ms, ms * 1e3 / max(n, 1), n), flush=True)

@@ -44,3 +44,22 @@ for B in (256, 64):
         tot = (rec[1:, 0] - rec[:-1, 0]).astype(np.float64) * 0.01
         print("B=%d workgroup %d: sub-step period %.2f us (min %.2f max %.2f)" % (B, blockid, tot.mean(), tot.min(), tot.max()))
         print("   " + "  ".join("%s %.2f" % (n, v) for n, v in zip(NAMES, d.mean(axis=0))))
+
+
+# ---- fp32 forward (config 2 arithmetic)
+NAMES32 = ["poll", "ring prologue issue", "first chunk (wait + 16 MFMA)", "7 more chunks", "partials", "cell math", "store issue", "drain", "signal"]
+for B, pair in ((64, False), (64, True)):
+    g = torch.Generator().manual_seed(1)
+    gx = torch.randn(24 * B, 4 * H, generator=g).to(DEV)
+    bias = (torch.randn(4 * H, generator=g) * 0.3).to(DEV)
+    w = (torch.randn(4 * H, H, generator=g) * H ** -0.5).to(DEV)
+    stamps = torch.zeros(4096 * 16, dtype=torch.int64, device=DEV)
+    lib.s2vt_experiment_set_stamps(ctypes.c_void_p(stamps.data_ptr()), 17)
+    ops.lstm_seq_fwd_persist(T, B, gx, 24, bias, w, block=0, second=(gx, bias, w) if pair else None)
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy().reshape(4096, 16)
+    rec = s[4:T]
+    d = np.diff(rec[:, :10].astype(np.float64), axis=1) * 0.01
+    tot = (rec[1:, 0] - rec[:-1, 0]).astype(np.float64) * 0.01
+    print("fp32 B=%d %s workgroup 17: sub-step period %.2f us (min %.2f max %.2f)" % (B, "two layers" if pair else "one layer", tot.mean(), tot.min(), tot.max()))
+    print("   " + "  ".join("%s %.2f" % (n, v) for n, v in zip(NAMES32, d.mean(axis=0))))
