@@ -287,14 +287,22 @@ def main():
         # under profiles/ — counters cannot be collected from inside this process.  Only valid for the default workload.
         pmc = {}
         try:
-            if B == 64:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round1_traffic_pmc.json")))["kernels"]
+            if B == 64 and not bf:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_traffic_pmc_c2.json")))["kernels"]
+            elif B == 256 and bf:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_traffic_pmc_c3.json")))["kernels"]
         except Exception:
             pmc = {}
 
         def traffic(kernel):
+            """HBM bytes per launch; for a persistent kernel (one launch = many timesteps) per layer timestep, the unit its
+            `achieved` / `algorithmic_bytes_per_launch` fields are expressed in"""
             e = pmc.get(kernel)
-            return int(e["hbm_bytes_per_launch"]) if e and "hbm_bytes_per_launch" in e else None
+            if not e:
+                return None
+            if "hbm_bytes_per_layer_timestep" in e:
+                return int(e["hbm_bytes_per_layer_timestep"])
+            return int(e["hbm_bytes_per_launch"]) if "hbm_bytes_per_launch" in e else None
 
         rmode = lib.s2vt_set_recurrence_mode(-1)
         persist_bf16 = bf and rmode >= 1           # the timed configuration runs the persistent bf16 recurrence kernels

@@ -15,7 +15,9 @@ for tag in ("fetch", "write", "l2"):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
             fam = None
-            for key in ("gemm_x3_kernel", "gemm_f32_kernel", "lstm_step_fwd_kernel", "lstm_step_bwd_kernel",
+            for key in ("gemm_x3_kernel", "gemm_f32_kernel", "gemm_b1_kernel", "lstm_step_fwd_kernel", "lstm_step_bwd_kernel",
+                        "lstm_step_fwd_bf16_kernel", "lstm_step_bwd_bf16_kernel", "lstm_seq_fwd_bf16_persist_kernel",
+                        "lstm_seq_bwd_bf16_persist_kernel", "lstm_seq_fwd_f32_persist_kernel", "lstm_seq_bwd_f32_persist_kernel",
                         "split_dual_kernel", "logits_argmax_kernel", "ce_row_kernel", "ce_bwd_kernel"):
                 if key in n:
                     fam = key
@@ -36,7 +38,13 @@ for fam, c in acc.items():
     h, m = c.get("TCC_HIT_sum", []), c.get("TCC_MISS_sum", [])
     if h and m:
         e["l2_hit_rate"] = sum(h) / (sum(h) + sum(m))
+    if "persist" in fam and "hbm_bytes_per_launch" in e:
+        # a persistent launch covers a block of timesteps of one or two layers: 2 x 159 layer timesteps per pass in all
+        iters = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+        e["layer_timesteps_per_pass"] = 318
+        e["hbm_bytes_per_layer_timestep"] = e["hbm_bytes_per_launch"] * e["launches"] / (318.0 * iters)
     out[fam] = e
-print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum, tools/prof_path.py c2 2 "
-                            "(one C2 train forward+backward x2), FETCH_SIZE doubled per MI355X_MICROARCH.md",
+what = sys.argv[2] if len(sys.argv) > 2 else "c2"
+print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum (separate passes), tools/prof_path.py %s "
+                            "(train forward+backward passes), FETCH_SIZE doubled per MI355X_MICROARCH.md" % what,
                   "kernels": out}, indent=1))
