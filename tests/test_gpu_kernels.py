@@ -203,6 +203,29 @@ def test_decode_argmax_first_max_wins(lib):
     assert torch.equal(ids[safe], ref.argmax(1)[safe])
 
 
+@pytest.mark.parametrize("B,H,V", [(128, 1000, 12000), (100, 72, 1000), (48, 500, 97), (300, 128, 530)])
+def test_decode_argmax_at_decode_sizes(lib, B, H, V):
+    """logits_argmax_kernel at decode sizes (B = 128, V = 12000, H = 1000) and ragged B / V / H: planted ties resolve to the
+    lowest index, random logits give the fp64 argmax wherever the top-2 gap exceeds fp32 rounding."""
+    from s2vt_video_caption_amd import ops
+    h = torch.zeros(B, H); h[:, 0] = 1.0
+    w = torch.zeros(V, H)
+    g = torch.Generator().manual_seed(3)
+    w[:, 0] = torch.randint(-50, 50, (V,), generator=g).float()
+    w[[5, V // 2, V - 1], 0] = 60.0
+    ids = ops.decode_step_argmax(h.to(DEV), w.to(DEV), torch.zeros(V).to(DEV)).cpu()
+    assert (ids == 5).all()
+    hh = _r(B, H, seed=5); ww = _r(V, H, seed=6, scale=H ** -0.5); bb = _r(V, seed=7)
+    ids = ops.decode_step_argmax(hh.to(DEV), ww.to(DEV), bb.to(DEV)).cpu()
+    ref = (hh.double() @ ww.double().t() + bb.double())
+    top2 = ref.topk(2, 1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert safe.sum() > B // 2
+    assert torch.equal(ids[safe], ref.argmax(1)[safe])
+    ids = ops.decode_step_argmax(hh.to(DEV), ww.to(DEV), (bb - 1000).to(DEV)).cpu()          # all-negative logits
+    assert torch.equal(ids[safe], ref.argmax(1)[safe])
+
+
 def test_feat_proj_fwd_bwd(lib):
     from s2vt_video_caption_amd import ops
     B, L, Fd, H = 3, 5, 70, 20
