@@ -54,8 +54,6 @@ class S2VT(nn.Module):
                 raise NotImplementedError(
                     "the HIP S2VT path implements the reference configuration (1-layer unidirectional LSTM); "
                     "GRU / num_layers>1 / bidirectional are outside the hot path (SURVEY.md §8)")
-        if self.training and self.out_drop.p > 0:
-            raise NotImplementedError("out_dropout > 0 in training mode is not implemented on the HIP path")
 
     def forward(self, feats, targets=None, mode='train', beam_width=3, max_beam_depth=30):
         """
@@ -74,7 +72,14 @@ class S2VT(nn.Module):
         if mode == 'train':
             if targets is None:
                 raise ValueError("mode='train' needs targets")
-            return _F.train_forward(feats, targets, params, grad_sink=_F.grad_sink_for(self))
+            out_mask = None
+            if self.training and self.out_drop.p > 0:
+                # S2VTModel.py:79 applies nn.Dropout to the [B, L-1, H] decode-step hidden states: the same call on a ones
+                # tensor of that shape draws the same mask from torch's generator; the kernels want it time-major
+                B, H = feats.shape[0], self.dim_hid
+                keep = self.out_drop(torch.ones(B, self.length - 1, H, dtype=torch.float32, device=feats.device))
+                out_mask = keep.transpose(0, 1).reshape((self.length - 1) * B, H).contiguous()
+            return _F.train_forward(feats, targets, params, grad_sink=_F.grad_sink_for(self), out_mask=out_mask)
         elif mode == 'test':
             return _F.greedy_decode(feats, params, self.sos_ix)
         return None                                        # the reference falls through for unknown modes

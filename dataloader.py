@@ -124,22 +124,23 @@ def feed_batches(loader, dev=None, depth=2):
 
     th = threading.Thread(target=producer, name="s2vt-feed", daemon=True)
     th.start()
-    prev = None
     try:
         while True:
             item = ready.get()
-            cur = torch.cuda.current_stream(dev)
-            if prev is not None:                           # everything enqueued so far that reads the previous batch
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                slots[prev]["consumed"] = ev
             if item is None:
                 break
             if isinstance(item, BaseException):
                 raise item
-            prev, (f, t, m), ids, ev = item
+            slot_ix, (f, t, m), ids, ev = item
+            cur = torch.cuda.current_stream(dev)
             cur.wait_event(ev)
             yield f, t, ids, m
+            # The caller is back for the next batch: everything that reads this batch is enqueued.  Publish "consumed" NOW,
+            # before the ready.get() above frees a queue place: that get() is what lets the producer move on to the slot
+            # this batch lives in, and it must find the event there (an event published after the get() could be missed).
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(dev))
+            slots[slot_ix]["consumed"] = done
     finally:
         stop.set()
         while th.is_alive():                               # unblock a producer waiting on the bounded queue

@@ -81,6 +81,13 @@ size_t s2vt_train_workspace_bytes(const s2vt_dims* d);
 int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
                        int64_t targets_ld, float* logits, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with out_dropout > 0 (S2VTModel.py:25,79: `res = self.out_drop(res)` between word_rnn and out_linear in
+ * training mode).  out_mask: [(L-1)*B, H] TIME-MAJOR (row j*B + b = caption step j of sample b), entries 0 or 1/(1-p),
+ * drawn by the caller (torch's dropout on a ones tensor: the reference's RNG stream); the backward must get the same mask. */
+int s2vt_train_forward_dropout(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
+                               int64_t targets_ld, const float* out_mask, float* logits, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* Device-side errors are asynchronous: a target id outside [0, V) (the reference's nn.Embedding raises IndexError,
  * S2VTModel.py:71) or a timed-out hand-off of the persistent recurrence raise a flag that every s2vt_train_forward
  * copies to the host at its end.  The NEXT s2vt_train_forward / s2vt_train_backward that finds the copy complete returns
@@ -114,6 +121,9 @@ int s2vt_backward_wait_grads(int32_t group, void* stream);
  * dfeats [B, L, F] may be NULL (nothing reads it in the reference: SURVEY.md §3.1 note). */
 int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
                         const s2vt_grads* g, float* dfeats, void* workspace, size_t workspace_bytes, void* stream);
+int s2vt_train_backward_dropout(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
+                                const float* out_mask, const s2vt_grads* g, float* dfeats, void* workspace,
+                                size_t workspace_bytes, void* stream);
 
 size_t s2vt_decode_workspace_bytes(const s2vt_dims* d);
 

@@ -84,7 +84,7 @@ def _word_step(p, emb, vid_h, h, c):
 
 
 # ------------------------------------------------------------------------ forward
-def forward_train(params, feats, targets, dtype=torch.float32):
+def forward_train(params, feats, targets, dtype=torch.float32, out_mask=None):
     """``S2VT.forward(feats, targets, mode='train')`` (S2VTModel.py:48-54, 63-81).
 
     feats [B, L, F]; targets [B, L-1] int64 (= caption[:, :-1]); returns logits
@@ -107,6 +107,8 @@ def forward_train(params, feats, targets, dtype=torch.float32):
         if t >= L:
             outs.append(h)                                                    # :78
     res = torch.stack(outs, dim=1)
+    if out_mask is not None:      # out_drop (:79) with a given keep mask [B, L-1, H], entries 0 or 1/(1-p)
+        res = res * out_mask.to(dtype)
     return res @ p["out_linear.weight"].t() + p["out_linear.bias"]            # :80
 
 
@@ -265,8 +267,8 @@ class OracleModel(torch.nn.Module):
     def as_dict(self):
         return {k: p for k, p in zip(self.names, self.params)}
 
-    def forward(self, feats, targets):
-        return forward_train(self.as_dict(), feats, targets, dtype=self.dtype)
+    def forward(self, feats, targets, out_mask=None):
+        return forward_train(self.as_dict(), feats, targets, dtype=self.dtype, out_mask=out_mask)
 
 
 def train_steps(state_dict, feats, caps, mask, n_steps, lr=1e-4, dtype=torch.float32):

@@ -41,6 +41,10 @@ SIGNATURES = {
     "s2vt_train_workspace_bytes": (c_size_t, [POINTER(Dims)]),
     "s2vt_train_forward": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
+    "s2vt_train_forward_dropout": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
+                                             c_void_p, c_size_t, c_void_p]),
+    "s2vt_train_backward_dropout": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_void_p, c_void_p, POINTER(Grads),
+                                              c_void_p, c_void_p, c_size_t, c_void_p]),
     "s2vt_check_async_error": (c_int32, [c_int32]),
     "s2vt_train_backward": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_void_p, POINTER(Grads), c_void_p,
                                       c_void_p, c_size_t, c_void_p]),

@@ -654,8 +654,19 @@ static bool dual_on() {
     return g_dual != 0;
 }
 
+// out_mask: optional out_drop mask (S2VTModel.py:79), time-major [(L-1)*B, H], entries 0 or 1/(1-p); nullptr = no dropout.
+// The masked decode-step hidden states replace the row planes of the logits GEMM (the recurrence is done with them by then).
+static int masked_logits_planes(const Lane& ln, const TrainWS& w, const PlaneWS& q, const float* out_mask, int B, int L, int H) {
+    if (!out_mask) return 0;
+    const int R = (L - 1) * B;
+    int rc;
+    if ((rc = mul_vectors(ln.s, w.h2 + (int64_t)L * B * H, out_mask, w.dh2dec, (int64_t)R * H))) return rc;   // dh2dec: free in the forward
+    return psplit(ln, q.h2r, L * B, w.dh2dec, H, ID, R, H);
+}
+
 static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
-                            int64_t targets_ld, float* logits, const TrainWS& w, const PlaneWS& q, hipStream_t st) {
+                            int64_t targets_ld, float* logits, const TrainWS& w, const PlaneWS& q, hipStream_t st,
+                            const float* out_mask) {
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1, R = (L - 1) * B;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
     const int blk = pipe_block();
@@ -729,6 +740,7 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
             }
         }
         if ((rc = handoff(sx, st, ev++))) return rc;
+        if ((rc = masked_logits_planes(la, w, q, out_mask, B, L, H))) return rc;
         return pgemm(la, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
     }
     if (!bf && blk > 0 && persist_f32_on() && lstm_seq_fwd_f32_persist_supported(B, H)) {
@@ -761,6 +773,7 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
                     return rc;
             }
         }
+        if ((rc = masked_logits_planes(la, w, q, out_mask, B, L, H))) return rc;
         return pgemm(la, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
     }
     if (bf && persist_fwd_ok(B, H, q.whh1, q.h1) && blk > 0) {
@@ -793,6 +806,7 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
                     return rc;
             }
         }
+        if ((rc = masked_logits_planes(la, w, q, out_mask, B, L, H))) return rc;
         return pgemm(la, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
     }
     for (size_t k = 0; k + 1 < bd.size(); ++k) {
@@ -819,12 +833,14 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
                         t0 * B, nullptr)))
             return rc;
     }
+    if ((rc = masked_logits_planes(lb, w, q, out_mask, B, L, H))) return rc;
     if ((rc = pgemm(lb, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false))) return rc;
     return handoff(sx, st, ev++);
 }
 
 static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
-                             const s2vt_grads* g, float* dfeats, const TrainWS& w, const PlaneWS& q, hipStream_t st) {
+                             const s2vt_grads* g, float* dfeats, const TrainWS& w, const PlaneWS& q, hipStream_t st,
+                             const float* out_mask) {
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1, R = (L - 1) * B;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
     const int blk = pipe_block();
@@ -845,11 +861,15 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = pdual(la, dlogits, V, ID, R, V, &q.dlog, 0, &q.dlogT, 0, w.colsum_c))) return rc;
     if ((rc = handoff(st, sx, ev++))) return rc;
     if ((rc = pgemm(la, R, H, V, q.dlog, 0, 0, q.woT, 0, 0, w.dh2dec, H, perm(L - 1, B), nullptr, false))) return rc;
+    if (out_mask && (rc = mul_vectors(st, w.dh2dec, out_mask, w.dh2dec, (int64_t)R * H))) return rc;      // autograd of out_drop
     if ((rc = transpose_f32(st, p->word_w_hh, 4 * H, H, w.wt2))) return rc;
     const bool paired = !bf && dual_on() && blk > 0;      // both layers' BPTT steps run on the caller's stream
     if (paired && (rc = transpose_f32(st, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     // lane B meanwhile: out_linear weight/bias gradients (k = batch-major row index) and W_hh1^T
-    if ((rc = psplitT(lb, q.h2decT, 0, w.h2 + L * BH, H, perm(L - 1, B), R, H))) return rc;
+    if (out_mask) {      // dW_o sees the masked hidden states (dx1 is free until the vid_rnn input gradient)
+        if ((rc = mul_vectors(sx, w.h2 + L * BH, out_mask, w.dx1, (int64_t)R * H))) return rc;
+        if ((rc = psplitT(lb, q.h2decT, 0, w.dx1, H, perm(L - 1, B), R, H))) return rc;
+    } else if ((rc = psplitT(lb, q.h2decT, 0, w.h2 + L * BH, H, perm(L - 1, B), R, H))) return rc;
     if ((rc = pgemm(lb, V, H, R, q.dlogT, 0, 0, q.h2decT, 0, 0, g->out_w, H, ID, nullptr, false))) return rc;
     if ((rc = colsum_finish(sx, w.colsum_c, cdiv(R, 64), V, g->out_b, false))) return rc;
     if ((rc = grads_ready(0, sx))) return rc;
@@ -1025,8 +1045,9 @@ size_t s2vt_train_workspace_bytes(const s2vt_dims* d) {
     return n;
 }
 
-int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
-                       int64_t targets_ld, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+static int train_forward_impl(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
+                              int64_t targets_ld, float* logits, void* workspace, size_t workspace_bytes, void* stream,
+                              const float* out_mask) {
     S2VT_REQUIRE(dims_ok(d) && p && feats && targets && logits && workspace, "s2vt_train_forward: null/invalid argument");
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
@@ -1041,7 +1062,7 @@ int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* fe
         const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
         S2VT_REQUIRE(workspace_bytes >= w.bytes + q.bytes, "s2vt_train_forward: workspace %zu < %zu bytes",
                      workspace_bytes, w.bytes + q.bytes);
-        int rc0 = train_forward_x3(d, p, feats, targets, targets_ld, logits, w, q, st);
+        int rc0 = train_forward_x3(d, p, feats, targets, targets_ld, logits, w, q, st, out_mask);
         return rc0 ? rc0 : post_async_error(st, w.err);
     }
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
@@ -1081,18 +1102,34 @@ int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* fe
             return rc;
         if ((rc = seq_fwd(sx, t0, t1, B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, true))) return rc;
     }
-    // logits[b, j, :] = h2[L + j]·W_o^T + b_o                                        S2VTModel.py:78-80
-    if ((rc = lgemm(lb, true, true, (L - 1) * B, V, H, w.h2 + L * BH, H, ID, p->out_w, H, ID, logits, V, perm(B, L - 1),
+    // logits[b, j, :] = (out_drop mask (.)) h2[L + j]·W_o^T + b_o                    S2VTModel.py:78-80
+    const float* hdec = w.h2 + L * BH;
+    if (out_mask) {
+        if ((rc = mul_vectors(sx, hdec, out_mask, w.dh2dec, (int64_t)(L - 1) * B * H))) return rc;     // dh2dec: free in the forward
+        hdec = w.dh2dec;
+    }
+    if ((rc = lgemm(lb, true, true, (L - 1) * B, V, H, hdec, H, ID, p->out_w, H, ID, logits, V, perm(B, L - 1),
                     p->out_b, false)))
         return rc;
     if ((rc = handoff(sx, st, ev++))) return rc;
     return post_async_error(st, w.err);
 }
 
+int s2vt_train_forward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
+                       int64_t targets_ld, float* logits, void* workspace, size_t workspace_bytes, void* stream) {
+    return train_forward_impl(d, p, feats, targets, targets_ld, logits, workspace, workspace_bytes, stream, nullptr);
+}
+int s2vt_train_forward_dropout(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
+                               int64_t targets_ld, const float* out_mask, float* logits, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    return train_forward_impl(d, p, feats, targets, targets_ld, logits, workspace, workspace_bytes, stream, out_mask);
+}
+
 int s2vt_check_async_error(int32_t wait) { return poll_async_error(wait != 0); }
 
-int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
-                        const s2vt_grads* g, float* dfeats, void* workspace, size_t workspace_bytes, void* stream) {
+static int train_backward_impl(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
+                               const s2vt_grads* g, float* dfeats, void* workspace, size_t workspace_bytes, void* stream,
+                               const float* out_mask) {
     S2VT_REQUIRE(dims_ok(d) && p && feats && dlogits && g && workspace, "s2vt_train_backward: null/invalid argument");
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
@@ -1107,7 +1144,7 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
         const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
         S2VT_REQUIRE(workspace_bytes >= w.bytes + q.bytes, "s2vt_train_backward: workspace %zu < %zu bytes",
                      workspace_bytes, w.bytes + q.bytes);
-        int rc0 = train_backward_x3(d, p, feats, dlogits, g, dfeats, w, q, st);
+        int rc0 = train_backward_x3(d, p, feats, dlogits, g, dfeats, w, q, st, out_mask);
         return rc0 ? rc0 : post_async_error(st, w.err, 1);
     }
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
@@ -1124,10 +1161,15 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
     // lane A: gradient into the decode-step hidden states, then word_rnn BPTT       (autograd of S2VTModel.py:80, :77)
     if ((rc = lgemm(la, true, false, R, H, V, dlogits, V, ID, p->out_w, H, ID, w.dh2dec, H, perm(L - 1, B), nullptr, false)))
         return rc;
+    if (out_mask && (rc = mul_vectors(st, w.dh2dec, out_mask, w.dh2dec, (int64_t)R * H))) return rc;      // autograd of out_drop
     if ((rc = transpose_f32(st, p->word_w_hh, 4 * H, H, w.wt2))) return rc;
-    // lane B meanwhile: out_linear weight/bias gradients (need only dlogits and h2) and W_hh1^T
-    if ((rc = lgemm(lb, false, false, V, H, R, dlogits, V, ID, w.h2 + L * BH, H, perm(L - 1, B), g->out_w, H, ID, nullptr,
-                    false)))
+    // lane B meanwhile: out_linear weight/bias gradients (need only dlogits and the (masked) h2) and W_hh1^T
+    const float* hdec = w.h2 + L * BH;
+    if (out_mask) {
+        if ((rc = mul_vectors(sx, hdec, out_mask, w.dx1, (int64_t)R * H))) return rc;      // dx1: free until the vid_rnn input gradient
+        hdec = w.dx1;
+    }
+    if ((rc = lgemm(lb, false, false, V, H, R, dlogits, V, ID, hdec, H, perm(L - 1, B), g->out_w, H, ID, nullptr, false)))
         return rc;
     if ((rc = colsum_f32(sx, dlogits, R, V, V, lb.colsum, g->out_b, false))) return rc;
     if ((rc = grads_ready(0, sx))) return rc;
@@ -1181,6 +1223,16 @@ int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* f
             return rc;
     }
     return handoff(sx, st, ev++);
+}
+
+int s2vt_train_backward(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
+                        const s2vt_grads* g, float* dfeats, void* workspace, size_t workspace_bytes, void* stream) {
+    return train_backward_impl(d, p, feats, dlogits, g, dfeats, workspace, workspace_bytes, stream, nullptr);
+}
+int s2vt_train_backward_dropout(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
+                                const float* out_mask, const s2vt_grads* g, float* dfeats, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+    return train_backward_impl(d, p, feats, dlogits, g, dfeats, workspace, workspace_bytes, stream, out_mask);
 }
 
 // ------------------------------------------------------------------ greedy decode

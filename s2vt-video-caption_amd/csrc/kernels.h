@@ -173,6 +173,7 @@ int logits_argmax(hipStream_t stream, const LogitsArgmaxArgs& a);
 
 // ---- misc.hip
 int add_vectors(hipStream_t s, const float* a, const float* b, float* out, int n);
+int mul_vectors(hipStream_t s, const float* a, const float* b, float* out, int64_t n);
 int transpose_f32(hipStream_t s, const float* in, int rows, int cols, float* out);   // out[cols][rows]
 int colsum_f32(hipStream_t s, const float* x, int64_t rows, int cols, int64_t ld, float* partial, float* out,
                bool accumulate);

@@ -10,6 +10,18 @@ __global__ void add_vectors_kernel(const float* a, const float* b, float* out, i
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = a[i] + b[i];
 }
+__global__ void mul_vectors_kernel(const float* a, const float* b, float* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+// out = a (.) b, element-wise (out may alias a): the out_drop mask of S2VTModel.py:79 and its gradient
+int mul_vectors(hipStream_t s, const float* a, const float* b, float* out, int64_t n) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(mul_vectors_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, out, n);
+    S2VT_LAUNCH_CHECK("mul_vectors_kernel");
+    return 0;
+}
+
 int add_vectors(hipStream_t s, const float* a, const float* b, float* out, int n) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(add_vectors_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, a, b, out, n);

@@ -53,7 +53,7 @@ def _dims(feats, params):
 
 class _TrainForward(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, targets, grad_sink, *params):
+    def forward(ctx, feats, targets, grad_sink, out_mask, *params):
         lib = capi.load()
         feats = _f32c(feats, "feats")
         params = tuple(_f32c(p, "parameter") for p in params)
@@ -71,9 +71,18 @@ class _TrainForward(torch.autograd.Function):
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             logits = torch.empty(d.B, d.L - 1, d.V, dtype=torch.float32, device=dev)
             ps = _params_struct(capi.Params, params)
-            capi.check(lib.s2vt_train_forward(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), _ptr(targets),
-                                              targets.stride(0), _ptr(logits), _ptr(ws), nbytes, _stream(dev)),
-                       "s2vt_train_forward")
+            if out_mask is None:
+                capi.check(lib.s2vt_train_forward(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), _ptr(targets),
+                                                  targets.stride(0), _ptr(logits), _ptr(ws), nbytes, _stream(dev)),
+                           "s2vt_train_forward")
+            else:       # out_dropout > 0: mask [(L-1)*B, H] time-major, entries 0 or 1/(1-p)
+                out_mask = _f32c(out_mask, "out_mask")
+                if tuple(out_mask.shape) != ((d.L - 1) * d.B, d.H):
+                    raise ValueError("out_mask must be [(L-1)*B, H] = [%d, %d], got %s" % ((d.L - 1) * d.B, d.H, tuple(out_mask.shape)))
+                capi.check(lib.s2vt_train_forward_dropout(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), _ptr(targets),
+                                                          targets.stride(0), _ptr(out_mask), _ptr(logits), _ptr(ws), nbytes,
+                                                          _stream(dev)), "s2vt_train_forward_dropout")
+        ctx.out_mask = out_mask
         ctx.save_for_backward(feats, *params)
         ctx.ws, ctx.d, ctx.used, ctx.grad_sink = ws, d, False, grad_sink
         return logits
@@ -103,13 +112,18 @@ class _TrainForward(torch.autograd.Function):
             dfeats = torch.empty_like(feats) if ctx.needs_input_grad[0] else None
             ps = _params_struct(capi.Params, params)
             gs = _params_struct(capi.Grads, grads)
-            capi.check(lib.s2vt_train_backward(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), _ptr(dlogits),
-                                               ctypes.byref(gs), _ptr(dfeats), _ptr(ws), ws.numel(), _stream(dev)),
-                       "s2vt_train_backward")
+            if ctx.out_mask is None:
+                capi.check(lib.s2vt_train_backward(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), _ptr(dlogits),
+                                                   ctypes.byref(gs), _ptr(dfeats), _ptr(ws), ws.numel(), _stream(dev)),
+                           "s2vt_train_backward")
+            else:
+                capi.check(lib.s2vt_train_backward_dropout(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), _ptr(dlogits),
+                                                           _ptr(ctx.out_mask), ctypes.byref(gs), _ptr(dfeats), _ptr(ws),
+                                                           ws.numel(), _stream(dev)), "s2vt_train_backward_dropout")
         ctx.ws = None
         if sink is not None:
-            return (dfeats, None, None) + (None,) * len(params)
-        return (dfeats, None, None) + tuple(grads)
+            return (dfeats, None, None, None) + (None,) * len(params)
+        return (dfeats, None, None, None) + tuple(grads)
 
 
 # model -> 13 gradient tensors (capi.PARAM_KEYS order) the backward writes into; kept OUT of the module's __dict__ so
@@ -128,10 +142,11 @@ def grad_sink_for(model):
     return _GRAD_SINKS.get(model)
 
 
-def train_forward(feats, targets, params, grad_sink=None):
+def train_forward(feats, targets, params, grad_sink=None, out_mask=None):
     """logits [B, L-1, V] of S2VT.forward(mode='train'); `params` in capi.PARAM_KEYS order.  `grad_sink`: optional 13
-    tensors (same order) the backward writes the parameter gradients into instead of returning them to autograd."""
-    return _TrainForward.apply(feats, targets, grad_sink, *params)
+    tensors (same order) the backward writes the parameter gradients into instead of returning them to autograd.
+    `out_mask`: the out_drop mask (S2VTModel.py:79) as [(L-1)*B, H] time-major, entries 0 or 1/(1-p); None = no dropout."""
+    return _TrainForward.apply(feats, targets, grad_sink, out_mask, *params)
 
 
 @torch.no_grad()

@@ -332,6 +332,63 @@ def test_out_of_range_target_raises_index_error(lib):
     assert torch.isfinite(logits).all()
 
 
+@pytest.mark.parametrize("B,gemm_mode", [(5, 3), (64, 3), (64, 1)])
+def test_out_dropout_train_mode_matches_oracle_with_the_same_mask(lib, B, gemm_mode):
+    """out_dropout > 0 (S2VTModel.py:25,79): the decode-step hidden states are masked between word_rnn and out_linear.  With
+    the SAME keep mask the oracle must give the same logits and the same 13 gradients (fp32 paths: B=5 takes the fp32-MFMA
+    driver, B=64 the split-precision plane driver; gemm mode 1 = bf16 operands at bf16 bounds); at model level the mask
+    is drawn like the reference draws it, eval mode ignores it."""
+    import S2VTModel, utils
+    from s2vt_video_caption_amd import functional as F
+    L, Fd, H, E, V = 6, 48, 64, 40, 90
+    sd = synth.make_state_dict(V, Fd, H, E, seed=8)
+    feats, caps, mask = synth.make_batch(B, L, Fd, V, seed=8, min_words=1, max_words=3)
+    p = 0.35
+    keep = torch.nn.functional.dropout(torch.ones(B, L - 1, H), p, training=True)       # [B, L-1, H], 0 or 1/(1-p)
+    om = orc.OracleModel(sd)
+    ologits = om(feats, caps[:, :-1], out_mask=keep)
+    oloss = orc.mask_criterion(ologits, caps, mask)
+    oloss.backward()
+    m = S2VTModel.S2VT(V, Fd, L, dim_hid=H, dim_embed=E, out_dropout=p)
+    m.load_state_dict(sd)
+    m.to(DEV).train()
+    prev = lib.s2vt_set_gemm_mode(gemm_mode)
+    try:
+        keep_tm = keep.transpose(0, 1).reshape((L - 1) * B, H).contiguous().to(DEV)
+        logits = F.train_forward(feats.to(DEV), caps[:, :-1].to(DEV), m._hip_params(), out_mask=keep_tm)
+        loss = utils.MaskCriterion()(logits, caps.to(DEV), mask.to(DEV))
+        loss.backward()
+        bf = gemm_mode == 1
+        scale = ologits.detach().abs().max().item()
+        assert (logits.detach().cpu() - ologits.detach()).abs().max().item() < (2e-2 * scale if bf else 2e-5)
+        for (n, prm), (k, q) in zip(m.named_parameters(), om.as_dict().items()):
+            if bf:
+                assert (prm.grad.cpu() - q.grad).norm().item() <= 3e-2 * q.grad.norm().item() + 1e-9, n
+            else:
+                assert (prm.grad.cpu() - q.grad).abs().max().item() <= 1e-6 + 1e-4 * q.grad.abs().max().item(), n
+        # model level: a mask is drawn (train mode differs from the no-dropout logits, two calls differ), eval ignores it
+        with torch.no_grad():
+            a = m(feats.to(DEV), targets=caps[:, :-1].to(DEV), mode="train")
+            b = m(feats.to(DEV), targets=caps[:, :-1].to(DEV), mode="train")
+            m.eval()
+            c = m(feats.to(DEV), targets=caps[:, :-1].to(DEV), mode="train")
+            d = m(feats.to(DEV), targets=caps[:, :-1].to(DEV), mode="train")
+        assert not torch.equal(a, b) and torch.equal(c, d)
+        if not bf:
+            assert (c.cpu() - orc.forward_train(sd, feats, caps[:, :-1])).abs().max().item() < 2e-5
+        # the mask is the one nn.Dropout draws for a [B, L-1, H] tensor from the same generator state
+        m.train()
+        torch.manual_seed(123)
+        e = m(feats.to(DEV), targets=caps[:, :-1].to(DEV), mode="train").detach()
+        torch.manual_seed(123)
+        keep2 = torch.nn.functional.dropout(torch.ones(B, L - 1, H, device=DEV), p, training=True)
+        f = F.train_forward(feats.to(DEV), caps[:, :-1].to(DEV), m._hip_params(),
+                            out_mask=keep2.transpose(0, 1).reshape((L - 1) * B, H).contiguous()).detach()
+        assert torch.equal(e, f)
+    finally:
+        lib.s2vt_set_gemm_mode(prev)
+
+
 def test_backward_refuses_a_workspace_of_another_mode(lib):
     """Changing the arithmetic mode between a forward and its backward would carve the workspace differently: refused."""
     import utils
