@@ -86,8 +86,10 @@ def test_split_precision_gemm_is_exact_on_integers(lib):
     assert torch.equal(got, a @ b.t())
 
 
-@pytest.mark.parametrize("B,H", [(1, 32), (4, 500), (33, 40), (64, 1000), (16, 8), (17, 36)])
+@pytest.mark.parametrize("B,H", [(1, 32), (4, 500), (33, 40), (64, 1000), (16, 8), (17, 36), (8, 1000), (5, 1000), (2, 1500),
+                                 (3, 30)])
 def test_lstm_step_fwd_matches_cell(lib, B, H):
+    """Batches from 1 to 64, including the small batches (B <= 8) of the reference's plumbing configuration and of decode."""
     from s2vt_video_caption_amd import ops
     k = 1.0 / H ** 0.5
     w_hh = (torch.rand(4 * H, H, generator=torch.Generator().manual_seed(1)) * 2 - 1) * k
