@@ -144,6 +144,7 @@ def main():
     ap.add_argument("--gemm-mode", type=int, default=None, choices=[0, 1, 3],
                     help="0 fp32-input MFMA, 3 split-precision bf16x3 (default, fp32-equivalent), 1 bf16 operands "
                          "(BASELINE configs[2]: use with --batch 256)")
+    ap.add_argument("--no-config3", action="store_true", help="skip the B=256 bf16 sub-record (BASELINE configs[2])")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU-only rehearsal of the N-rank launch path (gloo); prints n_gpus")
     args = ap.parse_args()
@@ -262,13 +263,14 @@ def main():
         # Pass 1 in the timed configuration (layers pipelined on two streams: kernels of the two lanes overlap,
         # so a launch's duration includes the share of the chip it cedes to the other lane); pass 2 with the
         # pipeline off (s2vt_set_pipeline_block(0)): every kernel alone on the GPU.
-        def profile(nprof=2):
+        def profile(nprof=2, batch=None):
+            pf, pc, pm = batch if batch is not None else (feats, caps, mask)
             capi.check(lib.s2vt_prof_reset(), "prof_reset")
             capi.check(lib.s2vt_prof_enable(1), "prof_enable")
             for _ in range(nprof):
                 model.zero_grad(set_to_none=False)
-                probs = model(feats, targets=caps[:, :-1], mode="train")
-                l2 = crit(probs, caps, mask)
+                probs = model(pf, targets=pc[:, :-1], mode="train")
+                l2 = crit(probs, pc, pm)
                 l2.backward()
             torch.cuda.synchronize(dev)
             capi.check(lib.s2vt_prof_enable(0), "prof_enable")
@@ -376,7 +378,8 @@ def main():
         # ---- greedy decode captions/s (one mode='test' call per measurement) + its out_linear/argmax kernel
         Bd = args.decode_batch or 128        # BASELINE configs[4]: inference at B=128
         dfe = feats[:Bd] if Bd <= B else synth.make_batch(Bd, L, F, V, seed=99)[0].to(dev)
-        model.eval()
+        model.load_state_dict(sd)            # the seeded weights again (the train steps above moved them): the decode and beam
+        model.eval()                         # legs are then the same computation in every run
         with torch.no_grad():
             model(dfe, mode="test")
             torch.cuda.synchronize(dev)
@@ -416,6 +419,44 @@ def main():
                 "batch": Bd, "ms_per_call": round(bdt * 1e3, 2), "n_gpus": 1, "calls_timed": nbm}
         model.train()
 
+        # ---- BASELINE configs[2] in the same run (N = 1): B=256, bf16 operands / fp32 accumulate (s2vt_set_gemm_mode(1)),
+        # persistent recurrence kernels - the configuration north_star puts its roofline target on
+        config3 = None
+        if world == 1 and not bf and B != 256 and not args.no_config3:
+            prev_mode = lib.s2vt_set_gemm_mode(1)
+            try:
+                b3 = tuple(t.to(dev) for t in synth.make_batch(256, L, F, V, seed=777))
+                for _ in range(2):
+                    dp.train_step(model, crit, opt, b3[0], b3[1], b3[2], None)
+                torch.cuda.synchronize(dev)
+                t3 = time.perf_counter()
+                n3 = 5
+                for _ in range(n3):
+                    dp.train_step(model, crit, opt, b3[0], b3[1], b3[2], None)
+                torch.cuda.synchronize(dev)
+                d3 = (time.perf_counter() - t3) / n3
+                pr3 = profile(2, b3)
+                pair3 = step_bytes_fwd(256, H, H, s=2) + step_bytes_fwd(256, H, E + H, s=2)
+                fus, bus = pr3["step_fwd"][0] * 1e3 / (2 * T), pr3["step_bwd"][0] * 1e3 / (2 * T)
+                pers = lib.s2vt_set_recurrence_mode(-1) >= 1
+
+                def rec(kernel, us):
+                    gbs = (pair3 / 2) / (us * 1e-6) / 1e9
+                    return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_us": round(us, 3), "launches_per_step": 2 * T,
+                            "algorithmic_bytes_per_launch": pair3 // 2,
+                            "note": "per layer timestep; persistent-weights kernel (W_hh not re-streamed)" if pers else "per launch"}
+                config3 = {"workload": "BASELINE configs[2]: B=256, 80x4096 feats, hidden=embed=1000, vocab=12000, bf16 operands / "
+                                       "fp32 accumulate, Adam", "dtype": "bf16", "value": round(256 * L / d3, 1), "unit": "frames/s",
+                           "ms_per_step": round(d3 * 1e3, 3), "steps": n3,
+                           "roofline_lstm_step": rec("lstm_seq_fwd_bf16_persist_kernel" if pers else "lstm_step_fwd_bf16_kernel", fus),
+                           "roofline_lstm_step_bwd": rec("lstm_seq_bwd_bf16_persist_kernel" if pers else "lstm_step_bwd_bf16_kernel", bus),
+                           "gemm_tflops": round(gemm_flops_train(256, L, F, H, E, V) / 1e9 / pr3["gemm"][0], 1),
+                           "kernel_ms_per_step": {k: round(v[0], 3) for k, v in pr3.items()}}
+                del b3
+            finally:
+                lib.s2vt_set_gemm_mode(prev_mode)
+            log("config3: %s" % config3)
         log("decode: %s" % decode)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
@@ -479,6 +520,7 @@ def main():
             "rccl_ranks": dist.get_world_size() if use_pg else 1,
             "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if use_pg else None,
             "dp_b128": shard128,
+            "config3": config3,
         }
         print(json.dumps(out), flush=True)
     if use_pg:
