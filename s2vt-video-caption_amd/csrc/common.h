@@ -61,6 +61,10 @@ __device__ __forceinline__ int map_row_perm(const RowMap& m, int r) {
 // 16 bytes of zeros in device memory: the target of redirected out-of-range loads (see load4_guard).
 static __device__ __attribute__((aligned(16))) float g_zero4[4] = {0.f, 0.f, 0.f, 0.f};
 
+// Cell activations of the fp32 timestep kernels: hardware exp (v_exp_f32, ~1 ulp) + IEEE division; absolute error ~1.5e-7
+// for both (tanh as 1 - 2 / (1 + e^{2x}): exact limits +-1, no cancellation blow-up in absolute terms).  libm's
+// expf / tanhf cost ~3x the instructions in the epilogue of a latency-bound kernel for the same fp32-level accuracy.
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
 
 }  // namespace s2vt

@@ -277,12 +277,12 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
         float pre[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) pre[g] = read_sum<MT, NT, NWAVE>(red, bl, g * UN + u) + gxv[g];
-        const float ig = 1.0f / (1.0f + expf(-pre[0]));
-        const float fg = 1.0f / (1.0f + expf(-pre[1]));
-        const float gg = tanhf(pre[2]);
-        const float og = 1.0f / (1.0f + expf(-pre[3]));
+        const float ig = sigmoidf_(pre[0]);
+        const float fg = sigmoidf_(pre[1]);
+        const float gg = tanhf_(pre[2]);
+        const float og = sigmoidf_(pre[3]);
         const float c = fg * cpv + ig * gg;
-        const float h = og * tanhf(c);
+        const float h = og * tanhf_(c);
         p.h_out[(int64_t)b * p.ldho + unit] = h;
         if (p.h_out2) p.h_out2[(int64_t)b * p.ldho2 + unit] = h;
         p.c_out[(int64_t)b * p.ldco + unit] = c;
@@ -402,7 +402,7 @@ __device__ __forceinline__ void lstm_step_bwd_body(const StepBwdArgs& p, int bid
         const int b = eb, unit = eunit;
         const float dh = read_sum<MT, NT, NWAVE>(red, ebl, eul) + dhov;
         const float ig = stv[0], fg = stv[1], gg = stv[2], og = stv[3];
-        const float tc = tanhf(cv);
+        const float tc = tanhf_(cv);
         const float dc = dh * og * (1.0f - tc * tc) + dcv;
         const float d_o = dh * tc;
         float* dg = p.dg + (int64_t)b * p.lddg_out + unit;

@@ -181,12 +181,12 @@ __global__ __launch_bounds__(BNT) void lstm_step_fwd_bf16_kernel(StepFwdBf16Args
         float pre[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) pre[g] = read_sum32<MT, NT>(red, bl, g * UN + u) + gxv[e][g];
-        const float ig = 1.0f / (1.0f + expf(-pre[0]));
-        const float fg = 1.0f / (1.0f + expf(-pre[1]));
-        const float gg = tanhf(pre[2]);
-        const float og = 1.0f / (1.0f + expf(-pre[3]));
+        const float ig = sigmoidf_(pre[0]);
+        const float fg = sigmoidf_(pre[1]);
+        const float gg = tanhf_(pre[2]);
+        const float og = sigmoidf_(pre[3]);
         const float c = fg * cpv[e] + ig * gg;
-        const float h = og * tanhf(c);
+        const float h = og * tanhf_(c);
         if (p.h_out) p.h_out[(int64_t)b * p.ldho + unit] = h;
         p.hb_out[(int64_t)b * p.ldhbo + unit] = f2bf(h);
         p.c_out[(int64_t)b * p.ldco + unit] = c;
@@ -278,7 +278,7 @@ __global__ __launch_bounds__(BNT) void lstm_step_bwd_bf16_kernel(StepBwdBf16Args
         if (idx >= TM * TN || b >= p.B || unit >= p.H) continue;
         const float dh = read_sum32<MT, NT>(red, bl, ul) + dhov[e];
         const float ig = stv[e][0], fg = stv[e][1], gg = stv[e][2], og = stv[e][3];
-        const float tc = tanhf(cv[e]);
+        const float tc = tanhf_(cv[e]);
         const float dc = dh * og * (1.0f - tc * tc) + dcv[e];
         const float d_o = dh * tc;
         const float d4[4] = {dc * gg * ig * (1.0f - ig), dc * cpv[e] * fg * (1.0f - fg), dc * ig * (1.0f - gg * gg),
