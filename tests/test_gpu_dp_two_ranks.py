@@ -1,0 +1,104 @@
+"""GPU, world_size 2: two processes share the one card of the test box and average gradients through
+dp.FlatGradAllReducer.attach() - the backward writes into the flat buffer, s2vt_backward_wait_grads gates each gradient
+group, the all-reduces run on the side stream under the rest of the backward.  The collective backend is gloo (RCCL
+refuses two ranks on one device; on a node bench.py / train.py use "nccl" = RCCL, same code path above the backend).
+Two half-batch replicas must end where the single-process global-batch loop ends (mean of shard
+means = global mean, averaged gradients = global-batch gradients)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+STEPS = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup(cfg, B, rank=None, world=None):
+    sys.path.insert(0, ROOT)
+    import S2VTModel
+    import utils
+    from s2vt_video_caption_amd import dp, synth
+    d = dict(synth.CONFIGS[cfg])
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=11)
+    batch = synth.make_batch(B, d["L"], d["F"], d["V"], seed=21)
+    if rank is not None:
+        batch = dp.shard_batch(batch, rank, world)
+    feats, caps, mask = (t.to("cuda:0") for t in batch)
+    m = S2VTModel.S2VT(d["V"], d["F"], d["L"], dim_hid=d["H"], dim_embed=d["E"]).to("cuda:0")
+    m.load_state_dict(sd)
+    return m, utils.MaskCriterion(), feats, caps, mask
+
+
+def _worker(rank, world, port, out_dir, cfg, B):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m, crit, feats, caps, mask = _setup(cfg, B, rank, world)
+    from s2vt_video_caption_amd import capi, dp
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    red = dp.FlatGradAllReducer(m.parameters()).attach(m)
+    assert red.world == 2 and red.comm_stream is not None
+    losses, grads1 = [], None
+    for s in range(STEPS):
+        losses.append(float(dp.train_step(m, crit, opt, feats, caps, mask, red)))
+        if s == 0:
+            torch.cuda.synchronize()
+            grads1 = red.flat.detach().cpu().clone()
+    torch.cuda.synchronize()
+    capi.check_async_error()
+    torch.save({"losses": losses, "grads1": grads1, "params": {k: v.detach().cpu() for k, v in m.state_dict().items()}},
+               os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("cfg,B", [("tiny", 4), ("c1", 8), ("c2", 64)])
+def test_two_ranks_on_one_card_equal_the_global_batch(tmp_path, lib, cfg, B):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), cfg, B), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt")
+    r1 = torch.load(tmp_path / "rank1.pt")
+
+    # single process, global batch, plain autograd accumulation + Adam (train.py:116-127)
+    m, crit, feats, caps, mask = _setup(cfg, B)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    losses, grads1 = [], None
+    for s in range(STEPS):
+        opt.zero_grad()
+        loss = crit(m(feats, targets=caps[:, :-1], mode="train"), caps, mask)
+        loss.backward()
+        if s == 0:
+            grads1 = torch.cat([p.grad.detach().reshape(-1) for p in m.parameters() if p.requires_grad]).cpu()
+        opt.step()
+        losses.append(float(loss.detach()))
+    torch.cuda.synchronize()
+    final = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+    # the replicas hold the same averaged gradients and stay bitwise identical
+    assert torch.equal(r0["grads1"], r1["grads1"])
+    for k in final:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
+    # averaged shard gradients = global-batch gradients (fp32 summation order differs: norm-relative 1e-5)
+    rel = (r0["grads1"] - grads1).norm().item() / grads1.norm().item()
+    assert rel < 1e-5, rel
+    for s in range(STEPS):
+        assert abs(0.5 * (r0["losses"][s] + r1["losses"][s]) - losses[s]) < 5e-6 * max(1.0, abs(losses[s])), s
+    # Adam divides by sqrt(v): an element whose gradient is ~0 can move by up to lr per step in either direction, so
+    # parameters are compared against the step size, not the rounding error
+    for k in final:
+        assert (r0["params"][k] - final[k]).abs().max().item() < STEPS * 1e-4 * 0.05 + 1e-6, k
