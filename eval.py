@@ -2,9 +2,10 @@
 (`eval()` eval.py:30-60, `beam_eval()` :63-99) on top of the drop-in model — load a full-module checkpoint, decode the
 test split greedily or by beam search, map ids to words and cut at `<eos>` (eval.py:54-58, :90-96).
 
-The COCO caption metrics of the reference (eval.py:138-219) shell out to Java jars that the reference lists as missing
-(`.MISSING_LARGE_BLOBS`); they are outside the hot path and not reproduced here — `main()` writes the predictions as JSON
-in the format `COCOScorer.score` consumes ({video_id: caption}).
+`main()` writes the predictions as JSON ({video_id: caption}) and, with --gts, scores them as the reference's
+`__main__` does (eval.py:222-236: gts.json -> pred_to_coco_samples_IDs -> COCOScorer.score) with caption_metrics.py:
+BLEU-1..4, ROUGE-L, CIDEr.  METEOR and the Stanford tokenizer are Java jars the reference does not ship
+(`.MISSING_LARGE_BLOBS`); see caption_metrics.py for what stands in for them.
 """
 import argparse
 import json
@@ -46,6 +47,24 @@ def generate(model_path, caption_file, feats_path, batch_size=10, mode='test', b
     return preds
 
 
+def to_samples(prediction_dict, gts):
+    """{video_id: caption} -> ({video_id: [{'image_id', 'caption'}]}, ids) for the ids that have ground truth
+    (pred_to_coco_samples_IDs, eval.py:138-151)."""
+    samples = {k: [{'image_id': k, 'caption': v}] for k, v in prediction_dict.items() if k in gts}
+    return samples, list(samples.keys())
+
+
+def score(prediction_dict, gts_file):
+    """Metrics of a prediction dictionary against a gts.json ({'gts': {video_id: [{'caption': ...}, ...]}})."""
+    import caption_metrics
+    with open(gts_file, encoding='utf-8') as f:
+        gts = json.load(f)['gts']
+    samples, ids = to_samples(prediction_dict, gts)
+    scorer = caption_metrics.CaptionScorer()
+    scorer.score(gts, samples, ids)
+    return scorer
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--model-path", required=True)
@@ -54,12 +73,18 @@ def main():
     ap.add_argument("--batch-size", type=int, default=10)
     ap.add_argument("--beam", type=int, default=0, help="beam width (0: greedy)")
     ap.add_argument("--out", default="predictions.json")
+    ap.add_argument("--gts", default=None, help="gts.json: also print BLEU / ROUGE-L / CIDEr of the predictions")
     a = ap.parse_args()
     preds = generate(a.model_path, a.caption_file, a.feats_path, a.batch_size,
                      'beam_search' if a.beam else 'test', beam_width=a.beam or 5)
     with open(a.out, 'w', encoding='utf-8') as f:
         json.dump(preds, f, ensure_ascii=False, indent=1)
     print("wrote {} captions to {}".format(len(preds), a.out))
+    if a.gts:
+        scorer = score(preds, a.gts)
+        print("***********************")
+        print(scorer.eval)
+        print("***********************")
 
 
 if __name__ == '__main__':
