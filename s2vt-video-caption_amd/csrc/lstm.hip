@@ -133,9 +133,11 @@ __device__ __forceinline__ void wave_gemm_nt(f32x4 (&acc)[MT][NT][NA], const flo
 
 // Sum the NWAVE waves' partial tiles: every wave writes its accumulators to red[wave][row][col],
 // after which red holds 4 partials per output.  16x16 C/D layout: col = lane&15, row = 4*(lane>>4)+reg.
-template <int MT, int NT, int NA>
+// RLD = row stride of the partial tiles in floats, chosen per kernel so that the EPILOGUE's read pattern is free of bank
+// conflicts (ds_read_b32: 32 banks, conflicts counted per 32-lane half).
+template <int MT, int NT, int NA, int RLD = 16 * NT + 1>
 __device__ __forceinline__ void write_partials(const f32x4 (&acc)[MT][NT][NA], float* red, int wave, int lane) {
-    constexpr int TM = 16 * MT, RLD = 16 * NT + 1;
+    constexpr int TM = 16 * MT;
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -148,9 +150,9 @@ __device__ __forceinline__ void write_partials(const f32x4 (&acc)[MT][NT][NA], f
             }
 }
 
-template <int MT, int NT, int NWAVE>
+template <int MT, int NT, int NWAVE, int RLD = 16 * NT + 1>
 __device__ __forceinline__ float read_sum(const float* red, int row, int col) {
-    constexpr int TM = 16 * MT, RLD = 16 * NT + 1;
+    constexpr int TM = 16 * MT;
     float s = red[row * RLD + col];
 #pragma unroll
     for (int w = 1; w < NWAVE; ++w) s += red[(w * TM + row) * RLD + col];
@@ -267,16 +269,20 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
         wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.x2, p.w2, arow, brow, p.K2, sA, sB, wave, lane);
     }
 
+    // a half-wave of the epilogue reads 4 rows x UN = 8 consecutive columns per gate: row stride 8 (mod 32) puts the 32
+    // lanes on 32 banks (stride 33 put them on 11: 4-way conflicts on each of the 32 reads of a thread)
+    constexpr int RLD = TN + 8;
+    static_assert(UN == 8 && NWAVE * TM * RLD <= NWAVE * (TM + TN) * SLD, "partial tiles fit the staging area");
     __syncthreads();
     float* red = smem;
-    write_partials<MT, NT, NA>(acc, red, wave, lane);
+    write_partials<MT, NT, NA, RLD>(acc, red, wave, lane);
     __syncthreads();
 
     if (evalid) {
         const int bl = ebl, u = eu, b = eb, unit = eunit;
         float pre[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pre[g] = read_sum<MT, NT, NWAVE>(red, bl, g * UN + u) + gxv[g];
+        for (int g = 0; g < 4; ++g) pre[g] = read_sum<MT, NT, NWAVE, RLD>(red, bl, g * UN + u) + gxv[g];
         const float ig = sigmoidf_(pre[0]);
         const float fg = sigmoidf_(pre[1]);
         const float gg = tanhf_(pre[2]);
