@@ -134,7 +134,10 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
 
 /* MaskCriterion's inner nn.CrossEntropyLoss() (utils.py:11,22): mean CE of logits [B, L-1, V] against
  * target[:, 1:] (target int64 [B, L], row stride target_ld).  lse [B*(L-1)] and rowloss [B*(L-1)] are
- * caller-provided scratch (lse is consumed by the backward); loss_out is one device float. */
+ * caller-provided scratch (lse is consumed by the backward); loss_out is one device float.
+ * A target id outside [0, V) (nn.CrossEntropyLoss raises IndexError; ignore_index is not used by the reference) is
+ * detected on the device and reported as S2VT_ERR_INDEX by s2vt_check_async_error / the next call, like the
+ * embedding's check in s2vt_train_forward; the row's loss is then computed against the clamped id. */
 int s2vt_mean_ce_forward(int32_t B, int32_t Lm1, int32_t V, const float* logits, const int64_t* target,
                          int64_t target_ld, float* lse, float* rowloss, float* loss_out, void* stream);
 /* dlogits = (softmax(logits) - onehot(target)) * gout[0] / (B*(L-1)); gout is a device scalar. */

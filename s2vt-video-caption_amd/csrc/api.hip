@@ -41,7 +41,7 @@ int check_hip(hipError_t e, const char* what) {
 // event complete reports the error.  One step late by construction, never silent; callers that synchronise anyway
 // (loss.item()) call s2vt_check_async_error(1) right there and get it immediately.
 struct ErrRecord { int* host; hipEvent_t ev; bool pending; };
-static ErrRecord g_async[2] = {{nullptr, nullptr, false}, {nullptr, nullptr, false}};     // [0] forward, [1] backward
+static ErrRecord g_async[3] = {{nullptr, nullptr, false}, {nullptr, nullptr, false}, {nullptr, nullptr, false}};   // forward, backward, loss
 static int read_record(ErrRecord& r, bool wait) {
     if (!r.pending) return 0;
     if (wait) {
@@ -55,8 +55,9 @@ static int read_record(ErrRecord& r, bool wait) {
     const int bad_target = r.host[0], timed_out = r.host[1];
     r.host[0] = r.host[1] = 0;
     if (bad_target) {
-        set_error("index out of range: a target id of the previous s2vt_train_forward lies outside [0, vocab_size) "
-                  "(the reference raises IndexError in nn.Embedding, S2VTModel.py:71)");
+        set_error("index out of range: a target id of the previous s2vt_train_forward / s2vt_mean_ce_forward lies outside "
+                  "[0, vocab_size) (the reference raises IndexError in nn.Embedding, S2VTModel.py:71, and in "
+                  "nn.CrossEntropyLoss, utils.py:22)");
         return S2VT_ERR_INDEX;
     }
     if (timed_out) {
@@ -66,7 +67,7 @@ static int read_record(ErrRecord& r, bool wait) {
     return 0;
 }
 static int poll_async_error(bool wait) {
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < 3; ++k) {
         int rc = read_record(g_async[k], wait);
         if (rc) return rc;
     }
@@ -1468,9 +1469,23 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
 int s2vt_mean_ce_forward(int32_t B, int32_t Lm1, int32_t V, const float* logits, const int64_t* target,
                          int64_t target_ld, float* lse, float* rowloss, float* loss_out, void* stream) {
     S2VT_REQUIRE(B > 0 && Lm1 > 0 && V > 0, "s2vt_mean_ce_forward: bad dims");
-    ProfScope ps((hipStream_t)stream, K_CE, 1);
-    return mean_ce_fwd((hipStream_t)stream, logits, (int64_t)B * Lm1, V, target, Lm1, target_ld, lse, rowloss, loss_out,
-                       nullptr);
+    hipStream_t st = (hipStream_t)stream;
+    // target ids outside [0, V): flagged on the device, reported like the embedding's (s2vt_check_async_error).  The four
+    // flag words are the only device memory the library owns: 16 bytes per device, allocated on first use.
+    static int* flags_of[64] = {};
+    int dev = 0;
+    S2VT_HIP(hipGetDevice(&dev));
+    S2VT_REQUIRE(dev >= 0 && dev < 64, "s2vt_mean_ce_forward: device index %d", dev);
+    if (!flags_of[dev]) S2VT_HIP(hipMalloc(reinterpret_cast<void**>(&flags_of[dev]), 4 * sizeof(int)));
+    const int rc0 = poll_async_error(false);
+    int rc;
+    if ((rc = fill_zero(st, flags_of[dev], 4 * sizeof(int)))) return rc;
+    {
+        ProfScope ps(st, K_CE, 1);
+        if ((rc = mean_ce_fwd(st, logits, (int64_t)B * Lm1, V, target, Lm1, target_ld, lse, rowloss, loss_out, flags_of[dev])))
+            return rc;
+    }
+    return rc0 ? rc0 : post_async_error(st, flags_of[dev], 2);
 }
 int s2vt_mean_ce_backward(int32_t B, int32_t Lm1, int32_t V, const float* logits, const int64_t* target,
                           int64_t target_ld, const float* lse, const float* gout, float* dlogits, void* stream) {

@@ -332,6 +332,30 @@ def test_out_of_range_target_raises_index_error(lib):
     assert torch.isfinite(logits).all()
 
 
+def test_out_of_range_loss_target_raises_index_error(lib):
+    """The LAST caption column never passes through the embedding (targets[:, :-1] feeds the model) but it is a class index
+    of the loss (utils.py:22 against target[:, 1:]): nn.CrossEntropyLoss raises for an id outside the vocabulary, here
+    the loss kernel flags it and the error surfaces at the next synchronisation point."""
+    import utils
+    from s2vt_video_caption_amd import capi
+    d = synth.CONFIGS["tiny"]
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=3)
+    feats, caps, mask = (t.to(DEV) for t in synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=3))
+    m = _model(d, sd)
+    crit = utils.MaskCriterion()
+    logits = m(feats, targets=caps[:, :-1], mode="train")
+    bad = caps.clone()
+    bad[0, -1] = d["V"] + 7
+    crit(logits, bad, mask)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        capi.check_async_error()
+    loss = crit(logits, caps, mask)          # a clean call works again
+    torch.cuda.synchronize()
+    capi.check_async_error()
+    assert torch.isfinite(loss)
+
+
 @pytest.mark.parametrize("B,gemm_mode", [(5, 3), (64, 3), (64, 1)])
 def test_out_dropout_train_mode_matches_oracle_with_the_same_mask(lib, B, gemm_mode):
     """out_dropout > 0 (S2VTModel.py:25,79): the decode-step hidden states are masked between word_rnn and out_linear.  With
