@@ -611,50 +611,6 @@ static int check_forward_record(const void* ws, const s2vt_dims& d, bool planes)
     return 0;
 }
 
-// ---- argument builders for single timesteps (used by the paired-launch schedule)
-static StepFwdArgs fwd_args(int t, int B, int H, float* gx_stash, int n_gx, const float* bias, const float* w_hh,
-                            float* h_all, float* c_all) {
-    const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
-    StepFwdArgs a;
-    memset(&a, 0, sizeof(a));
-    a.B = B; a.H = H;
-    a.h_prev = t ? h_all + (t - 1) * BH : nullptr; a.ldh = H;
-    a.w_hh = w_hh; a.ldw = H;
-    a.gx = (t < n_gx) ? gx_stash + t * B4H : nullptr; a.ldgx = 4 * (int64_t)H;
-    a.bias = bias;
-    a.c_prev = t ? c_all + (t - 1) * BH : nullptr; a.ldc = H;
-    a.h_out = h_all + t * BH; a.ldho = H;
-    a.c_out = c_all + t * BH; a.ldco = H;
-    a.stash = gx_stash + t * B4H; a.ldst = 4 * (int64_t)H;
-    return a;
-}
-static StepBwdArgs bwd_args(int t, int T, int B, int H, const float* w_hh_t, const float* dh_out, int dh_first,
-                            const float* c_all, float* stash_dg, float* dc) {
-    const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
-    StepBwdArgs a;
-    memset(&a, 0, sizeof(a));
-    a.B = B; a.H = H;
-    a.dg_next = (t < T - 1) ? stash_dg + (t + 1) * B4H : nullptr; a.lddg = 4 * (int64_t)H;
-    a.w_hh_t = w_hh_t; a.ldwt = 4 * (int64_t)H;
-    a.dh_out = (dh_out && t >= dh_first) ? dh_out + (int64_t)(t - dh_first) * BH : nullptr; a.lddho = H;
-    a.stash = stash_dg + t * B4H; a.ldst = 4 * (int64_t)H;
-    a.c = c_all + t * BH; a.ldc = H;
-    a.c_prev = t ? c_all + (t - 1) * BH : nullptr; a.ldcp = H;
-    a.dc = dc; a.lddc = H;
-    a.dc_is_zero = (t == T - 1) ? 1 : 0;
-    a.dg = stash_dg + t * B4H; a.lddg_out = 4 * (int64_t)H;
-    return a;
-}
-// Paired launches (vid step of block k+1 with word step of block k in ONE dispatch, everything on one stream):
-// correct (S2VT_DUAL=1 passes the parity suite) but measured 8 % SLOWER than the two-stream pipeline (14.67 vs
-// 13.58 ms per C2 step): the block's plane split + input GEMM then sit between the step blocks on the same stream.
-// Kept as an option for systems where the two streams cannot be made concurrent; default off.
-static int g_dual = -1;
-static bool dual_on() {
-    if (g_dual < 0) { const char* e = getenv("S2VT_DUAL"); g_dual = e ? (atoi(e) != 0) : 0; }
-    return g_dual != 0;
-}
-
 // out_mask: optional out_drop mask (S2VTModel.py:79), time-major [(L-1)*B, H], entries 0 or 1/(1-p); nullptr = no dropout.
 // The masked decode-step hidden states replace the row planes of the logits GEMM (the recurrence is done with them by then).
 static int masked_logits_planes(const Lane& ln, const TrainWS& w, const PlaneWS& q, const float* out_mask, int B, int L, int H) {
@@ -704,46 +660,6 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
     if ((rc = pdual(la, w.x1, H, ID, L * B, H, &q.x1, 0, &q.x1T, 0, nullptr))) return rc;
     if ((rc = pgemm(la, L * B, 4 * H, H, q.x1, 0, 0, q.wih1, 0, 0, w.s1, 4 * H, ID, w.bsum1, false))) return rc;
     const std::vector<int> bd = pipe_bounds(T, L, blk);
-    if (!bf && dual_on() && blk > 0) {
-        // Paired-launch schedule: every timestep launch carries the vid_rnn step of block k together with the
-        // word_rnn step of block k-1 (one dispatch, co-resident by construction); the block's plane split and input
-        // GEMM run on the same stream between blocks, the h2 plane splits on the side stream.
-        if ((rc = handoff(sx, st, ev++))) return rc;              // lane A uses the W_v planes from here on
-        const int nb = (int)bd.size() - 1;
-        for (int k = 0; k <= nb; ++k) {
-            const int v0 = (k < nb) ? bd[k] : 0, v1 = (k < nb) ? bd[k + 1] : 0;          // vid block k
-            const int w0 = (k >= 1) ? bd[k - 1] : 0, w1 = (k >= 1) ? bd[k] : 0;          // word block k-1
-            const int nv = v1 - v0, nw = w1 - w0, n = nv > nw ? nv : nw;
-            {
-                ProfScope ps(st, K_STEP_FWD, nv + nw);
-                for (int i = 0; i < n; ++i) {
-                    const bool hv = i < nv, hw = i < nw;
-                    StepFwdArgs av, aw;
-                    if (hv) av = fwd_args(v0 + i, B, H, w.s1, L, w.bsum1, p->vid_w_hh, w.h1, w.c1);
-                    if (hw) aw = fwd_args(w0 + i, B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2);
-                    if (hv && hw) rc = lstm_step_fwd2(st, av, &aw);
-                    else rc = lstm_step_fwd2(st, hv ? av : aw, nullptr);
-                    if (rc) return rc;
-                }
-            }
-            if (nv) {   // vid_out half of the word_rnn gate input for block k
-                const bool cap = v0 >= L;
-                if ((rc = pdual(la, w.h1 + v0 * BH, H, ID, nv * B, H, &q.h1, v0 * B, &q.h1T, v0 * B, nullptr))) return rc;
-                if ((rc = pgemm(la, nv * B, 4 * H, H, q.h1, v0 * B, 0, q.wv, 0, 0, w.s2 + v0 * B4H, 4 * H, ID,
-                                cap ? nullptr : w.bsum2, cap)))
-                    return rc;
-            }
-            if (nw) {   // h2 planes of block k-1 on the side stream
-                const bool cap = w0 >= L;
-                if ((rc = handoff(st, sx, ev++))) return rc;
-                if ((rc = pdual(lb, w.h2 + w0 * BH, H, ID, nw * B, H, cap ? &q.h2r : nullptr, w0 * B, &q.h2T, w0 * B, nullptr)))
-                    return rc;
-            }
-        }
-        if ((rc = handoff(sx, st, ev++))) return rc;
-        if ((rc = masked_logits_planes(la, w, q, out_mask, B, L, H))) return rc;
-        return pgemm(la, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
-    }
     if (!bf && blk > 0 && persist_f32_on() && lstm_seq_fwd_f32_persist_supported(B, H)) {
         // fp32 persistent schedule (lstm_persist_f32.hip), ONE stream: stage k = vid_rnn block k next to word_rnn block k-1
         if ((rc = handoff(sx, st, ev++))) return rc;
@@ -864,8 +780,6 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = pgemm(la, R, H, V, q.dlog, 0, 0, q.woT, 0, 0, w.dh2dec, H, perm(L - 1, B), nullptr, false))) return rc;
     if (out_mask && (rc = mul_vectors(st, w.dh2dec, out_mask, w.dh2dec, (int64_t)R * H))) return rc;      // autograd of out_drop
     if ((rc = transpose_f32(st, p->word_w_hh, 4 * H, H, w.wt2))) return rc;
-    const bool paired = !bf && dual_on() && blk > 0;      // both layers' BPTT steps run on the caller's stream
-    if (paired && (rc = transpose_f32(st, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     // lane B meanwhile: out_linear weight/bias gradients (k = batch-major row index) and W_hh1^T
     if (out_mask) {      // dW_o sees the masked hidden states (dx1 is free until the vid_rnn input gradient)
         if ((rc = mul_vectors(sx, w.h2 + L * BH, out_mask, w.dx1, (int64_t)R * H))) return rc;
@@ -874,7 +788,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = pgemm(lb, V, H, R, q.dlogT, 0, 0, q.h2decT, 0, 0, g->out_w, H, ID, nullptr, false))) return rc;
     if ((rc = colsum_finish(sx, w.colsum_c, cdiv(R, 64), V, g->out_b, false))) return rc;
     if ((rc = grads_ready(0, sx))) return rc;
-    if (!paired && (rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
+    if ((rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     const std::vector<int> bd = pipe_bounds(T, L, blk);
     if (!bf && blk > 0 && persist_f32_on() && lstm_seq_bwd_f32_persist_supported(B, H)) {
         // fp32 persistent schedule, ONE stream: stage k = word_rnn BPTT of block k next to vid_rnn BPTT of block k+1
@@ -940,40 +854,6 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
             }
         }
         if ((rc = handoff(st, sx, ev++))) return rc;               // lane B's parameter-gradient GEMMs need dG1
-    } else if (paired) {
-        // Paired-launch schedule (see the forward): word_rnn BPTT step of block k with vid_rnn BPTT step of block k+1
-        const int nb = (int)bd.size() - 1;
-        for (int k = nb - 1; k >= -1; --k) {
-            const int w0 = (k >= 0) ? bd[k] : 0, w1 = (k >= 0) ? bd[k + 1] : 0;                  // word block k
-            const int v0 = (k + 1 < nb) ? bd[k + 1] : 0, v1 = (k + 1 < nb) ? bd[k + 2] : 0;      // vid block k+1
-            const int nw = w1 - w0, nv = v1 - v0, n = nv > nw ? nv : nw;
-            {
-                ProfScope ps(st, K_STEP_BWD, nv + nw);
-                for (int i = 0; i < n; ++i) {
-                    const bool hw = i < nw, hv = i < nv;
-                    StepBwdArgs aw, av;
-                    if (hw) aw = bwd_args(w1 - 1 - i, T, B, H, w.wt2, w.dh2dec, L, w.c2, w.s2, w.dc2);
-                    if (hv) av = bwd_args(v1 - 1 - i, T, B, H, w.wt1, w.dh1, 0, w.c1, w.s1, w.dc1);
-                    if (hw && hv) rc = lstm_step_bwd2(st, aw, &av);
-                    else rc = lstm_step_bwd2(st, hw ? aw : av, nullptr);
-                    if (rc) return rc;
-                }
-            }
-            if (nw) {
-                if ((rc = pdual(la, w.s2 + w0 * B4H, 4 * H, ID, nw * B, 4 * H, &q.dg2, w0 * B, &q.dg2T, w0 * B,
-                                w.colsum_a + (int64_t)(w0 * B / 64) * 4 * H)))
-                    return rc;
-                if ((rc = pgemm(la, nw * B, H, 4 * H, q.dg2, w0 * B, 0, q.wvT, 0, 0, w.dh1 + w0 * BH, H, ID, nullptr, false)))
-                    return rc;
-            }
-            if (nv) {
-                if ((rc = handoff(st, sx, ev++))) return rc;
-                if ((rc = pdual(lb, w.s1 + v0 * B4H, 4 * H, ID, nv * B, 4 * H, (v0 < L) ? &q.dg1 : nullptr, v0 * B, &q.dg1T,
-                                v0 * B, w.colsum_b + (int64_t)(v0 * B / 64) * 4 * H)))
-                    return rc;
-            }
-        }
-        if ((rc = handoff(st, sx, ev++))) return rc;
     } else
     for (size_t k = bd.size() - 1; k >= 1; --k) {
         const int t0 = bd[k - 1], t1 = bd[k];

@@ -106,9 +106,6 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
     const int a_off = (wm * (MI / 2)) * X_REC + lh * 1024 + li * 16;
     const int b_off = (NRA + wn) * X_REC + lh * 1024 + li * 16;
 
-#ifndef S2VT_X3_SPREAD
-#define S2VT_X3_SPREAD 1      // 1: one DMA request after each of the six MFMA groups; 0: all six right after the barrier
-#endif
     // One k16 stage.  MORE (compile time): stage s+2 exists and is requested during this stage.
     auto stage = [&](int s, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
@@ -118,7 +115,6 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         const unsigned char* g2 = src + (int64_t)(s + 2) * X_REC;
         unsigned char* l2 = ldst + ((s + 2) % X_NS) * X_STAGE;
-        if (MORE && !S2VT_X3_SPREAD) request(s + 2);
         const unsigned char* st = smem + (s % X_NS) * X_STAGE;
         bf16x8 a[3][MI], b[3][2];
         // Fragment reads are issued in the order the products consume them - (a1 b1) (a0 b2) (a2 b0) - as inline asm
@@ -143,24 +139,20 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
 #define X3_PROD(PA, PB)                                                                                          \
     _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)           \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][mi], b[PB][ni], acc[mi][ni], 0, 0, 0);
-#define X3_REQ(J) if (MORE && S2VT_X3_SPREAD && loader) glds16(g2 + (J) * 1024, l2 + (J) * 1024);
+#define X3_REQ(J) if (MORE && loader) glds16(g2 + (J) * 1024, l2 + (J) * 1024);
         X3_WAIT(12, 8, 1, 1) X3_PROD(1, 1) X3_REQ(0) X3_WAIT(6, 4, 0, 2) X3_PROD(0, 2) X3_REQ(1) X3_WAIT(0, 0, 2, 0) X3_PROD(2, 0) X3_REQ(2)
         X3_PROD(0, 1) X3_REQ(3) X3_PROD(1, 0) X3_REQ(4) X3_PROD(0, 0) X3_REQ(5)
 #undef X3_WAIT
 #undef X3_RD
 #undef X3_LDA
 #undef X3_LDB
-#ifndef S2VT_X3_PIN
-#define S2VT_X3_PIN 1         // pin the issue order: 18 fragment reads, then 6 x (8 MFMAs, 1 DMA request)
-#endif
-#if S2VT_X3_PIN
+        // pin the issue order: 18 fragment reads, then 6 x (8 MFMAs, 1 DMA request)
         __builtin_amdgcn_sched_group_barrier(0x100, 3 * (MI + 2), 0);
 #pragma unroll
         for (int g = 0; g < 6; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 2 * MI, 0);
-            if (MORE && S2VT_X3_SPREAD && MI == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            if (MORE && MI == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
-#endif
 #undef X3_REQ
 #undef X3_PROD
     };

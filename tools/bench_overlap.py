@@ -10,7 +10,7 @@ import torch  # noqa: E402
 
 from s2vt_video_caption_amd import build  # noqa: E402
 
-VARIANTS = {"base": [], "gemm1wg": ["S2VT_X3_LDS_PAD=30720"]}
+VARIANTS = {"base": []}
 B, H, T = 64, 1000, 159
 dev = "cuda:0"
 vp, i64 = ctypes.c_void_p, ctypes.c_int64
