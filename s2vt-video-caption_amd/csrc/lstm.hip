@@ -15,8 +15,8 @@
 // Both operands are k-contiguous (h/dG rows, W_hh rows / W_hh^T rows), LDS row stride 36 floats:
 // 16-B aligned staging writes and conflict-free ds_read_b128 operand reads.  Within each 16-wide
 // k block lane quarter q owns k = 4q..4q+3 for both operands (fixed summation order).
-// (These are the launch-per-timestep kernels: decode, beam search, shapes the persistent kernels of
-// lstm_persist_f32.hip do not take.)
+// (These are the launch-per-timestep kernels: the fp32 training path (two layers on two streams, overlapped with the
+// batched GEMMs), decode and beam search; the persistent kernels of lstm_persist*.hip are the bf16 configuration's.)
 #include "common.h"
 #include "kernels.h"
 
