@@ -280,5 +280,7 @@ if __name__ == "__main__":
         gen("c2", seed=160, n_steps=2, out_scale=2.0, do_beam=False)
     if "c3" in which:     # BASELINE configs[2] shape (B=256): ONE fp32 reference train step; the bf16 GPU run is compared
         gen("c3", seed=5, n_steps=1, out_scale=1.0, do_beam=False, greedy=False)      # with it at bf16 bounds
+    if "c4" in which:     # BASELINE configs[3]: the B=128 shard one GPU of the 8-way data-parallel run takes; two fp32 train steps
+        gen("c4", seed=7, n_steps=2, out_scale=1.0, do_beam=False, greedy=False)
     if "c5beam" in which:
         gen_beam_only("c5beam", "c5", seed=C5_CHOICE[0], beam_b=4, beam_width=5, out_scale=C5_CHOICE[1])

@@ -143,12 +143,23 @@ def test_c2_train_with_fp32_persistent_recurrence(lib, golden):
         lib.s2vt_set_recurrence_mode(prev)
 
 
-def _c2_body(g, d, sd, feats, caps, mask):
+def test_c4_shard_full_size_against_reference_golden(lib, golden):
+    """BASELINE configs[3] per-GPU shard: B=128 at full dims (the batch one rank of the 8-way data-parallel run trains on),
+    two fp32 train steps of the reference (tests/golden/c4.npz): loss within 1e-4, logits slice, every gradient by norm,
+    sum and leading entries.  (Greedy / beam ids at B=128 are test_c5_dims_...; the all-reduce above the shard is
+    tests/test_gpu_dp_two_ranks.py.)"""
+    g = golden("c4")
+    d, sd, feats, caps, mask = _setup(g, "c4")
+    _c2_body(g, d, sd, feats, caps, mask, greedy=False)
+
+
+def _c2_body(g, d, sd, feats, caps, mask, greedy=True):
     m = _model(d, sd)
-    m.eval()
-    with torch.no_grad():
-        ids = m(feats.to(DEV), mode="test").cpu().numpy()
-    np.testing.assert_array_equal(ids, g["greedy_ids"])          # bit-exact, every row, every step
+    if greedy:
+        m.eval()
+        with torch.no_grad():
+            ids = m(feats.to(DEV), mode="test").cpu().numpy()
+        np.testing.assert_array_equal(ids, g["greedy_ids"])          # bit-exact, every row, every step
     m.train()
     losses, grads, logits = _train(m, feats, caps, mask, int(g["n_steps"]))
     assert np.abs(np.array(losses) - g["losses"]).max() < 1e-4, (losses, g["losses"])
