@@ -145,6 +145,10 @@ def main():
                     help="0 fp32-input MFMA, 3 split-precision bf16x3 (default, fp32-equivalent), 1 bf16 operands "
                          "(BASELINE configs[2]: use with --batch 256)")
     ap.add_argument("--no-config3", action="store_true", help="skip the B=256 bf16 sub-record (BASELINE configs[2])")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed steps and the live kernel timing of the headline workload (no B=128 shard, isolated "
+                         "pass, decode, beam, config3, CPU baseline): what tools/profile_round2.sh runs under rocprofv3, so "
+                         "that the kernel-stats averages are those of the headline workload alone")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU-only rehearsal of the N-rank launch path (gloo); prints n_gpus")
     args = ap.parse_args()
@@ -235,7 +239,7 @@ def main():
     # ---- BASELINE configs[3] shard: B=128 per GPU (global 1024 at 8 GPUs), same step, every rank takes part (sub-record;
     # the headline stays B per GPU so that N=1 agrees with the single-GPU line)
     shard128 = None
-    if B != 128 and mode != 1:
+    if B != 128 and mode != 1 and not args.headline_only:
         f2, c2, m2 = synth.make_batch(128, L, F, V, seed=4321 + rank)
         f2, c2, m2 = f2.to(dev), c2.to(dev), m2.to(dev)
         for _ in range(2):
@@ -357,72 +361,80 @@ def main():
             return rg, rs, rb
 
         live = profile()
-        prev_blk = lib.s2vt_set_pipeline_block(0)
-        alone = profile()
-        lib.s2vt_set_pipeline_block(prev_blk)
-        log("profiled steps done (pipeline block %d)" % prev_blk)
+        prev_blk = lib.s2vt_set_pipeline_block(0)          # (returns the block in use ...
+        lib.s2vt_set_pipeline_block(prev_blk)              # ... and this puts it back)
         roof_gemm, roof_step, roof_bstep = rooflines(live, "live, layers pipelined (block %d)" % prev_blk, persist_bf16 or persist_f32)
-        # pipeline off = one launch per timestep, every kernel alone on the GPU (the persistent kernels need the block schedule)
-        roof_gemm_alone, roof_step_alone, roof_bstep_alone = rooflines(alone, "pipeline off: launch per timestep, every kernel alone on the GPU", False)
+        if args.headline_only:
+            alone = live
+            roof_gemm_alone = roof_step_alone = roof_bstep_alone = None
+        else:
+            lib.s2vt_set_pipeline_block(0)
+            alone = profile()
+            lib.s2vt_set_pipeline_block(prev_blk)
+            # pipeline off = one launch per timestep, every kernel alone on the GPU (the persistent kernels need the block schedule)
+            roof_gemm_alone, roof_step_alone, roof_bstep_alone = rooflines(alone, "pipeline off: launch per timestep, every kernel alone on the GPU", False)
+        log("profiled steps done (pipeline block %d)" % prev_blk)
         gname = roof_gemm["kernel"]
         fam = {gname: live["gemm"][0], roof_step["kernel"]: live["step_fwd"][0],
                roof_bstep["kernel"]: live["step_bwd"][0], "ce": live["ce"][0]}
-        fam_alone = {gname: alone["gemm"][0], roof_step_alone["kernel"]: alone["step_fwd"][0],
-                     roof_bstep_alone["kernel"]: alone["step_bwd"][0], "ce": alone["ce"][0]}
+        fam_alone = None if args.headline_only else {gname: alone["gemm"][0], roof_step_alone["kernel"]: alone["step_fwd"][0],
+                                                     roof_bstep_alone["kernel"]: alone["step_bwd"][0], "ce": alone["ce"][0]}
         # The headline roofline is the fused LSTM TIMESTEP (forward): it is the kernel north_star puts its target on, and the
         # timestep family (forward + BPTT) is the largest share of the kernel time of a step (the batched GEMMs are second).
         roofline = dict(roof_step)
         roofline["family_ms_per_step"] = {"timestep_fwd+bwd": round(fam[roof_step["kernel"]] + fam[roof_bstep["kernel"]], 3),
                                           "batched_gemm": round(fam[gname], 3)}
 
-        # ---- greedy decode captions/s (one mode='test' call per measurement) + its out_linear/argmax kernel
-        Bd = args.decode_batch or 128        # BASELINE configs[4]: inference at B=128
-        dfe = feats[:Bd] if Bd <= B else synth.make_batch(Bd, L, F, V, seed=99)[0].to(dev)
-        model.load_state_dict(sd)            # the seeded weights again (the train steps above moved them): the decode and beam
-        model.eval()                         # legs are then the same computation in every run
-        with torch.no_grad():
-            model(dfe, mode="test")
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            nd = 10
-            for _ in range(nd):
-                ids = model(dfe, mode="test")
-            torch.cuda.synchronize(dev)
-            ddt = (time.perf_counter() - t1) / nd
-            capi.check(lib.s2vt_prof_reset(), "prof_reset")
-            capi.check(lib.s2vt_prof_enable(1), "prof_enable")
-            model(dfe, mode="test")
-            torch.cuda.synchronize(dev)
-            capi.check(lib.s2vt_prof_enable(0), "prof_enable")
-            am_ms, am_n = capi.prof_read(4)
-            capi.check(lib.s2vt_prof_reset(), "prof_reset")
-        am_us = am_ms * 1e3 / max(am_n, 1)
-        am_bytes = 4 * V * H + 4 * V + 4 * Bd * H + 8 * Bd         # W_o + b_o + h + packed argmax words
-        decode = {"metric": "greedy-decode captions/sec", "value": round(Bd / ddt, 1), "unit": "captions/s",
-                  "batch": Bd, "ms_per_call": round(ddt * 1e3, 2), "n_gpus": 1, "calls_timed": nd,
-                  "roofline_logits_argmax": {"kernel": "logits_argmax_kernel", "bound": "hbm", "achieved": round(am_bytes / (am_us * 1e-6) / 1e9, 1),
-                                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(am_bytes / (am_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                             "avg_launch_us": round(am_us, 2), "launches_per_call": am_n,
-                                             "algorithmic_bytes_per_launch": am_bytes,
-                                             "gflop_per_launch": round(2.0 * Bd * V * H / 1e9, 2), "traffic": None}}
-        # ---- beam search (BASELINE configs[4]: B=128, beam_size 5, depth 30)
-        with torch.no_grad():
-            model(dfe, mode="beam_search", beam_width=5, max_beam_depth=30)
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            nbm = 3
-            for _ in range(nbm):
+        decode = beam = None
+        if not args.headline_only:
+            # ---- greedy decode captions/s (one mode='test' call per measurement) + its out_linear/argmax kernel
+            Bd = args.decode_batch or 128        # BASELINE configs[4]: inference at B=128
+            dfe = feats[:Bd] if Bd <= B else synth.make_batch(Bd, L, F, V, seed=99)[0].to(dev)
+            model.load_state_dict(sd)            # the seeded weights again (the train steps above moved them): the decode and beam
+            model.eval()                         # legs are then the same computation in every run
+            with torch.no_grad():
+                model(dfe, mode="test")
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                nd = 10
+                for _ in range(nd):
+                    ids = model(dfe, mode="test")
+                torch.cuda.synchronize(dev)
+                ddt = (time.perf_counter() - t1) / nd
+                capi.check(lib.s2vt_prof_reset(), "prof_reset")
+                capi.check(lib.s2vt_prof_enable(1), "prof_enable")
+                model(dfe, mode="test")
+                torch.cuda.synchronize(dev)
+                capi.check(lib.s2vt_prof_enable(0), "prof_enable")
+                am_ms, am_n = capi.prof_read(4)
+                capi.check(lib.s2vt_prof_reset(), "prof_reset")
+            am_us = am_ms * 1e3 / max(am_n, 1)
+            am_bytes = 4 * V * H + 4 * V + 4 * Bd * H + 8 * Bd         # W_o + b_o + h + packed argmax words
+            decode = {"metric": "greedy-decode captions/sec", "value": round(Bd / ddt, 1), "unit": "captions/s",
+                      "batch": Bd, "ms_per_call": round(ddt * 1e3, 2), "n_gpus": 1, "calls_timed": nd,
+                      "roofline_logits_argmax": {"kernel": "logits_argmax_kernel", "bound": "hbm", "achieved": round(am_bytes / (am_us * 1e-6) / 1e9, 1),
+                                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(am_bytes / (am_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                                 "avg_launch_us": round(am_us, 2), "launches_per_call": am_n,
+                                                 "algorithmic_bytes_per_launch": am_bytes,
+                                                 "gflop_per_launch": round(2.0 * Bd * V * H / 1e9, 2), "traffic": None}}
+            # ---- beam search (BASELINE configs[4]: B=128, beam_size 5, depth 30)
+            with torch.no_grad():
                 model(dfe, mode="beam_search", beam_width=5, max_beam_depth=30)
-            torch.cuda.synchronize(dev)
-            bdt = (time.perf_counter() - t1) / nbm
-        beam = {"metric": "beam-search captions/sec (beam 5, depth 30)", "value": round(Bd / bdt, 1), "unit": "captions/s",
-                "batch": Bd, "ms_per_call": round(bdt * 1e3, 2), "n_gpus": 1, "calls_timed": nbm}
-        model.train()
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                nbm = 3
+                for _ in range(nbm):
+                    model(dfe, mode="beam_search", beam_width=5, max_beam_depth=30)
+                torch.cuda.synchronize(dev)
+                bdt = (time.perf_counter() - t1) / nbm
+            beam = {"metric": "beam-search captions/sec (beam 5, depth 30)", "value": round(Bd / bdt, 1), "unit": "captions/s",
+                    "batch": Bd, "ms_per_call": round(bdt * 1e3, 2), "n_gpus": 1, "calls_timed": nbm}
+            model.train()
 
         # ---- BASELINE configs[2] in the same run (N = 1): B=256, bf16 operands / fp32 accumulate (s2vt_set_gemm_mode(1)),
         # persistent recurrence kernels - the configuration north_star puts its roofline target on
         config3 = None
-        if world == 1 and not bf and B != 256 and not args.no_config3:
+        if world == 1 and not bf and B != 256 and not args.no_config3 and not args.headline_only:
             prev_mode = lib.s2vt_set_gemm_mode(1)
             try:
                 b3 = tuple(t.to(dev) for t in synth.make_batch(256, L, F, V, seed=777))
@@ -459,7 +471,7 @@ def main():
             log("config3: %s" % config3)
         log("decode: %s" % decode)
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.headline_only:
             from oracle import s2vt_oracle as orc
             cores = usable_cores()
             log("cpu_baseline on %d threads" % cores)
@@ -511,9 +523,9 @@ def main():
             "roofline_gemm": roof_gemm,
             "roofline_lstm_step": roof_step,
             "roofline_lstm_step_bwd": roof_bstep,
-            "roofline_isolated": {"gemm": roof_gemm_alone, "lstm_step": roof_step_alone, "lstm_step_bwd": roof_bstep_alone},
+            "roofline_isolated": None if args.headline_only else {"gemm": roof_gemm_alone, "lstm_step": roof_step_alone, "lstm_step_bwd": roof_bstep_alone},
             "kernel_ms_per_step": {k: round(v, 3) for k, v in fam.items()},
-            "kernel_ms_per_step_isolated": {k: round(v, 3) for k, v in fam_alone.items()},
+            "kernel_ms_per_step_isolated": {k: round(v, 3) for k, v in fam_alone.items()} if fam_alone else None,
             "decode": decode,
             "beam": beam,
             "cpu_baseline": cpu,

@@ -2,8 +2,8 @@
 # and config 3 (--batch 256 --gemm-mode 1), then PMC traffic passes (separate FETCH_SIZE / WRITE_SIZE / L2 passes, no other
 # trace domain beside them).  Summaries are copied to profiles/ by hand afterwards.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/prof_r2 &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r2 -o c2 -- python3 bench.py --no-cpu-baseline > gpurun_out/prof_r2/c2_bench_line_under_rocprof.json 2> gpurun_out/prof_r2/c2.err &&
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r2 -o c3 -- python3 bench.py --batch 256 --gemm-mode 1 --no-cpu-baseline --steps 10 > gpurun_out/prof_r2/c3_bench_line_under_rocprof.json 2> gpurun_out/prof_r2/c3.err &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r2 -o c2 -- python3 bench.py --headline-only > gpurun_out/prof_r2/c2_bench_line_under_rocprof.json 2> gpurun_out/prof_r2/c2.err &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r2 -o c3 -- python3 bench.py --batch 256 --gemm-mode 1 --headline-only --steps 10 > gpurun_out/prof_r2/c3_bench_line_under_rocprof.json 2> gpurun_out/prof_r2/c3.err &&
 export S2VT_GEMM_MODE=1 &&
 for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "l2 TCC_HIT_sum TCC_MISS_sum"; do
   set -- $pass; tag=$1; shift
