@@ -72,6 +72,33 @@ def test_split_precision_gemm_blocked_planes(lib, M, N, K):
     assert (out.cpu().double() - (ref + c0.double())).abs().max().item() < tol
 
 
+@pytest.mark.parametrize("M,N,K", [(5, 7, 3), (200, 300, 104), (257, 513, 1000), (640, 256, 2048), (64, 1000, 4100), (1, 1, 1),
+                                   (1000, 1000, 1000), (2048, 1000, 4000), (4000, 1000, 5056), (1203, 4000, 1000)])
+def test_plain_bf16_gemm_rows(lib, M, N, K):
+    """gemm_b1_kernel (config 3: bf16 operand rows, fp32 accumulate) with and without split-K, full and clamped tiles:
+    against fp64 products of the bf16-ROUNDED operands - the only error left is the fp32 accumulation order (<= 2e-5 of
+    the largest output, measured ~1e-6) - with bias, accumulate and split-K scratch; integer operands must come out exact."""
+    from s2vt_video_caption_amd import ops
+    a, b, bias = _r(M, K, seed=11), _r(N, K, seed=12), _r(N, seed=13)
+    ar, br = a.bfloat16().double(), b.bfloat16().double()
+    ref = ar @ br.t()
+    tol = 2e-5 * ref.abs().max().item() + 1e-6
+    pa, pb = ops.split_planes(a.to(DEV), 1), ops.split_planes(b.to(DEV), 1)
+    assert torch.equal(pa[0][:M, :K].cpu().view(torch.bfloat16), a.bfloat16())          # the plane IS the rounded operand
+    got = ops.gemm_planes(pa, pb, M, N, nplanes=1, bias=bias.to(DEV)).cpu()
+    assert (got.double() - (ref + bias.double())).abs().max().item() < tol
+    c0 = _r(M, N, seed=14)
+    out = c0.to(DEV).clone()
+    ws = torch.empty(8 * M * N + 1, device=DEV)
+    ops.gemm_planes(pa, pb, M, N, nplanes=1, out=out, accumulate=True, splitk_ws=ws)
+    assert (out.cpu().double() - (ref + c0.double())).abs().max().item() < tol
+    g = torch.Generator().manual_seed(M + N)
+    ai = torch.randint(-4, 5, (M, K), generator=g).float()
+    bi = torch.randint(-4, 5, (N, K), generator=g).float()
+    goti = ops.gemm_planes(ops.split_planes(ai.to(DEV), 1), ops.split_planes(bi.to(DEV), 1), M, N, nplanes=1, splitk_ws=ws).cpu()
+    assert torch.equal(goti, ai @ bi.t())
+
+
 def test_split_precision_gemm_is_exact_on_integers(lib):
     """Small integers are exact in the hi plane (mid/lo planes zero) and every partial sum is representable: the
     result must be exact - catches any wrong piece / fragment / k mapping of the blocked layout."""
