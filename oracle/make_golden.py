@@ -47,10 +47,10 @@ def _ref_model(S2VT, d, sd):
     return m
 
 
-def _ref_train(S2VT, Crit, d, sd, feats, caps, mask, n_steps):
+def _ref_train(S2VT, Crit, d, sd, feats, caps, mask, n_steps, lr=1e-4):
     m = _ref_model(S2VT, d, sd)
     crit = Crit()
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)            # train.py:89-93
+    opt = torch.optim.Adam(m.parameters(), lr=lr)              # train.py:89-93
     losses, grads, logits0 = [], None, None
     for s in range(n_steps):                                   # train.py:116-127
         opt.zero_grad()
@@ -185,6 +185,25 @@ def gen(name, seed, n_steps, out_scale, do_beam, beam_b=None, beam_width=3, full
     return S2VT, d, sd
 
 
+def gen_long(name="c1long", cfg="c1", seed=31, n_steps=40, lr=1e-3):
+    """A LONG loss trajectory of the reference on one fixed batch (40 Adam steps at a ten times larger learning rate than
+    train.py's, so that the weights really move: the loss falls by an order of magnitude): every later step runs on weights
+    that carry the rounding history of all earlier ones."""
+    S2VT, Crit = _reference()
+    d = synth.CONFIGS[cfg]
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed)
+    feats, caps, mask = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
+    t0 = time.time()
+    losses, _, _, final = _ref_train(S2VT, Crit, d, sd, feats, caps, mask, n_steps, lr=lr)
+    print(f"[{name}] reference train x{n_steps} (lr {lr}): {time.time()-t0:.1f}s first {losses[0]:.4f} last {losses[-1]:.4f}")
+    out = dict(seed=seed, out_scale=1.0, n_steps=n_steps, lr=lr, dims=np.array([d[k] for k in "BLFHEV"], dtype=np.int64),
+               losses=np.array(losses, dtype=np.float64))
+    for k, g in final.items():
+        out["finalnorm/" + k] = np.array(g.double().norm().item())
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[{name}] wrote {os.path.join(GOLD, name + '.npz')}")
+
+
 def gen_beam_only(name, cfg, seed, beam_b, beam_width, out_scale=1.0):
     """BASELINE config 5 dims (H=E=1000, V=12000), a few samples: reference beam-search ids (beam 5, depth 30) and
     greedy ids; the reference needs ~16 s per caption on CPU, so only `beam_b` samples are generated."""
@@ -282,5 +301,9 @@ if __name__ == "__main__":
         gen("c3", seed=5, n_steps=1, out_scale=1.0, do_beam=False, greedy=False)      # with it at bf16 bounds
     if "c4" in which:     # BASELINE configs[3]: the B=128 shard one GPU of the 8-way data-parallel run takes; two fp32 train steps
         gen("c4", seed=7, n_steps=2, out_scale=1.0, do_beam=False, greedy=False)
+    if "c1long" in which:
+        gen_long()
+    if "mid64long" in which:
+        gen_long("mid64long", "mid64", seed=41)
     if "c5beam" in which:
         gen_beam_only("c5beam", "c5", seed=C5_CHOICE[0], beam_b=4, beam_width=5, out_scale=C5_CHOICE[1])

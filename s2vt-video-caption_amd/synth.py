@@ -88,4 +88,6 @@ CONFIGS = {
     "c3": dict(B=256, L=80, F=4096, H=1000, E=1000, V=12000),
     "c4": dict(B=128, L=80, F=4096, H=1000, E=1000, V=12000),
     "c5": dict(B=128, L=80, F=4096, H=1000, E=1000, V=12000),
+    # not a BASELINE config: B = 64 (split-precision / two-stream drivers) at dims small enough for long CPU reference runs
+    "mid64": dict(B=64, L=24, F=512, H=256, E=256, V=1000),
 }
