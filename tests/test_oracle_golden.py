@@ -70,6 +70,18 @@ def test_c1_train_trajectory_matches_reference(golden):
         assert abs(float(final[k].double().norm()) - float(g["finalnorm/" + k])) <= 1e-5 * float(g["finalnorm/" + k]), k
 
 
+def test_long_trajectory_prefix_matches_reference(golden):
+    """The first 8 of the 40 Adam steps of tests/golden/mid64long.npz (B=64, lr 1e-3) with the oracle's explicit cell loops:
+    the oracle follows the reference's trajectory, not only its first step."""
+    g = golden("mid64long")
+    d = synth.CONFIGS["mid64"]
+    seed = int(g["seed"])
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed)
+    feats, caps, mask = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
+    losses, _, _ = orc.train_steps(sd, feats, caps, mask, 8, lr=float(g["lr"]))
+    np.testing.assert_allclose(losses, g["losses"][:8], rtol=0, atol=2e-5)
+
+
 def test_mask_criterion_is_plain_mean_ce_and_nan_on_empty_mask():
     torch.manual_seed(0)
     logits = torch.randn(3, 7, 11)
