@@ -84,9 +84,42 @@ class S2VT(nn.Module):
             return _F.greedy_decode(feats, params, self.sos_ix)
         return None                                        # the reference falls through for unknown modes
 
+    @staticmethod
+    def _get_word2embed_from_glove(glove_path, ix2word):
+        """{word: [floats]} for the vocabulary words found in a GloVe text file (one 'word v1 v2 ...' line per word)."""
+        wanted = set(ix2word.values())
+        table = {}
+        with open(glove_path, encoding='utf-8') as f:
+            for line in f:
+                word, _, rest = line.rstrip('\n').partition(' ')
+                if word in wanted:
+                    table[word] = [float(x) for x in rest.split(' ') if x]
+        return table
+
     def load_glove_weights(self, glove_path, glove_dim, ix2word, word2embed='./data/word2embed.json'):
-        raise NotImplementedError("GloVe initialisation (S2VTModel.py:112-147) is a dead feature of the reference "
-                                  "(train.py:88 is commented out) and outside the hot path")
+        """Initialise the embedding from GloVe vectors (S2VTModel.py:112-147; train.py:88 has the call commented out).
+        `word2embed` None: parse `glove_path` and cache the {word: vector} table as ./data/word2embed.json; otherwise the
+        path of such a cache.  Words without a vector keep a Xavier-normal row; the embedding stays trainable.  Host-side
+        torch glue: the new `nn.Embedding` is an ordinary parameter of the HIP path."""
+        import json
+        import os
+        assert glove_dim == self.dim_embed
+        if word2embed is None:
+            table = self._get_word2embed_from_glove(glove_path, ix2word)
+            os.makedirs('./data', exist_ok=True)
+            with open('./data/word2embed.json', 'w+', encoding='utf-8') as fp:
+                json.dump(table, fp)
+        else:
+            with open(word2embed, encoding='utf-8') as fp:
+                table = json.load(fp)
+        print('get {} word2embed'.format(len(table)))
+        dev = self.embedding.weight.device
+        weights = torch.zeros([self.vocab_size, glove_dim], dtype=torch.float, device=dev)
+        torch.nn.init.xavier_normal_(weights)
+        for ix, word in ix2word.items():
+            if word in table:
+                weights[int(ix)] = torch.tensor(table[word], dtype=torch.float, device=dev)
+        self.embedding = nn.Embedding.from_pretrained(weights, freeze=False)
 
 
 BeamSearchNode = _beam.BeamSearchNode

@@ -193,3 +193,28 @@ def test_dp_reducer_attach_groups_cover_the_flat_buffer():
         assert g.data_ptr() == named[k].grad.data_ptr() and g.shape == named[k].shape
     # the sink lives outside the module: full-module pickles keep the reference's layout
     assert not any("sink" in k for k in m.__dict__)
+
+
+def test_load_glove_weights_fills_known_words_and_keeps_the_embedding_trainable(tmp_path, monkeypatch):
+    """S2VTModel.py:112-147: vocabulary words found in the GloVe file get its vectors, the others a Xavier-normal row; the
+    table is cached as ./data/word2embed.json and can be loaded back from that cache."""
+    import S2VTModel
+    monkeypatch.chdir(tmp_path)
+    ix2word = {"0": "<pad>", "1": "a", "2": "man", "3": "<sos>", "4": "<eos>", "5": "guitar"}
+    with open(tmp_path / "glove.txt", "w", encoding="utf-8") as f:
+        f.write("the 9 9 9 9\n")                       # not in the vocabulary: skipped
+        f.write("man 0.5 -1.25 2 0.125\n")
+        f.write("guitar 1 2 3 4\n")
+    m = S2VTModel.S2VT(vocab_size=6, feat_dim=8, length=4, dim_hid=8, dim_embed=4)
+    m.load_glove_weights(str(tmp_path / "glove.txt"), 4, ix2word, word2embed=None)
+    w = m.embedding.weight
+    assert w.requires_grad and tuple(w.shape) == (6, 4)
+    assert torch.equal(w[2].detach(), torch.tensor([0.5, -1.25, 2.0, 0.125]))
+    assert torch.equal(w[5].detach(), torch.tensor([1.0, 2.0, 3.0, 4.0]))
+    assert float(w[1].detach().abs().sum()) > 0          # no vector for "a": random row, not zeros
+    assert sorted(m.state_dict()) == sorted(S2VTModel.S2VT(6, 8, 4, dim_hid=8, dim_embed=4).state_dict())
+    m2 = S2VTModel.S2VT(vocab_size=6, feat_dim=8, length=4, dim_hid=8, dim_embed=4)
+    m2.load_glove_weights("unused", 4, ix2word, word2embed=str(tmp_path / "data" / "word2embed.json"))
+    assert torch.equal(m2.embedding.weight[5].detach(), w[5].detach())
+    with pytest.raises(AssertionError):
+        m2.load_glove_weights("unused", 3, ix2word)
