@@ -1337,6 +1337,7 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
                 la2.h = w.h2 + (t & 1) * BH; la2.ldh = H;
                 la2.w_out = p->out_w; la2.ldw = H; la2.b_out = p->out_b;
                 la2.packed = w.packed + (int64_t)(t - L) * B;
+                la2.stamps = nullptr;
                 if ((rc = logits_argmax(sx, la2))) return rc;
             }
         }
@@ -1737,6 +1738,10 @@ int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, con
     LogitsArgmaxArgs la;
     la.B = B; la.H = H; la.V = V; la.h = h; la.ldh = H; la.w_out = w_out; la.ldw = H; la.b_out = b_out;
     la.packed = packed;
+    la.stamps = nullptr;
+#ifdef S2VT_EXPERIMENT_STAMPS
+    la.stamps = g_xstamps;
+#endif
     ProfScope ps((hipStream_t)stream, K_ARGMAX, 1);
     return logits_argmax((hipStream_t)stream, la);
 }

@@ -168,6 +168,7 @@ struct LogitsArgmaxArgs {
     const float* w_out; int64_t ldw;         // [V,H]
     const float* b_out;
     unsigned long long* packed;              // [B] zero-initialised; atomicMax of (ordered logit << 32 | ~index)
+    unsigned long long* stamps;              // timing experiments only (experiment.h); null in the product
 };
 int logits_argmax(hipStream_t stream, const LogitsArgmaxArgs& a);
 

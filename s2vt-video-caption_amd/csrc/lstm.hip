@@ -18,6 +18,7 @@
 // (These are the launch-per-timestep kernels: the fp32 training path (two layers on two streams, overlapped with the
 // batched GEMMs), decode and beam search; the persistent kernels of lstm_persist*.hip are the bf16 configuration's.)
 #include "common.h"
+#include "experiment.h"
 #include "kernels.h"
 
 namespace s2vt {
@@ -442,10 +443,10 @@ __device__ __forceinline__ uint32_t ordered_bits(float x) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-template <int MT, int NT, bool VEC>
-__global__ __launch_bounds__(NW_FWD * 64) void logits_argmax_kernel(LogitsArgmaxArgs p) {
+template <int MT, int NT, bool VEC, int NWAVE>
+__global__ __launch_bounds__(NWAVE * 64, 4) void logits_argmax_kernel(LogitsArgmaxArgs p) {
     constexpr int TM = 16 * MT, TN = 16 * NT;
-    constexpr int NWAVE = NW_FWD, NTHR = NWAVE * 64;
+    constexpr int NTHR = NWAVE * 64;
     constexpr int NA = (MT * NT == 1) ? 2 : 1;
     __shared__ __attribute__((aligned(16))) float smem[NWAVE * (TM + TN) * SLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -453,8 +454,23 @@ __global__ __launch_bounds__(NW_FWD * 64) void logits_argmax_kernel(LogitsArgmax
     float* sB = sA + TM * SLD;
     int tx, ty;
     if (!xcd_tile((p.V + TN - 1) / TN, (p.B + TM - 1) / TM, tx, ty)) return;
+    const int xrec = p.stamps ? (int)blockIdx.x : -1;
+    XSTAMP(p.stamps, xrec, 0);
     const int b0 = ty * TM, n0 = tx * TN;
     const int lrow = lane / LPR;
+
+    // epilogue role: 8 threads per batch row, TN/8 columns each; the bias of those columns is requested NOW, ahead of the
+    // contraction (in-kernel stamps: fetched in the epilogue it cost every tile ~1.5 us of exposed latency)
+    constexpr int CPT = TN / 8;
+    static_assert(TM * 8 == 256 && TM * 8 <= NTHR, "one pass over the tile");
+    const int bl = (tid >> 3) % TM, sub = tid & 7;
+    const bool active = tid < TM * 8;
+    float bv[CPT];
+#pragma unroll
+    for (int j = 0; j < CPT; ++j) {
+        const int n = n0 + sub * CPT + j;
+        bv[j] = *((active && p.b_out && n < p.V) ? p.b_out + n : g_zero4);
+    }
 
     f32x4 acc[MT][NT][NA];
 #pragma unroll
@@ -478,23 +494,22 @@ __global__ __launch_bounds__(NW_FWD * 64) void logits_argmax_kernel(LogitsArgmax
         }
         wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.h, p.w_out, arow, brow, p.H, sA, sB, wave, lane);
     }
+    XSTAMP(p.stamps, xrec, 1);
     __syncthreads();
+    XSTAMP(p.stamps, xrec, 2);
     float* red = smem;
     write_partials<MT, NT, NA>(acc, red, wave, lane);
     __syncthreads();
+    XSTAMP(p.stamps, xrec, 3);
 
     // 8 threads per batch row, TN/8 columns each; first-max (lowest index) wins ties.
-    constexpr int CPT = TN / 8;
-    static_assert(TM * 8 == 256, "one pass over the tile");
-    const int bl = (tid >> 3) % TM, sub = tid & 7;
     const int b = b0 + bl;
-    const bool active = tid < TM * 8;
     unsigned long long best = 0ull;
 #pragma unroll
     for (int j = 0; j < CPT; ++j) {
         const int nl = sub * CPT + j, n = n0 + nl;
         if (active && b < p.B && n < p.V) {
-            const float v = read_sum<MT, NT, NWAVE>(red, bl, nl) + (p.b_out ? p.b_out[n] : 0.f);
+            const float v = read_sum<MT, NT, NWAVE>(red, bl, nl) + bv[j];
             const unsigned long long key =
                 ((unsigned long long)ordered_bits(v) << 32) | (unsigned long long)(0xFFFFFFFFu - (uint32_t)n);
             best = key > best ? key : best;
@@ -506,14 +521,18 @@ __global__ __launch_bounds__(NW_FWD * 64) void logits_argmax_kernel(LogitsArgmax
         best = o > best ? o : best;
     }
     if (active && sub == 0 && b < p.B && best) atomicMax(&p.packed[b], best);
+    XSTAMP(p.stamps, xrec, 4);
 }
 
 int logits_argmax(hipStream_t stream, const LogitsArgmaxArgs& a) {
     S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.V > 0 && a.h && a.w_out && a.packed, "logits_argmax: bad arguments");
     const bool vec = vec_ok(a.h, a.ldh) && vec_ok(a.w_out, a.ldw) && a.H % 4 == 0;
     dim3 grid(xcd_grid(cdiv(a.V, 32), cdiv(a.B, 32)));
-    if (vec) hipLaunchKernelGGL((logits_argmax_kernel<2, 2, true>), grid, dim3(NW_FWD * 64), 0, stream, a);
-    else hipLaunchKernelGGL((logits_argmax_kernel<2, 2, false>), grid, dim3(NW_FWD * 64), 0, stream, a);
+    // 4 waves per tile (K split four ways, 36.9 KB LDS, four workgroups per CU): with eight (two workgroups per CU) every
+    // workgroup of a CU sat in its reduction / argmax phase at about the same time and the CU's ingest idled meanwhile
+    // (in-kernel stamps of all 1500 workgroups, tools/bench_argmax_stamps.py; 2 % on a greedy decode)
+    if (vec) hipLaunchKernelGGL((logits_argmax_kernel<2, 2, true, 4>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((logits_argmax_kernel<2, 2, false, 4>), grid, dim3(256), 0, stream, a);
     S2VT_LAUNCH_CHECK("logits_argmax_kernel");
     return 0;
 }
