@@ -29,6 +29,8 @@ def parse(argv=None):
     ap.add_argument("--dim-embed", type=int, default=512)
     ap.add_argument("--feat-dim", type=int, default=4096)
     ap.add_argument("--feat-dropout", type=float, default=0.0)
+    ap.add_argument("--out-dropout", type=float, default=0.0)
+    ap.add_argument("--rnn-dropout", type=float, default=0.0, help="accepted as upstream; no effect with one LSTM layer")
     ap.add_argument("--batch-size", type=int, default=16, help="per process")
     ap.add_argument("--workers", type=int, default=0,
                     help="DataLoader worker processes (0 = the reference's behaviour: items are loaded by the feed thread; "
@@ -69,6 +71,9 @@ def run(opt):
         np.random.seed(opt.seed + rank)
     start_time = time.strftime('%y_%m_%d_%H_%M_%S-', time.localtime())
     os.makedirs(opt.save_path, exist_ok=True)
+    if rank == 0:                                           # the run's configuration beside its checkpoints (save_opt, train.py:51-53)
+        with open(os.path.join(opt.save_path, start_time + 'opt.txt'), 'w+', encoding='utf-8') as f:
+            f.write(str(vars(opt)))
     trainset = dataloader.VideoDataset(opt.caption_file, opt.feats_path, max_len=opt.train_length)
     validset = dataloader.VideoDataset(opt.caption_file, opt.feats_path, max_len=opt.train_length, mode='valid')
     shuffle = not opt.no_shuffle
@@ -84,7 +89,8 @@ def run(opt):
 
     torch.manual_seed(0)        # identical replicas
     model = S2VT(len(word2ix), opt.feat_dim, length=opt.train_length, dim_hid=opt.dim_hidden, dim_embed=opt.dim_embed,
-                 feat_dropout=opt.feat_dropout, sos_ix=word2ix['<sos>'], eos_ix=word2ix['<eos>'])
+                 feat_dropout=opt.feat_dropout, rnn_dropout=opt.rnn_dropout, out_dropout=opt.out_dropout,
+                 sos_ix=word2ix['<sos>'], eos_ix=word2ix['<eos>'])
     if opt.init_state:
         model.load_state_dict(torch.load(opt.init_state))
     model.to(dev)
