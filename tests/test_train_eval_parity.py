@@ -100,7 +100,7 @@ def test_train_harness_and_generate_match_oracle(tmp_path):
     assert np.abs(np.array(got["valid_loss"]) - np.array(ref["valid_loss"])).max() < 1e-4, (got["valid_loss"], ref["valid_loss"])
     files = sorted(os.listdir(ck))
     st = got["start_time"]
-    assert sorted(st + n for n in set(got["checkpoints"])) == files
+    assert sorted([st + n for n in set(got["checkpoints"])] + [st + "opt.txt"]) == files      # + the run's configuration (save_opt)
     final = torch.load(ck / (st + "final.pth"), weights_only=False)
     for k, v in final.state_dict().items():
         assert (v.cpu() - ref["final_state"][k]).abs().max().item() < 2e-4, k
