@@ -185,7 +185,7 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     w.h2 = c.take<float>(T * B * H);
     w.c2 = c.take<float>(T * B * H);
     w.tok = c.take<int32_t>((L - 1) * B);
-    w.embws = c.take<int>(embedding_grad_ws_ints((int64_t)(L - 1) * B));
+    w.embws = c.take<int>(embedding_grad_ws_ints((int64_t)(L - 1) * B, (int)d.V));
     w.err = c.take<int>(4);
     w.psync_a = c.take<unsigned int>(lstm_persist_sync_bytes() / sizeof(unsigned int));
     w.psync_b = c.take<unsigned int>(lstm_persist_sync_bytes() / sizeof(unsigned int));

@@ -184,7 +184,7 @@ int targets_to_time_major(hipStream_t s, const int64_t* targets, int B, int Lm1,
 // beam-search fan-out (ce.hip): log_softmax + the 20 most probable tokens per row in ascending token order
 int top20_logprob(hipStream_t s, const float* logits, int64_t ld, int64_t rows, int V, int32_t* top_ix, float* top_lp);
 int gather_rows_f32(hipStream_t s, const float* src, int64_t ld, const int32_t* idx, int64_t rows, int cols, float* out);
-size_t embedding_grad_ws_ints(int64_t rows);
+size_t embedding_grad_ws_ints(int64_t rows, int V);
 int embedding_grad(hipStream_t s, const float* d_rows, int64_t rows, int E, const int32_t* tok, int V, float* d_emb, int* ws);
 int unpack_tokens(hipStream_t s, const unsigned long long* packed, int steps, int B, int64_t* out_ids);
 int fill_zero(hipStream_t s, void* p, size_t bytes);

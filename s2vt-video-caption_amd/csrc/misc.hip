@@ -140,91 +140,144 @@ int targets_to_time_major(hipStream_t s, const int64_t* targets, int B, int Lm1,
 
 // Embedding gradient (autograd of S2VTModel.py:71): d_emb[v, :] = sum over the rows r with tok[r] == v of d_rows[r, :],
 // in a FIXED order - no atomics, so the whole training step is bitwise reproducible.
-//   emb_grad_kernel: one workgroup per vocabulary row v.  It scans the token list (order-preserving compaction by wave
-//     ballots); a row with <= EG_CAP matches is summed in ascending r (unused tokens are written as zeros: no separate
+//   emb_count_kernel: how often every token occurs (integer atomics: the counts do not depend on the order).
+//   emb_grad_kernel: one workgroup per vocabulary row v.  A token that does not occur (most of a 12000-word vocabulary in
+//     any one batch) gets its zeros at once; otherwise the workgroup scans the token list until it has found all count[v]
+//     matches (order-preserving compaction by wave ballots); a row with <= EG_CAP matches is summed in ascending r (unused tokens are written as zeros: no separate
 //     fill); a row with more (<pad>, <eos>, frequent words: thousands of matches) is only put on the `heavy` list.
-//   emb_grad_heavy_kernel: one workgroup per (heavy token, 16 columns): 16 row-lanes sum contiguous slices of the
-//     ordered match list, the 16 partials are added in lane order.
+//   emb_grad_heavy_kernel: one workgroup per (heavy token, 16 columns): 64 row-lanes sum contiguous slices of the
+//     ordered match list, the 64 partials are added in lane order.
 constexpr int EG_CAP = 64;
+template <int NW>
 __device__ __forceinline__ int eg_compact(bool hit, int r, int* list, int n_list, int* wave_cnt, int tid) {
     const int lane = tid & 63, wave = tid >> 6;
     const unsigned long long m = __ballot(hit);
     if (lane == 0) wave_cnt[wave] = __popcll(m);
     __syncthreads();
-    int off = n_list;
-    for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+    int off = n_list, total = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        if (w < wave) off += wave_cnt[w];
+        total += wave_cnt[w];
+    }
     if (hit && list) list[off + __popcll(m & ((1ull << lane) - 1ull))] = r;
-    const int total = wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
     __syncthreads();
     return n_list + total;
 }
+// (<pad> / <eos> fill most caption rows: counted straight into global memory their thousands of same-address atomics
+// serialise - 0.2 ms at B = 256 - so every workgroup first counts its slice of the rows in an LDS histogram and adds each
+// bin it touched once)
+constexpr int EC_LDS_BINS = 16000;          // 62.5 KB of dynamic LDS: vocabularies up to this size take the histogram path
+__global__ __launch_bounds__(256) void emb_count_kernel(const int32_t* tok, int rows, int V, int per_wg, int* count) {
+    extern __shared__ int hist[];
+    const int r0 = blockIdx.x * per_wg, r1 = (r0 + per_wg < rows) ? r0 + per_wg : rows;
+    if (V > EC_LDS_BINS) {
+        for (int r = r0 + threadIdx.x; r < r1; r += 256) atomicAdd(&count[tok[r]], 1);
+        return;
+    }
+    for (int v = threadIdx.x; v < V; v += 256) hist[v] = 0;
+    __syncthreads();
+    for (int r = r0 + threadIdx.x; r < r1; r += 256) atomicAdd(&hist[tok[r]], 1);
+    __syncthreads();
+    for (int v = threadIdx.x; v < V; v += 256) {
+        const int c = hist[v];
+        if (c) atomicAdd(&count[v], c);
+    }
+}
 __global__ __launch_bounds__(256) void emb_grad_kernel(const float* d_rows, int rows, int E, const int32_t* tok, float* d_emb,
-                                                       int* heavy, int* n_heavy) {
+                                                       int* heavy, int* n_heavy, const int* count) {
     __shared__ int list[EG_CAP + 256];
     __shared__ int wave_cnt[4];
     const int v = blockIdx.x, tid = threadIdx.x;
-    int n = 0;                                                // uniform: matches found so far
-    for (int base = 0; base < rows && n <= EG_CAP; base += 256) {
-        const int r = base + tid;
-        n = eg_compact((r < rows) && (tok[r] == v), r, list, n, wave_cnt, tid);
-    }
-    if (n > EG_CAP) {
+    const int want = count[v];                                // uniform
+    if (want > EG_CAP) {
         if (tid == 0) heavy[atomicAdd(n_heavy, 1)] = v;       // list order does not matter
         return;
+    }
+    int n = 0;                                                // uniform: matches found so far
+    for (int base = 0; base < rows && n < want; base += 256) {
+        const int r = base + tid;
+        n = eg_compact<4>((r < rows) && (tok[r] == v), r, list, n, wave_cnt, tid);
     }
     float* out = d_emb + (int64_t)v * E;
     for (int c = tid; c < E; c += 256) {
         float sum = 0.f;
-        for (int i = 0; i < n; ++i) sum += d_rows[(int64_t)list[i] * E + c];
+        for (int i = 0; i < n; i += 8) {                      // eight loads in flight, added in list order (see the heavy kernel)
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = d_rows[(int64_t)list[(i + j < n) ? i + j : n - 1] * E + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += (i + j < n) ? v[j] : 0.f;
+        }
         out[c] = sum;
     }
 }
 constexpr int EG_HLIST = 8192;      // matches of a heavy token handled per pass
-__global__ __launch_bounds__(256) void emb_grad_heavy_kernel(const float* d_rows, int rows, int E, const int32_t* tok,
-                                                             float* d_emb, const int* heavy, const int* n_heavy) {
-    __shared__ int list[EG_HLIST + 256];
-    __shared__ int wave_cnt[4];
-    __shared__ float part[16][17];
+constexpr int EG_HT = 1024;         // threads: 64 row-lanes x 16 columns (<pad> has ~15000 matches at B = 256: 16 row-lanes
+                                    // summed ~940 rows each, one load latency after the other; 64 lanes cut that four-fold)
+__global__ __launch_bounds__(EG_HT) void emb_grad_heavy_kernel(const float* d_rows, int rows, int E, const int32_t* tok,
+                                                               float* d_emb, const int* heavy, const int* n_heavy) {
+    __shared__ int list[EG_HLIST + EG_HT];
+    __shared__ int wave_cnt[EG_HT / 64];
+    __shared__ float part[EG_HT / 16][17];
     if ((int)blockIdx.y >= *n_heavy) return;
     const int v = heavy[blockIdx.y], tid = threadIdx.x;
     const int rl = tid >> 4, c = blockIdx.x * 16 + (tid & 15);
+    constexpr int NRL = EG_HT / 16;
     float total = 0.f;
     int base = 0;
     while (base < rows) {
         int n = 0;
-        for (; base < rows && n <= EG_HLIST; base += 256) {       // list holds EG_HLIST + 256
+        for (; base < rows && n <= EG_HLIST; base += EG_HT) {     // list holds EG_HLIST + EG_HT
             const int r = base + tid;
-            n = eg_compact((r < rows) && (tok[r] == v), r, list, n, wave_cnt, tid);
+            n = eg_compact<EG_HT / 64>((r < rows) && (tok[r] == v), r, list, n, wave_cnt, tid);
         }
         // row-lane rl sums the slice [rl*per, (rl+1)*per) of this pass's ordered matches
-        const int per = (n + 15) / 16, i0 = rl * per, i1 = (i0 + per < n) ? i0 + per : n;
+        const int per = (n + NRL - 1) / NRL, i0 = rl * per, i1 = (i0 + per < n) ? i0 + per : n;
         float sum = 0.f;
         if (c < E) {
-#pragma unroll 8
-            for (int i = i0; i < i1; ++i) sum += d_rows[(int64_t)list[i] * E + c];
+            // eight loads in flight (unconditional: an index past the slice re-reads its last row and is not added), added in
+            // list order; a loop with the bound test in front of every load issues them one latency after the other
+            for (int i = i0; i < i1; i += 8) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ii = (i + j < i1) ? i + j : i1 - 1;
+                    v[j] = d_rows[(int64_t)list[ii] * E + c];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += (i + j < i1) ? v[j] : 0.f;
+            }
         }
         part[rl][tid & 15] = sum;
         __syncthreads();
         if (rl == 0) {
             float s = part[0][tid & 15];
 #pragma unroll
-            for (int k = 1; k < 16; ++k) s += part[k][tid & 15];
+            for (int k = 1; k < NRL; ++k) s += part[k][tid & 15];
             total += s;
         }
         __syncthreads();
     }
     if (rl == 0 && c < E) d_emb[(int64_t)v * E + c] = total;
 }
-size_t embedding_grad_ws_ints(int64_t rows) { return (size_t)(rows / EG_CAP + 2) + 1; }
-// ws: embedding_grad_ws_ints(rows) ints of scratch (heavy-token list + its counter)
+size_t embedding_grad_ws_ints(int64_t rows, int V) { return (size_t)(rows / EG_CAP + 2) + 1 + (size_t)V; }
+// ws: embedding_grad_ws_ints(rows, V) ints of scratch (heavy-token list, its counter, per-token counts)
 int embedding_grad(hipStream_t s, const float* d_rows, int64_t rows, int E, const int32_t* tok, int V, float* d_emb, int* ws) {
     if (V <= 0 || E <= 0) return 0;
     const int max_heavy = (int)(rows / EG_CAP + 2);           // each heavy token owns > EG_CAP of the `rows` rows
     int* n_heavy = ws + max_heavy;
-    S2VT_HIP(hipMemsetAsync(n_heavy, 0, sizeof(int), s));
-    hipLaunchKernelGGL(emb_grad_kernel, dim3((unsigned)V), dim3(256), 0, s, d_rows, (int)rows, E, tok, d_emb, ws, n_heavy);
+    int* count = n_heavy + 1;
+    S2VT_HIP(hipMemsetAsync(n_heavy, 0, sizeof(int) * (size_t)(1 + V), s));
+    if (rows > 0) {
+        const int per_wg = 2048;
+        const size_t lds = (V <= EC_LDS_BINS) ? sizeof(int) * (size_t)V : 0;
+        hipLaunchKernelGGL(emb_count_kernel, dim3(cdiv((int)rows, per_wg)), dim3(256), lds, s, tok, (int)rows, V, per_wg, count);
+    }
+    S2VT_LAUNCH_CHECK("emb_count_kernel");
+    hipLaunchKernelGGL(emb_grad_kernel, dim3((unsigned)V), dim3(256), 0, s, d_rows, (int)rows, E, tok, d_emb, ws, n_heavy, count);
     S2VT_LAUNCH_CHECK("emb_grad_kernel");
-    hipLaunchKernelGGL(emb_grad_heavy_kernel, dim3(cdiv(E, 16), max_heavy), dim3(256), 0, s, d_rows, (int)rows, E, tok, d_emb,
+    hipLaunchKernelGGL(emb_grad_heavy_kernel, dim3(cdiv(E, 16), max_heavy), dim3(EG_HT), 0, s, d_rows, (int)rows, E, tok, d_emb,
                        ws, n_heavy);
     S2VT_LAUNCH_CHECK("emb_grad_heavy_kernel");
     return 0;
