@@ -165,7 +165,7 @@ __device__ __forceinline__ void seq_fwd_body(const SeqFwdBf16Args& p, const int 
 
             if (t > p.t0) {          // h_{t-1} of this chain published by every column slice of the row group?
                 if (tid == 0) {
-                    const bool ok = spin_until(cnt, (unsigned int)(nC * (t - p.t0)));
+                    const bool ok = spin_until(cnt, (unsigned int)(nC * t));     // every workgroup of the chain has finished steps 0..t-1
                     s_flag = ok ? 1 : 0;
                     if (!ok) atomicExch(p.err, 1);
                 }
@@ -410,9 +410,10 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
             const int rbase = row0 + s * P_SR;
             unsigned int* cnt = p.sync + (rg * P_MAXNS + s) * 32;
             const int done = p.t1 - 1 - t;             // steps of this launch already finished by every workgroup?
+            const int done_all = p.T - 1 - t;          // ... and of the whole sequence: the counters run on from launch to launch
             if (done > 0) {
                 if (tid == 0) {
-                    const bool ok = spin_until(cnt, (unsigned int)(nC * done));
+                    const bool ok = spin_until(cnt, (unsigned int)(nC * done_all));
                     s_flag = ok ? 1 : 0;
                     if (!ok) atomicExch(p.err, 1);
                 }
@@ -572,8 +573,10 @@ int lstm_seq_bwd_bf16_persist2(hipStream_t stream, SeqBwdBf16Args a, const SeqBw
     }
     const int na = (a.B / a.RB) * cdiv(a.H, P_UN), nb = b ? (bb.B / bb.RB) * cdiv(bb.H, P_UN) : 0;
     S2VT_REQUIRE(na + nb <= P_MAX_WG, "lstm_seq_bwd_bf16_persist: %d workgroups would not be co-resident", na + nb);
-    S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
-    if (b) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
+    // the hand-off counters count finished timesteps of the whole sequence: zeroed with its first block only (a memset
+    // is a 5-us kernel of its own on this stream: 28 of them per train step when every launch zeroed its counters)
+    if (a.t1 == a.T) S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
+    if (b && bb.t1 == bb.T) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
     hipLaunchKernelGGL(lstm_seq_bwd_bf16_persist_kernel, dim3(na + nb), dim3(P_NT), 0, stream, a, bb, na);
     S2VT_LAUNCH_CHECK("lstm_seq_bwd_bf16_persist_kernel");
     return 0;
@@ -614,8 +617,9 @@ int lstm_seq_fwd_bf16_persist2(hipStream_t stream, SeqFwdBf16Args a, const SeqFw
     }
     const int na = (a.B / a.RB) * cdiv(a.H, P_UN), nb = b ? (bb.B / bb.RB) * cdiv(bb.H, P_UN) : 0;
     S2VT_REQUIRE(na + nb <= P_MAX_WG, "lstm_seq_fwd_bf16_persist: %d workgroups would not be co-resident", na + nb);
-    S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
-    if (b) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
+    // (counters: see the BPTT launcher) zeroed with the sequence's first block
+    if (a.t0 == 0) S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
+    if (b && bb.t0 == 0) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
     if (a.Kp == 64 * P_KCH)
         hipLaunchKernelGGL((lstm_seq_fwd_bf16_persist_kernel<true>), dim3(na + nb), dim3(P_NT), 0, stream, a, bb, na);
     else

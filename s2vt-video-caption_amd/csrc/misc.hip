@@ -270,7 +270,7 @@ int embedding_grad(hipStream_t s, const float* d_rows, int64_t rows, int E, cons
     int* count = n_heavy + 1;
     S2VT_HIP(hipMemsetAsync(n_heavy, 0, sizeof(int) * (size_t)(1 + V), s));
     if (rows > 0) {
-        const int per_wg = 2048;
+        const int per_wg = 512;             // 40 workgroups at B = 256: zeroing and flushing the V bins is the fixed cost of each
         const size_t lds = (V <= EC_LDS_BINS) ? sizeof(int) * (size_t)V : 0;
         hipLaunchKernelGGL(emb_count_kernel, dim3(cdiv((int)rows, per_wg)), dim3(256), lds, s, tok, (int)rows, V, per_wg, count);
     }
