@@ -218,11 +218,14 @@ def test_long_loss_trajectory_against_reference(lib, golden, name, cfg, gemm_mod
 def test_against_oracle_on_fresh_seeds(lib):
     """Ragged / edge shapes the fixtures do not cover: B=1, B not a multiple of the tile, H not a multiple of
     8 or 4-aligned E, V not 4-aligned; the B=64 / B=128 cases take the split-precision, two-lane drivers (blocked plane
-    layout with partial 64-row blocks, k padding, clamped 256x256 tiles)."""
-    for (B, L, Fd, H, E, V, seed) in [(1, 4, 20, 12, 8, 23, 1), (19, 6, 33, 36, 20, 57, 2), (33, 3, 64, 40, 44, 30, 3),
-                                      (64, 5, 70, 44, 28, 61, 4), (128, 4, 36, 100, 52, 333, 5)]:
+    layout with partial 64-row blocks, k padding, clamped 256x256 tiles).  The last case has a 12-word vocabulary under
+    2816 caption rows: every token is "heavy" for the embedding gradient (more than 64 rows each: ten tokens go through the
+    heavy-token kernel, where the BASELINE batches have two or three)."""
+    for (B, L, Fd, H, E, V, seed, words) in [(1, 4, 20, 12, 8, 23, 1, (1, 2)), (19, 6, 33, 36, 20, 57, 2, (1, 2)),
+                                             (33, 3, 64, 40, 44, 30, 3, (1, 2)), (64, 5, 70, 44, 28, 61, 4, (1, 2)),
+                                             (128, 4, 36, 100, 52, 333, 5, (1, 2)), (256, 12, 24, 16, 8, 12, 6, (5, 9))]:
         sd = synth.make_state_dict(V, Fd, H, E, seed=seed)
-        feats, caps, mask = synth.make_batch(B, L, Fd, V, seed=seed, min_words=1, max_words=2)
+        feats, caps, mask = synth.make_batch(B, L, Fd, V, seed=seed, min_words=words[0], max_words=words[1])
         import S2VTModel, utils
         m = S2VTModel.S2VT(V, Fd, L, dim_hid=H, dim_embed=E)
         m.load_state_dict(sd)
