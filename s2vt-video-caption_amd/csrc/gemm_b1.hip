@@ -5,8 +5,10 @@
 // 256x256 tile, k chunk 64 per stage: the stage image is [512 rows][128 B], filled by global_load_lds_dwordx4 with
 // one wave-instruction per 8 rows (8 lanes x 16 B = one full 128-B line per row).  An LDS-DMA writes lane-linear, so the
 // XOR swizzle that keeps the fragment reads conflict-free is applied to the per-lane SOURCE address instead: position p
-// of row r holds the row's 16-B piece p ^ (r & 7); a reader wanting piece q of row r reads position q ^ (r & 7)
-// (32 consecutive rows x one piece index then cover all 16-B columns of the bank rows evenly).
+// of row r holds the row's 16-B piece p ^ ((r >> 1) & 7); a reader wanting piece q of row r reads position
+// q ^ ((r >> 1) & 7): the 16 rows of a ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) then take the 16 different
+// (row parity, (r >> 1) & 7) slots of the 256-B bank row.  (The first version XORed with r & 7: rows 12 and 20 of a group
+// met on one slot - PMC showed half of the kernel's LDS cycles as bank conflicts.)
 // Two stages (128 KB LDS, one workgroup per CU), one barrier per stage: after the barrier that opens stage s every wave
 // is done with stage s-1, whose slot takes the requests of stage s+1 while stage s is multiplied.  8 waves as 2x4,
 // wave tile 128x64: per k16 block 6 ds_read_b128 feed 8 v_mfma_f32_32x32x16_bf16; reads are inline asm with
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
     const int nk = (kend - kbeg) >> 6;                 // k64 stages
 
     // loader role: waves 0-3 fill the A image (64 rows each), waves 4-7 the B image; request j of a wave covers rows
-    // 8j..8j+7 of its 64: lane -> (row lane/8, position lane%8) <- piece (lane%8) ^ (lane/8); rows past the operand's
+    // 8j..8j+7 of its 64: lane -> (row lane/8, position lane%8) <- piece (lane%8) ^ ((row >> 1) & 7); rows past the operand's
     // end are clamped onto its last row (their outputs are never stored)
     const unsigned char* src[8];
     {
@@ -71,11 +73,12 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
         const int nrows = isA ? p.M : p.N, r0 = (isA ? m0 : n0) + (wave & 3) * 64 + (lane >> 3);
         const unsigned short* base = isA ? p.A : p.B;
         const int64_t ld = isA ? p.lda : p.ldb;
-        const int piece = (lane & 7) ^ (lane >> 3);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             int r = r0 + 8 * j;
             r = r < nrows ? r : nrows - 1;
+            // tile row 8j + lane/8 of this wave's 64: (row >> 1) & 7 = (4j + lane/16) & 7
+            const int piece = (lane & 7) ^ ((4 * j + (lane >> 4)) & 7);
             src[j] = reinterpret_cast<const unsigned char*>(base + (int64_t)r * ld + kbeg) + piece * 16;
         }
     }
@@ -89,9 +92,9 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    // fragment addresses: row r = tile row of lane (r & 7 == li & 7), k16 block c, half lh -> piece 2c+lh at position
-    // (2c+lh) ^ (li&7) = (2c) ^ y with y = lh ^ (li&7)
-    const int y = lh ^ (li & 7);
+    // fragment addresses: row r = tile row of lane ((r >> 1) & 7 == (li >> 1) & 7), k16 block c, half lh -> piece 2c+lh at
+    // position (2c+lh) ^ s = (2c) ^ y with s = (li >> 1) & 7, y = lh ^ s
+    const int y = lh ^ ((li >> 1) & 7);
     unsigned fa[4], fb[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
