@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "experiment.h"
 #include "kernels.h"
 
 namespace s2vt {
@@ -37,6 +38,7 @@ struct GemmB1Args {
     int accumulate;
     int ksplit;
     float* slabs;
+    unsigned long long* stamps; int stamp_block;    // timing experiments only
 };
 
 __device__ __forceinline__ void glds16b(const void* g, void* l) {
@@ -114,11 +116,17 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
 #define B1_FENCE __builtin_amdgcn_sched_barrier(0);
 
     // MORE: stage s+1 exists and is requested during stage s
+    const int xon = (p.stamps && (int)blockIdx.x == p.stamp_block && blockIdx.y == 0) ? 1 : 0;
     auto stage = [&](int s, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value;
+        const int xrec = xon ? s : -1;
+        XSTAMP(p.stamps, xrec, 0);
         // this wave's requests of stage s are the only ones outstanding; after the barrier all pieces of stage s are in
         // and every wave has finished reading stage s-1 (its slot takes stage s+1)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        XSTAMP(p.stamps, xrec, 1);
+        asm volatile("s_barrier" ::: "memory");
+        XSTAMP(p.stamps, xrec, 2);
         const unsigned so = (unsigned)((s & 1) * B_STAGE);
         unsigned char* l2 = ldst + ((s + 1) & 1) * B_STAGE;
         const int64_t g2 = (int64_t)(s + 1) * 128;
@@ -126,12 +134,16 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
         bf16x8 ax[4], bx[2], ay[4], by[2];
         B1_FENCE
         B1_READ(ax, bx, 0, so) B1_READ(ay, by, 1, so)
-        B1_WAIT(6, ax, bx) B1_PROD(ax, bx) B1_REQ(0) B1_REQ(1) B1_FENCE
+        B1_WAIT(6, ax, bx) XSTAMP(p.stamps, xrec, 3); B1_PROD(ax, bx) B1_REQ(0) B1_REQ(1) B1_FENCE
+        XSTAMP(p.stamps, xrec, 4);
         B1_READ(ax, bx, 2, so)
         B1_WAIT(6, ay, by) B1_PROD(ay, by) B1_REQ(2) B1_REQ(3) B1_FENCE
+        XSTAMP(p.stamps, xrec, 5);
         B1_READ(ay, by, 3, so)
         B1_WAIT(6, ax, bx) B1_PROD(ax, bx) B1_REQ(4) B1_REQ(5) B1_FENCE
+        XSTAMP(p.stamps, xrec, 6);
         B1_WAIT(0, ay, by) B1_PROD(ay, by) B1_REQ(6) B1_REQ(7) B1_FENCE
+        XSTAMP(p.stamps, xrec, 7);
 #undef B1_REQ
     };
     {
@@ -179,6 +191,11 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
 int splitk_reduce(hipStream_t stream, const float* slabs, int nsplit, int M, int N, float* C, int64_t ldc, RowMap cmap,
                   const float* bias, bool accumulate);
 
+#ifdef S2VT_EXPERIMENT_STAMPS
+static unsigned long long* g_b1_stamps = nullptr;
+static int g_b1_block = 0;
+extern "C" int s2vt_experiment_set_b1_stamps(unsigned long long* buf, int block) { g_b1_stamps = buf; g_b1_block = block; return 0; }
+#endif
 int gemm_b1(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
             int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
             size_t splitk_ws_floats) {
@@ -191,6 +208,10 @@ int gemm_b1(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
     p.A = A; p.lda = lda;
     p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.cmap = cmap; p.bias = bias; p.accumulate = accumulate ? 1 : 0;
+    p.stamps = nullptr; p.stamp_block = -1;
+#ifdef S2VT_EXPERIMENT_STAMPS
+    p.stamps = g_b1_stamps; p.stamp_block = g_b1_block;
+#endif
     const int tiles = cdiv(M, BT) * cdiv(N, BT);
     // split K by the same kind of time model as gemm_x3 (one sixth of its MFMA work per k unit)
     int nsplit = 1;
