@@ -49,7 +49,8 @@ constexpr int P_UN = 16;                          // hidden units per workgroup 
 constexpr int P_NT = 256;                         // 4 waves
 constexpr int P_KCH = 16;                         // k chunks of 64 (Kp <= 1024)
 constexpr int P_SLAB = P_KCH * P_SR * 128;        // h_{t-1} image: 64 KB
-constexpr int P_RLD = 68;                         // row stride of the partial-sum image (floats)
+constexpr int P_RLD = 72;                         // row stride of the partial-sum image (floats): 8 mod 64, so the epilogue's
+                                                  // f32x2 reads (4 rows x {0-7, 32-39} per half-wave) and the partial writes are conflict-free
 constexpr int P_HSM = P_SLAB;                     // bf16 h_t tile [32][16]
 constexpr int P_MAXNS = 4;
 constexpr int P_CST = P_HSM + P_SR * P_UN * 2;    // fp32 c_t of the workgroup's cells, per chain [32][16]
