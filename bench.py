@@ -226,14 +226,32 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     frames_per_s = world * B * L * args.steps / dt
+    capi.check_async_error()      # a device-side error inside the timed steps (bad token, timed-out hand-off) voids the number
     final_loss = float(loss)
-    # host-side enqueue cost of one step (no sync inside): must stay well below ms_per_step or the run is launch-bound
-    torch.cuda.synchronize(dev)
-    th = time.perf_counter()
-    for _ in range(3):
-        one_step()
-    host_ms = (time.perf_counter() - th) / 3 * 1e3
-    torch.cuda.synchronize(dev)
+    # Host-side cost of ENQUEUING one step: the phases of a step timed separately with the queues drained before each (a
+    # free-running host is throttled by queue back-pressure, which is GPU time, not host cost: round 2 reported that
+    # figure, 8.3 ms, as if it were enqueue cost).  Must stay well below ms_per_step or the run is launch-bound.
+    def host_cost(nrep=3):
+        acc = {"zero_grad": 0.0, "forward": 0.0, "criterion": 0.0, "backward": 0.0, "allreduce+adam": 0.0}
+
+        def ph(name, fn):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            r = fn()
+            acc[name] += time.perf_counter() - t0
+            return r
+        for _ in range(nrep):
+            ph("zero_grad", lambda: reducer.zero_grad() if reducer is not None else opt.zero_grad())
+            model.train()
+            probs = ph("forward", lambda: model(feats, targets=caps[:, :-1], mode="train"))
+            ls = ph("criterion", lambda: crit(probs, caps, mask))
+            ph("backward", lambda: ls.backward())
+            ph("allreduce+adam", lambda: (reducer.all_reduce() if reducer is not None else None, opt.step()))
+        torch.cuda.synchronize(dev)
+        return {k: round(v / nrep * 1e3, 3) for k, v in acc.items()}
+    host_phases = host_cost()
+    host_ms = sum(host_phases.values())
+    capi.check_async_error()
     log("timed region: %.3f ms/step, %.0f frames/s" % (ms_per_step, frames_per_s))
 
     # ---- BASELINE configs[3] shard: B=128 per GPU (global 1024 at 8 GPUs), same step, every rank takes part (sub-record;
@@ -246,11 +264,12 @@ def main():
             dp.train_step(model, crit, opt, f2, c2, m2, reducer)
         sync_all()
         t0 = time.perf_counter()
-        n128 = 5
+        n128 = 20
         for _ in range(n128):
             dp.train_step(model, crit, opt, f2, c2, m2, reducer)
         sync_all()
         d128 = time.perf_counter() - t0
+        capi.check_async_error()
         if use_pg:
             t = torch.tensor([d128], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -277,10 +296,15 @@ def main():
                 l2 = crit(probs, pc, pm)
                 l2.backward()
             torch.cuda.synchronize(dev)
+            capi.check_async_error()
             capi.check(lib.s2vt_prof_enable(0), "prof_enable")
-            r = {k: capi.prof_read(i) for i, k in enumerate(("gemm", "step_fwd", "step_bwd", "ce"))}
+            # (sum of bracket durations, launches, BUSY time = union of the brackets over both lanes): brackets of one
+            # kind overlap where the two lanes run the same kind of kernel side by side (the weight-gradient GEMMs of the
+            # two layers, the two layers' timesteps), and each overlapped launch lasts about twice as long as alone - the
+            # sum counts that time twice, throughput is priced with the busy time
+            r = {k: capi.prof_read(i) + (capi.prof_read_busy(i),) for i, k in enumerate(("gemm", "step_fwd", "step_bwd", "ce"))}
             capi.check(lib.s2vt_prof_reset(), "prof_reset")
-            return {k: (ms / nprof, n // nprof) for k, (ms, n) in r.items()}
+            return {k: (ms / nprof, n // nprof, busy / nprof) for k, (ms, n, busy) in r.items()}
 
         T = 2 * L - 1
         x3 = (mode == 3) and (B % 64 == 0)
@@ -291,73 +315,94 @@ def main():
 
         # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh), committed
         # under profiles/ — counters cannot be collected from inside this process.  Only valid for the default workload.
-        pmc = {}
-        try:
-            if B == 64 and not bf:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_traffic_pmc_c2.json")))["kernels"]
-            elif B == 256 and bf:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "round2_traffic_pmc_c3.json")))["kernels"]
-        except Exception:
-            pmc = {}
-
-        def traffic(kernel):
-            """HBM bytes per launch; for a persistent kernel (one launch = many timesteps) per layer timestep, the unit its
-            `achieved` / `algorithmic_bytes_per_launch` fields are expressed in"""
-            e = pmc.get(kernel)
-            if not e:
-                return None
-            if "hbm_bytes_per_layer_timestep" in e:
-                return int(e["hbm_bytes_per_layer_timestep"])
-            return int(e["hbm_bytes_per_launch"]) if "hbm_bytes_per_launch" in e else None
+        def load_pmc(tag):
+            """(kernels, provenance) of the committed PMC traffic file of this workload; STATIC data: the file names the
+            commit it was measured at, and a kernel changed since then carries a stale figure until the passes are re-run
+            (tools/profile_round3.sh)."""
+            for rnd in ("round3", "round2"):
+                path = os.path.join(ROOT, "profiles", "%s_traffic_pmc_%s.json" % (rnd, tag))
+                try:
+                    j = json.load(open(path))
+                    return j["kernels"], {"static": "profiles/%s@%s" % (os.path.basename(path), j.get("commit", "unrecorded"))}
+                except Exception:
+                    continue
+            return {}, None
+        pmc, pmc_src = ({}, None)
+        if B == 64 and not bf:
+            pmc, pmc_src = load_pmc("c2")
+        elif B == 256 and bf:
+            pmc, pmc_src = load_pmc("c3")
 
         rmode = lib.s2vt_set_recurrence_mode(-1)
         persist_bf16 = bf and rmode >= 1           # the timed configuration runs the persistent bf16 recurrence kernels
         persist_f32 = (not bf) and x3 and rmode >= 2
 
-        def rooflines(pr, how, persist):
-            gemm_ms, gemm_n = pr["gemm"]
+        def rooflines(pr, how, persist, B_=B, esz_=esz, bf_=bf, x3_=x3, pmc_=None, pmc_src_=None):
+            pmc_ = pmc if pmc_ is None else pmc_
+            pmc_src_ = pmc_src if pmc_src_ is None else pmc_src_
+
+            def traffic_of(kernel):
+                e = pmc_.get(kernel)
+                if not e:
+                    return None
+                if "hbm_bytes_per_layer_timestep" in e:
+                    return int(e["hbm_bytes_per_layer_timestep"])
+                return int(e["hbm_bytes_per_launch"]) if "hbm_bytes_per_launch" in e else None
+            gflop_ = gemm_flops_train(B_, L, F, H, E, V) / 1e9
+            pair_ = step_bytes_fwd(B_, H, H, s=esz_) + step_bytes_fwd(B_, H, E + H, s=esz_)
+            gemm_ms, gemm_n, gemm_busy = pr["gemm"]
             sf_ms, sb_ms = pr["step_fwd"][0], pr["step_bwd"][0]
-            gemm_tf = gflop / gemm_ms                 # GFLOP / ms = TFLOP/s
+            gemm_tf = gflop_ / gemm_busy              # GFLOP / ms = TFLOP/s over the time at least one GEMM was running
             step_us = sf_ms * 1e3 / (2 * T)           # average timestep of one layer, forward (2T per step: both layers)
             bstep_us = sb_ms * 1e3 / (2 * T)
-            step_gbs = (pair_bytes / 2) / (step_us * 1e-6) / 1e9
-            bstep_gbs = (pair_bytes / 2) / (bstep_us * 1e-6) / 1e9
-            if bf:
+            step_gbs = (pair_ / 2) / (step_us * 1e-6) / 1e9
+            bstep_gbs = (pair_ / 2) / (bstep_us * 1e-6) / 1e9
+            if bf_:
                 gk, gpeak, gnote = "gemm_b1_kernel", MFMA_BF16_PEAK_TF, "bf16 operands, fp32 accumulate"
-            elif x3:   # each algorithmic fp32 product costs six bf16 MFMA products (three planes per operand)
+            elif x3_:   # each algorithmic fp32 product costs six bf16 MFMA products (three planes per operand)
                 gk, gpeak = "gemm_x3_kernel", MFMA_BF16_PEAK_TF / 6.0
                 gnote = ("achieved = algorithmic (fp32-equivalent) FLOP/s; peak = bf16 dense MFMA peak / 6 plane products; "
                          "executed MFMA rate = 6 x achieved")
             else:
                 gk, gpeak, gnote = "gemm_f32_kernel", MFMA_F32_PEAK_TF, "fp32-input MFMA"
+            gnote += ("; achieved = algorithmic FLOPs of all GEMM launches of a step / BUSY time (union of the launch brackets: "
+                      "GEMMs of the two lanes that run side by side are counted once); `sum_of_launch_ms` counts overlapped "
+                      "launches twice and is what a per-kernel profile (rocprofv3 --stats) adds up to")
             rg = {"kernel": gk, "bound": "mfma", "achieved": round(gemm_tf, 2),
                   "peak": round(gpeak, 1), "unit": "TFLOP/s", "frac": round(gemm_tf / gpeak, 4),
-                  "traffic": traffic(gk), "launches_per_step": gemm_n, "ms_per_step": round(gemm_ms, 3),
-                  "algorithmic_bytes_or_flops_per_launch": round(gflop * 1e9 / max(gemm_n, 1)),
-                  "algorithmic_gflop_per_step": round(gflop, 1), "timing": how, "note": gnote}
+                  "traffic": traffic_of(gk), "traffic_source": pmc_src_, "launches_per_step": gemm_n,
+                  "busy_ms_per_step": round(gemm_busy, 3), "sum_of_launch_ms": round(gemm_ms, 3),
+                  "frac_by_sum_of_launch_ms": round(gflop_ / gemm_ms / gpeak, 4),
+                  "algorithmic_bytes_or_flops_per_launch": round(gflop_ * 1e9 / max(gemm_n, 1)),
+                  "algorithmic_gflop_per_step": round(gflop_, 1), "timing": how, "note": gnote}
             if persist:
-                fk = "lstm_seq_fwd_bf16_persist_kernel" if bf else "lstm_seq_fwd_f32_persist_kernel"
+                fk = "lstm_seq_fwd_bf16_persist_kernel" if bf_ else "lstm_seq_fwd_f32_persist_kernel"
                 fnote = ("PERSISTENT-WEIGHTS kernel: one launch runs a block of timesteps of BOTH layers with every W_hh slice "
                          "resident in registers, so W is not re-streamed and the fraction may exceed 1 (SURVEY.md §8(d)); "
-                         "achieved = §8(d) bytes of a (vid, word) timestep pair / 2 over the average per-layer timestep = launch "
-                         "duration / timesteps in the launch")
+                         "achieved = §8(d) ALGORITHMIC bytes of a (vid, word) timestep pair / 2 over the average per-layer timestep "
+                         "= launch duration / timesteps in the launch: an equivalent-streaming rate, not bytes that moved - "
+                         "`hbm_gbs_measured` is PMC traffic / the same time")
             else:
-                fk = "lstm_step_fwd_bf16_kernel" if bf else "lstm_step_fwd_kernel"
+                fk = "lstm_step_fwd_bf16_kernel" if bf_ else "lstm_step_fwd_kernel"
                 fnote = ("bytes per SURVEY.md §8(d) incl. W_ih although the x-part is hoisted into a batched GEMM; avg over vid+word "
                          "launches, loop-bracketed events (includes launch gaps)")
             if persist:
-                bk = "lstm_seq_bwd_bf16_persist_kernel" if bf else "lstm_seq_bwd_f32_persist_kernel"
+                bk = "lstm_seq_bwd_bf16_persist_kernel" if bf_ else "lstm_seq_bwd_f32_persist_kernel"
             else:
-                bk = "lstm_step_bwd_bf16_kernel" if bf else "lstm_step_bwd_kernel"
-            rs = {"kernel": fk, "bound": "hbm", "achieved": round(step_gbs, 1),
-                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(step_gbs / HBM_PEAK_GBS, 4),
-                  "traffic": traffic(fk), "avg_launch_us": round(step_us, 3), "launches_per_step": 2 * T,
-                  "algorithmic_bytes_per_launch": pair_bytes // 2, "timing": how, "note": fnote}
-            rb = {"kernel": bk, "bound": "hbm", "achieved": round(bstep_gbs, 1),
-                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(bstep_gbs / HBM_PEAK_GBS, 4),
-                  "traffic": traffic(bk), "avg_launch_us": round(bstep_us, 3), "launches_per_step": 2 * T,
-                  "algorithmic_bytes_per_launch": pair_bytes // 2, "timing": how,
-                  "note": "BPTT timestep: dh = dG_{t+1} W_hh + gate derivatives; same §8(d) byte accounting as the forward timestep"}
+                bk = "lstm_step_bwd_bf16_kernel" if bf_ else "lstm_step_bwd_kernel"
+
+            def step_rec(kernel, gbs, us, note):
+                tr = traffic_of(kernel)
+                return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                        "traffic": tr, "traffic_source": pmc_src_ if tr is not None else None,
+                        "hbm_gbs_measured": round(tr / (us * 1e-6) / 1e9, 1) if tr is not None else None,
+                        "avg_launch_us": round(us, 3), "launches_per_step": 2 * T,
+                        "ms_per_step": round(us * 2 * T / 1e3, 3),
+                        "algorithmic_bytes_per_launch": pair_ // 2, "timing": how, "note": note}
+            rs = step_rec(fk, step_gbs, step_us, fnote)
+            rb = step_rec(bk, bstep_gbs, bstep_us,
+                          "BPTT timestep: dh = dG_{t+1} W_hh + gate derivatives; same §8(d) byte accounting as the forward timestep")
             return rg, rs, rb
 
         live = profile()
@@ -379,11 +424,17 @@ def main():
                roof_bstep["kernel"]: live["step_bwd"][0], "ce": live["ce"][0]}
         fam_alone = None if args.headline_only else {gname: alone["gemm"][0], roof_step_alone["kernel"]: alone["step_fwd"][0],
                                                      roof_bstep_alone["kernel"]: alone["step_bwd"][0], "ce": alone["ce"][0]}
-        # The headline roofline is the fused LSTM TIMESTEP (forward): it is the kernel north_star puts its target on, and the
-        # timestep family (forward + BPTT) is the largest share of the kernel time of a step (the batched GEMMs are second).
-        roofline = dict(roof_step)
-        roofline["family_ms_per_step"] = {"timestep_fwd+bwd": round(fam[roof_step["kernel"]] + fam[roof_bstep["kernel"]], 3),
-                                          "batched_gemm": round(fam[gname], 3)}
+        # The headline `roofline` is the kernel family with the LARGEST live time in THIS run (sum of its launch durations, what
+        # a per-kernel profile ranks by); the other two families follow as roofline_gemm / roofline_lstm_step[_bwd], and
+        # `roofline_min` names the weakest fraction of the three.
+        cands = [roof_gemm, roof_step, roof_bstep]
+        live_ms = [live["gemm"][0], live["step_fwd"][0], live["step_bwd"][0]]
+        roofline = dict(cands[max(range(3), key=lambda i: live_ms[i])])
+        roofline["chosen_as"] = "largest sum of launch durations in this run"
+        roofline["family_ms_per_step"] = {"batched_gemm": round(live_ms[0], 3), "timestep_fwd": round(live_ms[1], 3),
+                                          "timestep_bwd": round(live_ms[2], 3)}
+        weakest = min(cands, key=lambda r: r["frac"])
+        roofline_min = {"kernel": weakest["kernel"], "frac": weakest["frac"], "bound": weakest["bound"]}
 
         decode = beam = None
         if not args.headline_only:
@@ -430,6 +481,7 @@ def main():
             beam = {"metric": "beam-search captions/sec (beam 5, depth 30)", "value": round(Bd / bdt, 1), "unit": "captions/s",
                     "batch": Bd, "ms_per_call": round(bdt * 1e3, 2), "n_gpus": 1, "calls_timed": nbm}
             model.train()
+            capi.check_async_error()
 
         # ---- BASELINE configs[2] in the same run (N = 1): B=256, bf16 operands / fp32 accumulate (s2vt_set_gemm_mode(1)),
         # persistent recurrence kernels - the configuration north_star puts its roofline target on
@@ -442,29 +494,24 @@ def main():
                     dp.train_step(model, crit, opt, b3[0], b3[1], b3[2], None)
                 torch.cuda.synchronize(dev)
                 t3 = time.perf_counter()
-                n3 = 5
+                n3 = 20
                 for _ in range(n3):
                     dp.train_step(model, crit, opt, b3[0], b3[1], b3[2], None)
                 torch.cuda.synchronize(dev)
                 d3 = (time.perf_counter() - t3) / n3
+                capi.check_async_error()
                 pr3 = profile(2, b3)
-                pair3 = step_bytes_fwd(256, H, H, s=2) + step_bytes_fwd(256, H, E + H, s=2)
-                fus, bus = pr3["step_fwd"][0] * 1e3 / (2 * T), pr3["step_bwd"][0] * 1e3 / (2 * T)
                 pers = lib.s2vt_set_recurrence_mode(-1) >= 1
-
-                def rec(kernel, us):
-                    gbs = (pair3 / 2) / (us * 1e-6) / 1e9
-                    return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(gbs / HBM_PEAK_GBS, 4), "avg_launch_us": round(us, 3), "launches_per_step": 2 * T,
-                            "algorithmic_bytes_per_launch": pair3 // 2,
-                            "note": "per layer timestep; persistent-weights kernel (W_hh not re-streamed)" if pers else "per launch"}
+                pmc3, pmc3_src = load_pmc("c3")
+                g3, f3, bw3 = rooflines(pr3, "live, persistent recurrence (block %d)" % prev_blk if pers else "live", pers,
+                                        B_=256, esz_=2, bf_=True, x3_=False, pmc_=pmc3, pmc_src_=pmc3_src)
                 config3 = {"workload": "BASELINE configs[2]: B=256, 80x4096 feats, hidden=embed=1000, vocab=12000, bf16 operands / "
                                        "fp32 accumulate, Adam", "dtype": "bf16", "value": round(256 * L / d3, 1), "unit": "frames/s",
                            "ms_per_step": round(d3 * 1e3, 3), "steps": n3,
-                           "roofline_lstm_step": rec("lstm_seq_fwd_bf16_persist_kernel" if pers else "lstm_step_fwd_bf16_kernel", fus),
-                           "roofline_lstm_step_bwd": rec("lstm_seq_bwd_bf16_persist_kernel" if pers else "lstm_step_bwd_bf16_kernel", bus),
-                           "gemm_tflops": round(gemm_flops_train(256, L, F, H, E, V) / 1e9 / pr3["gemm"][0], 1),
-                           "kernel_ms_per_step": {k: round(v[0], 3) for k, v in pr3.items()}}
+                           "roofline_lstm_step": f3, "roofline_lstm_step_bwd": bw3, "roofline_gemm": g3,
+                           "gemm_tflops": g3["achieved"],
+                           "kernel_ms_per_step": {k: round(v[0], 3) for k, v in pr3.items()},
+                           "kernel_busy_ms_per_step": {k: round(v[2], 3) for k, v in pr3.items()}}
                 del b3
             finally:
                 lib.s2vt_set_gemm_mode(prev_mode)
@@ -518,13 +565,17 @@ def main():
                                     "hidden=embed=1000, vocab=12000, fp32, Adam" % (B, world)),
                        "global_batch": B * world, "frames": L, "parallelism": "dp%d" % world},
             "final_loss": round(final_loss, 6), "host_enqueue_ms_per_step": round(host_ms, 3),
+            "host_enqueue_ms_by_phase": host_phases,
             "pipeline_streams_overlap": int(lib.s2vt_pipeline_overlaps()),
             "roofline": roofline,
+            "roofline_min": roofline_min,
             "roofline_gemm": roof_gemm,
             "roofline_lstm_step": roof_step,
             "roofline_lstm_step_bwd": roof_bstep,
             "roofline_isolated": None if args.headline_only else {"gemm": roof_gemm_alone, "lstm_step": roof_step_alone, "lstm_step_bwd": roof_bstep_alone},
             "kernel_ms_per_step": {k: round(v, 3) for k, v in fam.items()},
+            "kernel_busy_ms_per_step": {"gemm": round(live["gemm"][2], 3), "step_fwd": round(live["step_fwd"][2], 3),
+                                        "step_bwd": round(live["step_bwd"][2], 3), "ce": round(live["ce"][2], 3)},
             "kernel_ms_per_step_isolated": {k: round(v, 3) for k, v in fam_alone.items()} if fam_alone else None,
             "decode": decode,
             "beam": beam,

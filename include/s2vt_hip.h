@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define S2VT_ABI_VERSION 3
+#define S2VT_ABI_VERSION 4
 
 /* negative return codes (positive ones are hipError_t values) */
 #define S2VT_ERR_ARG (-1)      /* bad argument */
@@ -277,6 +277,11 @@ int s2vt_set_pipeline_block(int32_t steps);
  * candidate overlapped (the drivers still run, serially), -1 before the first pipelined call. */
 int s2vt_pipeline_overlaps(void);
 
+/* Test support (tests/test_gpu_kernels.py: co-residency of the persistent recurrence): launches `workgroups` one-wave
+ * workgroups that each hold `lds_bytes` (<= 160 KB) of LDS and spin for `microseconds` (<= 5 s) - a stand-in for a foreign
+ * kernel (an RCCL all-reduce on a communication stream, another tenant of the GPU) sitting on the compute units. */
+int s2vt_test_occupy_cus(int32_t workgroups, int32_t lds_bytes, int64_t microseconds, void* stream);
+
 /* ---------------------------------------------------------------- live kernel timing (bench.py)
  * When enabled, launch sites bracket kernels of one kind with hipEvents on the launch stream.
  * kinds: 0 gemm, 1 lstm_step_fwd (whole sequence loop), 2 lstm_step_bwd (whole sequence loop),
@@ -284,6 +289,9 @@ int s2vt_pipeline_overlaps(void);
 int s2vt_prof_enable(int32_t on);
 /* Synchronises the recorded events; returns summed milliseconds and launch count for `kind`. */
 int s2vt_prof_read(int32_t kind, double* total_ms, int64_t* launches);
+/* Milliseconds during which at least one bracket of `kind` was open (union of the intervals over both lanes): brackets of
+ * one kind overlap where the two lanes run the same kind of kernel side by side, and the sum above counts that time twice. */
+int s2vt_prof_read_busy(int32_t kind, double* busy_ms);
 int s2vt_prof_reset(void);
 
 #ifdef __cplusplus

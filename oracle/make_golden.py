@@ -235,6 +235,96 @@ def gen_beam_only(name, cfg, seed, beam_b, beam_width, out_scale=1.0):
     print(f"[{name}] wrote {name}.npz; oracle beam == reference beam")
 
 
+C5FULL_CHOICE = (460, 16.0)   # screen_c5full(range(400, 640)): seed 460 has the widest weakest greedy margin of 240 seeds (2.6e-4 at out_scale 1: no row below 1e-4);
+                                # out_scale 16: 1 of 128 beam searches rests on a score gap below 1e-5 (oracle replay), 7 below 3e-5
+
+
+def screen_c5full(seeds, scales=(1.0, 2.0, 4.0, 8.0)):
+    """Screening for the B=128 fixture of BASELINE configs[4]: per seed the smallest greedy top-2 margin over all 128 x 79
+    decisions at out_scale 1 (oracle) and the number of rows whose weakest margin is below 1e-4 / 3e-5."""
+    d = dict(synth.CONFIGS["c5"])
+    for seed in seeds:
+        sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed)
+        feats, _, _ = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
+        _, marg = orc.greedy_decode(sd, feats, return_margins=True)
+        rm = marg.min(dim=1).values
+        print(f"[screen c5full] seed={seed} min margin={marg.min().item():.3e} rows<1e-4: {int((rm < 1e-4).sum())} "
+              f"rows<3e-5: {int((rm < 3e-5).sum())}", flush=True)
+
+
+def _c5full_beam_worker(job):
+    """One worker = the reference's beam_search (S2VTModel.py:149-240) on rows [lo, hi) of the B=128 batch.  The encoder part
+    of forward(mode='beam_search') (:56-60) runs on the FULL batch in every worker (one thread: the same numbers everywhere);
+    only the per-sample Python search - 16 s per caption - is divided, by handing the reference's own method a slice of the
+    states it was called with."""
+    seed, out_scale, lo, hi, beam_width = job
+    torch.set_num_threads(1)
+    S2VT, _ = _reference()
+    d = synth.CONFIGS["c5"]
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed, out_scale=out_scale)
+    feats, _, _ = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
+    m = _ref_model(S2VT, d, sd)
+    m.eval()
+    search = m.beam_search
+
+    def rows_only(state1, state2, **kw):
+        return search(tuple(x[:, lo:hi].contiguous() for x in state1), tuple(x[:, lo:hi].contiguous() for x in state2), **kw)
+    m.beam_search = rows_only
+    with torch.no_grad():
+        out = m(feats, mode="beam_search", beam_width=beam_width, max_beam_depth=30)
+    return lo, [[int(t.item()) for t in s] for s in out]
+
+
+def gen_c5full(seed, out_scale, beam_width=5, workers=6, name="c5full"):
+    """BASELINE configs[4] at its own size: B=128, beam 5, depth 30 (S2VTModel.py:56-61,149-240; eval.py:81-96) and the greedy
+    decode of the same batch (S2VTModel.py:82-110), both from the REFERENCE (one CPU thread), with the per-row weakest top-2
+    margin of the greedy decode and the per-sample weakest decision gap of the beam search (oracle replay) stored beside the
+    ids so that a test can tell a wrong id from a legitimately flipped near-tie."""
+    import multiprocessing as mp
+    torch.set_num_threads(1)
+    S2VT, _ = _reference()
+    d = synth.CONFIGS["c5"]
+    B = d["B"]
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed, out_scale=out_scale)
+    feats, _, _ = synth.make_batch(B, d["L"], d["F"], d["V"], seed=1234 + seed)
+    t0 = time.time()
+    m = _ref_model(S2VT, d, sd)
+    m.eval()
+    with torch.no_grad():
+        ids = m(feats, mode="test")
+    print(f"[{name}] reference greedy B={B}: {time.time()-t0:.1f}s", flush=True)
+    step = (B + workers - 1) // workers
+    jobs = [(seed, out_scale, lo, min(lo + step, B), beam_width) for lo in range(0, B, step)]
+    t0 = time.time()
+    with mp.get_context("spawn").Pool(len(jobs)) as pool:
+        parts = dict(pool.map(_c5full_beam_worker, jobs))
+    ref_beam = [s for lo in sorted(parts) for s in parts[lo]]
+    assert len(ref_beam) == B
+    print(f"[{name}] reference beam(bw={beam_width}, B={B}) in {len(jobs)} workers: {time.time()-t0:.1f}s", flush=True)
+    torch.set_num_threads(8)
+    oids, marg = orc.greedy_decode(sd, feats, return_margins=True)
+    o_beam, gaps = orc.beam_search(sd, feats, beam_width=beam_width, max_depth=30, return_gap="per_sample")
+    g_same = (ids == oids).all(dim=1).numpy()
+    b_same = np.array([a == b for a, b in zip(o_beam, ref_beam)])
+    rm = marg.min(dim=1).values.numpy()
+    gaps = np.array(gaps, dtype=np.float64)
+    print(f"[{name}] oracle == reference: greedy rows {int(g_same.sum())}/{B}, beam rows {int(b_same.sum())}/{B}")
+    print(f"[{name}] weakest greedy margin {rm.min():.3e} (rows < 1e-4: {int((rm < 1e-4).sum())}); weakest beam gap "
+          f"{gaps.min():.3e} (rows < 1e-4: {int((gaps < 1e-4).sum())}, < 3e-5: {int((gaps < 3e-5).sum())})")
+    # the oracle may only differ from the reference where the recorded margin says a rounding difference can decide
+    assert all(rm[i] < 1e-4 for i in np.nonzero(~g_same)[0]), rm[~g_same]
+    assert all(gaps[i] < 1e-4 for i in np.nonzero(~b_same)[0]), gaps[~b_same]
+    mx = max(len(s) for s in ref_beam)
+    arr = -np.ones((B, mx), dtype=np.int64)
+    for i, s in enumerate(ref_beam):
+        arr[i, :len(s)] = s
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), seed=seed, out_scale=out_scale, beam_width=np.array(beam_width),
+                        dims=np.array([d[k] for k in "BLFHEV"], dtype=np.int64), beam_ids=arr, beam_gap=gaps,
+                        beam_oracle_equal=b_same, greedy_ids=ids.numpy(), greedy_margin=marg.numpy().astype(np.float32),
+                        greedy_oracle_equal=g_same)
+    print(f"[{name}] wrote {name}.npz")
+
+
 def gen_pickle():
     """A full-module pickle WRITTEN BY THE REFERENCE class (train.py:167-168 style) at tiny
     dims, to test that the drop-in S2VTModel.S2VT loads reference checkpoints."""
@@ -305,5 +395,9 @@ if __name__ == "__main__":
         gen_long()
     if "mid64long" in which:
         gen_long("mid64long", "mid64", seed=41)
+    if "c3long" in which:   # BASELINE configs[2] at its own size: 10 fp32 reference Adam steps (lr 1e-3) on one B=256 batch;
+        gen_long("c3long", "c3", seed=5, n_steps=10)       # the bf16 GPU trajectory is compared with it step by step
+    if "c5full" in which:
+        gen_c5full(*C5FULL_CHOICE)
     if "c5beam" in which:
         gen_beam_only("c5beam", "c5", seed=C5_CHOICE[0], beam_b=4, beam_width=5, out_scale=C5_CHOICE[1])

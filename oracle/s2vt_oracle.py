@@ -192,7 +192,7 @@ def beam_search(params, feats, beam_width=3, max_depth=30, sos_ix=3, eos_ix=4, f
     ``return_gap``: also return the smallest score gap any decision of the search rested on (per depth: between the
     last entry popped and the best entry discarded by the clear; at the end: between the winner and the runner-up).
     Fixture screening only (oracle/make_golden.py): a reimplementation whose log-probs differ by less than this gap
-    takes the same decisions.
+    takes the same decisions.  ``return_gap="per_sample"`` returns the list of per-sample gaps instead of their minimum.
     """
     p = _cast(params, dtype)
     feats = feats.to(dtype)
@@ -207,7 +207,9 @@ def beam_search(params, feats, beam_width=3, max_depth=30, sos_ix=3, eos_ix=4, f
 
     sentences = []
     min_gap = float("inf")
+    sample_gaps = []
     for b in range(B):                                                        # :170
+        min_gap = float("inf")
         root = _Node((h1[b:b + 1], c1[b:b + 1]), (h2[b:b + 1], c2[b:b + 1]), None, sos_ix, 0, 1)
         heap = []
         heapq.heappush(heap, (-root.score(), root))                           # :182
@@ -246,8 +248,11 @@ def beam_search(params, feats, beam_width=3, max_depth=30, sos_ix=3, eos_ix=4, f
             fin = fin.prev
             sent.append(fin.tok)
         sentences.append(sent[::-1])
+        sample_gaps.append(min_gap)
+    if return_gap == "per_sample":
+        return sentences, sample_gaps
     if return_gap:
-        return sentences, min_gap
+        return sentences, min(sample_gaps)
     return sentences
 
 

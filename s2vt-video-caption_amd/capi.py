@@ -33,7 +33,7 @@ class Grads(ctypes.Structure):
 
 
 # name -> (restype, argtypes): every symbol include/s2vt_hip.h declares
-ABI_VERSION = 3          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
+ABI_VERSION = 4          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
 
 SIGNATURES = {
     "s2vt_abi_version": (c_int32, []),
@@ -94,8 +94,10 @@ SIGNATURES = {
     "s2vt_set_gemm_mode": (c_int32, [c_int32]),
     "s2vt_set_pipeline_block": (c_int32, [c_int32]),
     "s2vt_pipeline_overlaps": (c_int32, []),
+    "s2vt_test_occupy_cus": (c_int32, [c_int32, c_int32, c_int64, c_void_p]),
     "s2vt_prof_enable": (c_int32, [c_int32]),
     "s2vt_prof_read": (c_int32, [c_int32, POINTER(c_double), POINTER(c_int64)]),
+    "s2vt_prof_read_busy": (c_int32, [c_int32, POINTER(c_double)]),
     "s2vt_prof_reset": (c_int32, []),
 }
 
@@ -150,6 +152,13 @@ def check_async_error(wait=True):
     """Raise the device-side error (target id out of range -> IndexError, hand-off time-out) of the last
     s2vt_train_forward, if any.  Call after a stream synchronisation (loss.item()) to get it without delay."""
     check(load().s2vt_check_async_error(1 if wait else 0), "s2vt_check_async_error")
+
+
+def prof_read_busy(kind):
+    """wall-clock ms during which at least one bracket of `kind` was open (overlapping lanes counted once)"""
+    ms = c_double(0.0)
+    check(load().s2vt_prof_read_busy(kind, ctypes.byref(ms)), "s2vt_prof_read_busy")
+    return ms.value
 
 
 def prof_read(kind):

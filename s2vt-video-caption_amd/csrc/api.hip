@@ -5,7 +5,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/s2vt_hip.h"
@@ -66,7 +68,9 @@ static int read_record(ErrRecord& r, bool wait) {
     }
     return 0;
 }
+static std::mutex g_async_mutex;        // forward (caller's thread) and backward (autograd's thread) both post and poll
 static int poll_async_error(bool wait) {
+    std::lock_guard<std::mutex> lock(g_async_mutex);
     for (int k = 0; k < 3; ++k) {
         int rc = read_record(g_async[k], wait);
         if (rc) return rc;
@@ -74,6 +78,7 @@ static int poll_async_error(bool wait) {
     return 0;
 }
 static int post_async_error(hipStream_t st, const int* dev_flags, int kind = 0) {
+    std::lock_guard<std::mutex> lock(g_async_mutex);
     ErrRecord& r = g_async[kind];
     if (!r.host) {
         S2VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&r.host), 4 * sizeof(int), hipHostMallocDefault));
@@ -591,17 +596,29 @@ static SeqBwdF32Args persist_bwd_f32_args(int T, int t0, int t1, int B, int H, c
 // What a forward was run with, keyed by its workspace: s2vt_train_backward must find the same arithmetic mode and
 // recurrence schedule (they decide how the workspace is carved and which images the forward left in it), otherwise it
 // refuses instead of reading a differently carved workspace.  Host-side only.
-struct FwdRecord { s2vt_dims d; int gemm_mode, planes, persist; };
+struct FwdRecord { s2vt_dims d; int gemm_mode, planes, persist; unsigned long long seq; };
 static std::map<const void*, FwdRecord> g_fwd_records;
+static std::mutex g_fwd_mutex;          // autograd runs the backward on its own thread
+static unsigned long long g_fwd_seq = 0;
 static void record_forward(const void* ws, const s2vt_dims& d, bool planes) {
-    if (g_fwd_records.size() >= 64) g_fwd_records.erase(g_fwd_records.begin());     // forwards that never ran a backward
-    g_fwd_records[ws] = FwdRecord{d, gemm_mode(), planes ? ((gemm_mode() == 1) ? 1 : 3) : 0, persist_mode()};
+    std::lock_guard<std::mutex> lock(g_fwd_mutex);
+    if (g_fwd_records.size() >= 64 && !g_fwd_records.count(ws)) {     // forwards that never ran a backward (validation,
+        auto oldest = g_fwd_records.begin();                          // forward-only tools): the OLDEST record goes, never
+        for (auto it = g_fwd_records.begin(); it != g_fwd_records.end(); ++it)      // one of a forward still awaiting its backward
+            if (it->second.seq < oldest->second.seq) oldest = it;
+        g_fwd_records.erase(oldest);
+    }
+    g_fwd_records[ws] = FwdRecord{d, gemm_mode(), planes ? ((gemm_mode() == 1) ? 1 : 3) : 0, persist_mode(), ++g_fwd_seq};
 }
 static int check_forward_record(const void* ws, const s2vt_dims& d, bool planes) {
-    auto it = g_fwd_records.find(ws);
-    S2VT_REQUIRE(it != g_fwd_records.end(), "s2vt_train_backward: no s2vt_train_forward has run on this workspace");
-    const FwdRecord r = it->second;
-    g_fwd_records.erase(it);
+    FwdRecord r;
+    {
+        std::lock_guard<std::mutex> lock(g_fwd_mutex);
+        auto it = g_fwd_records.find(ws);
+        S2VT_REQUIRE(it != g_fwd_records.end(), "s2vt_train_backward: no s2vt_train_forward has run on this workspace");
+        r = it->second;
+        g_fwd_records.erase(it);
+    }
     S2VT_REQUIRE(memcmp(&r.d, &d, sizeof(d)) == 0, "s2vt_train_backward: dims differ from the forward that filled this workspace");
     const int planes_now = planes ? ((gemm_mode() == 1) ? 1 : 3) : 0;
     S2VT_REQUIRE(r.gemm_mode == gemm_mode() && r.planes == planes_now && r.persist == persist_mode(),
@@ -820,6 +837,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
                     return rc;
             }
         }
+        if ((rc = grads_ready(0, st))) return rc;                  // (see the bf16 branch below)
         if ((rc = handoff(st, sx, ev++))) return rc;
     } else if (bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad) {
         // Persistent schedule, ONE stream (mirror of the forward): the launch of stage k runs the word_rnn BPTT of block k
@@ -853,6 +871,12 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
                     return rc;
             }
         }
+        // Data-parallel overlap: a persistent launch needs every one of its workgroups resident, so no foreign kernel (the
+        // RCCL all-reduce of gradient group 0 on the caller's communication stream) may start beside one and hold LDS /
+        // wave slots on a compute unit.  "Group 0 is final" is therefore re-recorded HERE, behind the last persistent
+        // launch: s2vt_backward_wait_grads(0) then releases the out_linear all-reduce when the recurrence has left the
+        // chip, and it overlaps the weight-gradient GEMMs below instead of the BPTT.
+        if ((rc = grads_ready(0, st))) return rc;
         if ((rc = handoff(st, sx, ev++))) return rc;               // lane B's parameter-gradient GEMMs need dG1
     } else
     for (size_t k = bd.size() - 1; k >= 1; --k) {
@@ -888,18 +912,21 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = pgemm(la, R, E, 4 * H, q.dg2, L * B, 0, q.weT, 0, 0, w.de, E, ID, nullptr, false))) return rc;
     if ((rc = embedding_grad(st, w.de, R, E, w.tok, V, g->emb_w, w.embws))) return rc;
     if ((rc = grads_ready(1, st))) return rc;
-    // lane B: vid_rnn and feat_linear parameter gradients
-    if ((rc = pgemm(lb, 4 * H, H, (T - 1) * B, q.dg1T, 0, B, q.h1T, 0, 0, g->vid_w_hh, H, ID, nullptr, false))) return rc;
-    if ((rc = pgemm(lb, 4 * H, H, L * B, q.dg1T, 0, 0, q.x1T, 0, 0, g->vid_w_ih, H, ID, nullptr, false))) return rc;
-    if ((rc = colsum_finish(sx, w.colsum_b, T * B / 64, 4 * H, g->vid_b_ih, false))) return rc;
-    S2VT_HIP(hipMemcpyAsync(g->vid_b_hh, g->vid_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, sx));
-    if ((rc = pgemm(lb, L * B, H, 4 * H, q.dg1, 0, 0, q.wih1T, 0, 0, w.dx1, H, ID, nullptr, false))) return rc;
-    if ((rc = pdual(lb, w.dx1, H, ID, L * B, H, nullptr, 0, &q.dx1T, 0, w.colsum_b))) return rc;
-    if ((rc = psplitT(lb, q.featsT, 0, feats, F, perm(B, L), L * B, F))) return rc;
-    if ((rc = pgemm(lb, H, F, L * B, q.dx1T, 0, 0, q.featsT, 0, 0, g->feat_w, F, ID, nullptr, false))) return rc;
-    if ((rc = colsum_finish(sx, w.colsum_b, L * B / 64, H, g->feat_b, false))) return rc;
+    // lane B: vid_rnn and feat_linear parameter gradients (S2VT_SERIAL_TAIL=1: behind lane A's on the caller's stream -
+    // an experiment switch: two MFMA-bound GEMMs side by side share the chip, neither gets faster)
+    static const bool serial_tail = getenv("S2VT_SERIAL_TAIL") && atoi(getenv("S2VT_SERIAL_TAIL")) != 0;
+    const Lane lt = serial_tail ? Lane{st, w.gws_b, w.gws_floats, w.colsum_b} : lb;
+    if ((rc = pgemm(lt, 4 * H, H, (T - 1) * B, q.dg1T, 0, B, q.h1T, 0, 0, g->vid_w_hh, H, ID, nullptr, false))) return rc;
+    if ((rc = pgemm(lt, 4 * H, H, L * B, q.dg1T, 0, 0, q.x1T, 0, 0, g->vid_w_ih, H, ID, nullptr, false))) return rc;
+    if ((rc = colsum_finish(lt.s, w.colsum_b, T * B / 64, 4 * H, g->vid_b_ih, false))) return rc;
+    S2VT_HIP(hipMemcpyAsync(g->vid_b_hh, g->vid_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, lt.s));
+    if ((rc = pgemm(lt, L * B, H, 4 * H, q.dg1, 0, 0, q.wih1T, 0, 0, w.dx1, H, ID, nullptr, false))) return rc;
+    if ((rc = pdual(lt, w.dx1, H, ID, L * B, H, nullptr, 0, &q.dx1T, 0, w.colsum_b))) return rc;
+    if ((rc = psplitT(lt, q.featsT, 0, feats, F, perm(B, L), L * B, F))) return rc;
+    if ((rc = pgemm(lt, H, F, L * B, q.dx1T, 0, 0, q.featsT, 0, 0, g->feat_w, F, ID, nullptr, false))) return rc;
+    if ((rc = colsum_finish(lt.s, w.colsum_b, L * B / 64, H, g->feat_b, false))) return rc;
     if (dfeats) {   // rarely requested (nothing reads it in the reference): fp32-MFMA GEMM
-        if ((rc = lgemm(lb, true, false, L * B, F, H, w.dx1, H, ID, p->feat_w, F, ID, dfeats, F, perm(B, L), nullptr, false)))
+        if ((rc = lgemm(lt, true, false, L * B, F, H, w.dx1, H, ID, p->feat_w, F, ID, dfeats, F, perm(B, L), nullptr, false)))
             return rc;
     }
     return handoff(sx, st, ev++);
@@ -1754,6 +1781,10 @@ int s2vt_set_gemm_mode(int32_t mode) {
 
 int s2vt_pipeline_overlaps(void) { return g_side_overlaps; }
 
+int s2vt_test_occupy_cus(int32_t workgroups, int32_t lds_bytes, int64_t microseconds, void* stream) {
+    return occupy_cus((hipStream_t)stream, workgroups, lds_bytes, microseconds);
+}
+
 int s2vt_set_pipeline_block(int32_t steps) {
     const int prev = pipe_block();
     g_pipe_block = steps < 0 ? 0 : steps;
@@ -1783,6 +1814,35 @@ int s2vt_prof_read(int32_t kind, double* total_ms, int64_t* launches) {
     }
     *total_ms = ms;
     *launches = n;
+    return 0;
+}
+
+// Wall-clock time during which AT LEAST ONE bracket of `kind` was open: the union of the recorded intervals on a common
+// time axis (the first bracket's start).  Brackets of one kind on the two lanes overlap (e.g. the weight-gradient GEMMs of
+// the two layers at the end of the backward share the chip: each launch then lasts about twice as long as alone), so the
+// SUM s2vt_prof_read returns counts that time twice; throughput figures must be priced with this one.
+int s2vt_prof_read_busy(int32_t kind, double* busy_ms) {
+    S2VT_REQUIRE(kind >= 0 && kind < K_NKINDS && busy_ms, "s2vt_prof_read_busy: bad arguments");
+    *busy_ms = 0.0;
+    if (g_recs.empty()) return 0;
+    const hipEvent_t ref = g_recs.front().a;
+    S2VT_HIP(hipEventSynchronize(ref));
+    std::vector<std::pair<double, double>> iv;
+    for (auto& r : g_recs) {
+        if (r.kind != kind) continue;
+        S2VT_HIP(hipEventSynchronize(r.b));
+        float s = 0.f, e = 0.f;
+        if (r.a != ref) S2VT_HIP(hipEventElapsedTime(&s, ref, r.a));
+        S2VT_HIP(hipEventElapsedTime(&e, ref, r.b));
+        if (e > s) iv.emplace_back((double)s, (double)e);
+    }
+    std::sort(iv.begin(), iv.end());
+    double busy = 0.0, hi = -1e300;
+    for (auto& x : iv) {
+        if (x.first > hi) { busy += x.second - x.first; hi = x.second; }
+        else if (x.second > hi) { busy += x.second - hi; hi = x.second; }
+    }
+    *busy_ms = busy;
     return 0;
 }
 

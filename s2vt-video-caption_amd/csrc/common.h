@@ -34,6 +34,11 @@ int check_hip(hipError_t e, const char* what);
     } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Workgroups of `kernel` (block size `block`, static LDS only) that can be RESIDENT AT ONCE on the current device: compute
+// units x occupancy per compute unit, as the runtime reports them (cached per device and kernel; 0 when the query fails).
+// The persistent recurrence kernels wait for each other inside a launch, so a launch may never be larger than this.
+int coresident_capacity(const void* kernel, int block);
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Row map of a stored matrix: stored_row = idx ? idx[r] : (inner ? (r % inner) * outer + r / inner : r).

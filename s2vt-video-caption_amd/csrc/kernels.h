@@ -188,6 +188,7 @@ size_t embedding_grad_ws_ints(int64_t rows, int V);
 int embedding_grad(hipStream_t s, const float* d_rows, int64_t rows, int E, const int32_t* tok, int V, float* d_emb, int* ws);
 int unpack_tokens(hipStream_t s, const unsigned long long* packed, int steps, int B, int64_t* out_ids);
 int fill_zero(hipStream_t s, void* p, size_t bytes);
+int occupy_cus(hipStream_t s, int workgroups, int lds_bytes, long long microseconds);   // test support (co-residency tests)
 int zero_pad_cols_u16(hipStream_t s, unsigned short* p, int64_t rows, int64_t ld, int col0, int col1);
 
 // ---- ce.hip

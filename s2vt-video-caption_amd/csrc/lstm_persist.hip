@@ -32,7 +32,9 @@
 // counter add; the consumer polls with an sc1 load, then a workgroup barrier, then loads.  h_t of every step has its
 // own address (time-major h image), so no CU ever holds an older copy of a line it is about to read; the LDS-DMA loads
 // carry sc1 as well.  Every spin is bounded (1 s of wall clock): on a time-out the workgroup sets *err and exits.
-// All workgroups of a launch must be co-resident (2 per CU): the launcher refuses grids above 2 x 252.
+// All workgroups of a launch must be co-resident (2 per CU): the launchers ask the runtime how many workgroups of the
+// kernel the device holds at once (compute units x occupancy, coresident_capacity()) and a shape that does not fit is
+// reported as unsupported, so the drivers fall back to one launch per timestep (api.hip).
 #include "common.h"
 #include "experiment.h"
 #include "kernels.h"
@@ -55,7 +57,8 @@ constexpr int P_HSM = P_SLAB;                     // bf16 h_t tile [32][16]
 constexpr int P_MAXNS = 4;
 constexpr int P_CST = P_HSM + P_SR * P_UN * 2;    // fp32 c_t of the workgroup's cells, per chain [32][16]
 constexpr int P_LDS = P_CST + P_MAXNS * P_SR * P_UN * 4;
-constexpr int P_MAX_WG = 504;                     // 2 workgroups on each of 252 CUs
+constexpr int P_MAX_WG = 512;                     // design point: 2 workgroups on each of 256 CUs (config 3 needs 2 x 252);
+                                                  // the launchers cap this by what the device reports (persist_capacity)
 constexpr unsigned long long P_SPIN_TICKS = 100000000ull;      // 1 s of the 100-MHz wall clock
 
 __device__ __forceinline__ unsigned short f2bf_rn(float x) {
@@ -323,6 +326,32 @@ __global__ __launch_bounds__(P_NT, 2) void lstm_seq_fwd_bf16_persist_kernel(SeqF
 int lstm_seq_fwd_bf16_persist_supported(int B, int H, int Kp);
 size_t lstm_persist_sync_bytes();
 
+int coresident_capacity(const void* kernel, int block) {
+    struct Entry { int dev; const void* k; int cap; };
+    static Entry cache[32];
+    static int n = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    for (int i = 0; i < n; ++i)
+        if (cache[i].dev == dev && cache[i].k == kernel) return cache[i].cap;
+    int cus = 0, occ = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block, 0) != hipSuccess) occ = 0;
+    (void)hipGetLastError();
+    const int cap = (cus > 0 && occ > 0) ? cus * occ : 0;
+    if (n < 32) cache[n++] = Entry{dev, kernel, cap};
+    return cap;
+}
+// what one launch of the bf16 kernels may hold: the smaller of the three kernels' capacities, at most the design point
+static int persist_capacity() {
+    int cap = P_MAX_WG;
+    const int c1 = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_fwd_bf16_persist_kernel<true>), P_NT);
+    const int c2 = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_fwd_bf16_persist_kernel<false>), P_NT);
+    if (c1 < cap) cap = c1;
+    if (c2 < cap) cap = c2;
+    return cap;
+}
+
 // =============================================================================================== backward (BPTT)
 // Same decomposition and hand-off protocol, time reversed: workgroup (rg, cs) owns rows x 16 hidden units, keeps
 // W_hh^T[its 16 units][all 4H] in registers (4 waves split k: 128 VGPRs each, v_mfma_f32_16x16x32_bf16) and per sub-step
@@ -544,14 +573,30 @@ __global__ __launch_bounds__(P_NT, 2) void lstm_seq_bwd_bf16_persist_kernel(SeqB
     else seq_bwd_body<0>(pb, blockIdx.x - na, smem, s_flag);
 }
 
+// chains per workgroup such that TWO layers of this shape fit `cap` co-resident workgroups (0: they do not)
+static int chains_for(int B, int H, int cap) {
+    const int nC = cdiv(H, P_UN);
+    int R = B / P_SR;                       // row groups (one 32-row chain each) ...
+    int ns = 1;
+    while (R * nC > cap / 2 && ns < P_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }   // ... merged until a layer fits half
+    return (R * nC <= cap / 2 && R <= 64) ? ns : 0;                               // the device (two layers co-run)
+}
+
 int lstm_seq_bwd_bf16_persist_supported(int B, int H, int Kp4) {
-    if (!(H % 8 == 0 && Kp4 % 64 == 0 && Kp4 >= 4 * H && Kp4 <= 64 * Q_KCH)) return 0;
-    return lstm_seq_fwd_bf16_persist_supported(B, H, ((H + 63) / 64) * 64);
+    if (!(B > 0 && B % P_SR == 0 && H % 8 == 0 && Kp4 % 64 == 0 && Kp4 >= 4 * H && Kp4 <= 64 * Q_KCH)) return 0;
+    int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_bwd_bf16_persist_kernel), P_NT);
+    if (cap > P_MAX_WG) cap = P_MAX_WG;
+    return chains_for(B, H, cap);
+}
+static int bwd_capacity() {
+    const int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_bwd_bf16_persist_kernel), P_NT);
+    return cap < P_MAX_WG ? cap : P_MAX_WG;
 }
 
 static int prep_bwd(SeqBwdBf16Args& a) {
     const int ns = lstm_seq_bwd_bf16_persist_supported(a.B, a.H, a.Kp);
-    S2VT_REQUIRE(ns > 0, "lstm_seq_bwd_bf16_persist: unsupported shape (B %% 32, H %% 8, 4H <= 4096, <= 252 workgroups)");
+    S2VT_REQUIRE(ns > 0, "lstm_seq_bwd_bf16_persist: unsupported shape (B %% 32, H %% 8, 4H <= 4096) or two layers of it do not "
+                 "fit the %d workgroups this device keeps resident", bwd_capacity());
     S2VT_REQUIRE(a.T > 0 && a.t1 > a.t0 && a.t0 >= 0 && a.t1 <= a.T && a.wtb && a.dgb && a.stash_dg && a.c_all && a.dc && a.sync && a.err,
                  "lstm_seq_bwd_bf16_persist: bad arguments");
     S2VT_REQUIRE(a.lddgb % 8 == 0 && a.ldwtb % 8 == 0 && a.lddgb >= a.Kp && a.ldwtb >= a.Kp &&
@@ -573,7 +618,8 @@ int lstm_seq_bwd_bf16_persist2(hipStream_t stream, SeqBwdBf16Args a, const SeqBw
         S2VT_REQUIRE(bb.sync != a.sync, "lstm_seq_bwd_bf16_persist: paired layers need their own counters");
     }
     const int na = (a.B / a.RB) * cdiv(a.H, P_UN), nb = b ? (bb.B / bb.RB) * cdiv(bb.H, P_UN) : 0;
-    S2VT_REQUIRE(na + nb <= P_MAX_WG, "lstm_seq_bwd_bf16_persist: %d workgroups would not be co-resident", na + nb);
+    S2VT_REQUIRE(na + nb <= bwd_capacity(), "lstm_seq_bwd_bf16_persist: %d workgroups would not be co-resident (device capacity %d)",
+                 na + nb, bwd_capacity());
     // the hand-off counters count finished timesteps of the whole sequence: zeroed with its first block only (a memset
     // is a 5-us kernel of its own on this stream: 28 of them per train step when every launch zeroed its counters)
     if (a.t1 == a.T) S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
@@ -585,18 +631,15 @@ int lstm_seq_bwd_bf16_persist2(hipStream_t stream, SeqBwdBf16Args a, const SeqBw
 
 int lstm_seq_fwd_bf16_persist_supported(int B, int H, int Kp) {
     if (!(B > 0 && B % P_SR == 0 && Kp % 64 == 0 && Kp >= H && Kp <= 64 * P_KCH)) return 0;
-    const int nC = cdiv(H, P_UN);
-    int R = B / P_SR;                       // row groups (one 32-row chain each) ...
-    int ns = 1;
-    while (R * nC > P_MAX_WG / 2 && ns < P_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }   // ... merged until a layer fits half
-    return (R * nC <= P_MAX_WG / 2 && R <= 64) ? ns : 0;                               // the chip (two layers co-run)
+    return chains_for(B, H, persist_capacity());
 }
 
 size_t lstm_persist_sync_bytes() { return (size_t)64 * P_MAXNS * 32 * sizeof(unsigned int); }   // <= 64 row groups
 
 static int prep(SeqFwdBf16Args& a, const char* who) {
     const int ns = lstm_seq_fwd_bf16_persist_supported(a.B, a.H, a.Kp);
-    S2VT_REQUIRE(ns > 0, "%s: unsupported shape (B %% 32, Kp <= 1024, <= 252 workgroups)", who);
+    S2VT_REQUIRE(ns > 0, "%s: unsupported shape (B %% 32, Kp <= 1024) or two layers of it do not fit the %d workgroups this device "
+                 "keeps resident", who, persist_capacity());
     S2VT_REQUIRE(a.t1 > a.t0 && a.t0 >= 0 && a.wb && a.hb && a.gx_stash && a.c_all && a.sync && a.err && (a.bias || a.n_gx >= a.t1),
                  "%s: bad arguments", who);
     S2VT_REQUIRE(a.ldhb % 8 == 0 && a.ldwb % 8 == 0 && a.ldhb >= a.Kp && a.ldwb >= a.Kp &&
@@ -617,7 +660,8 @@ int lstm_seq_fwd_bf16_persist2(hipStream_t stream, SeqFwdBf16Args a, const SeqFw
         S2VT_REQUIRE(bb.Kp == a.Kp && bb.sync != a.sync, "lstm_seq_fwd_bf16_persist: paired layers need the same Kp and their own counters");
     }
     const int na = (a.B / a.RB) * cdiv(a.H, P_UN), nb = b ? (bb.B / bb.RB) * cdiv(bb.H, P_UN) : 0;
-    S2VT_REQUIRE(na + nb <= P_MAX_WG, "lstm_seq_fwd_bf16_persist: %d workgroups would not be co-resident", na + nb);
+    S2VT_REQUIRE(na + nb <= persist_capacity(), "lstm_seq_fwd_bf16_persist: %d workgroups would not be co-resident (device capacity %d)",
+                 na + nb, persist_capacity());
     // (counters: see the BPTT launcher) zeroed with the sequence's first block
     if (a.t0 == 0) S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
     if (b && bb.t0 == 0) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));

@@ -36,7 +36,7 @@ constexpr int F_HSM = 4 * F_RING;                 // fp32 h_t tile [32][8]
 constexpr int F_MAXNS = 4;
 constexpr int F_CST = F_HSM + F_SR * F_UN * 4;    // c_t of the workgroup's cells, per chain [32][8]
 constexpr int F_LDS = F_CST + F_MAXNS * F_SR * F_UN * 4;
-constexpr int F_MAX_WG = 504;
+constexpr int F_MAX_WG = 512;                     // design point (2 per CU); capped by coresident_capacity() at launch
 constexpr unsigned long long F_SPIN_TICKS = 100000000ull;
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
@@ -246,18 +246,23 @@ __global__ __launch_bounds__(F_NT, 2) void lstm_seq_fwd_f32_persist_kernel(SeqFw
     else seq_fwd_f32_body(pb, blockIdx.x - na, smem, s_flag);
 }
 
-// returns the number of 32-row chains per workgroup (0: unsupported)
+static int fwd_f32_capacity() {
+    const int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_fwd_f32_persist_kernel), F_NT);
+    return cap < F_MAX_WG ? cap : F_MAX_WG;
+}
+// returns the number of 32-row chains per workgroup (0: unsupported, or two layers do not fit the device's resident capacity)
 int lstm_seq_fwd_f32_persist_supported(int B, int H) {
     if (!(B > 0 && B % F_SR == 0 && H % 8 == 0 && H >= 8 && H <= 1024)) return 0;
+    const int cap = fwd_f32_capacity();
     const int nC = H / F_UN;
     int R = B / F_SR, ns = 1;
-    while (R * nC > F_MAX_WG / 2 && ns < F_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }
-    return (R * nC <= F_MAX_WG / 2 && R <= 64) ? ns : 0;
+    while (R * nC > cap / 2 && ns < F_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }
+    return (R * nC <= cap / 2 && R <= 64) ? ns : 0;
 }
 
 static int prep_f(SeqFwdF32Args& a) {
     const int ns = lstm_seq_fwd_f32_persist_supported(a.B, a.H);
-    S2VT_REQUIRE(ns > 0, "lstm_seq_fwd_f32_persist: unsupported shape (B %% 32, H %% 8, H <= 1024, <= 252 workgroups)");
+    S2VT_REQUIRE(ns > 0, "lstm_seq_fwd_f32_persist: unsupported shape (B %% 32, H %% 8, H <= 1024) or it does not fit the device's resident capacity");
     S2VT_REQUIRE(a.t1 > a.t0 && a.t0 >= 0 && a.w_hh && a.h_all && a.gx_stash && a.c_all && a.sync && a.err && (a.bias || a.n_gx >= a.t1),
                  "lstm_seq_fwd_f32_persist: bad arguments");
     S2VT_REQUIRE(a.ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(a.w_hh) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.h_all) & 15) == 0,
@@ -276,7 +281,8 @@ int lstm_seq_fwd_f32_persist2(hipStream_t stream, SeqFwdF32Args a, const SeqFwdF
         S2VT_REQUIRE(bb.sync != a.sync, "lstm_seq_fwd_f32_persist: paired layers need their own counters");
     }
     const int na = (a.B / a.RB) * (a.H / F_UN), nb = b ? (bb.B / bb.RB) * (bb.H / F_UN) : 0;
-    S2VT_REQUIRE(na + nb <= F_MAX_WG, "lstm_seq_fwd_f32_persist: %d workgroups would not be co-resident", na + nb);
+    S2VT_REQUIRE(na + nb <= fwd_f32_capacity(), "lstm_seq_fwd_f32_persist: %d workgroups would not be co-resident (device capacity %d)",
+                 na + nb, fwd_f32_capacity());
     S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
     if (b) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
     hipLaunchKernelGGL(lstm_seq_fwd_f32_persist_kernel, dim3(na + nb), dim3(F_NT), 0, stream, a, bb, na);
@@ -292,7 +298,7 @@ constexpr int G_PLD = 20;                         // row stride of a partial til
 constexpr int G_DGSM = 8 * G_RING;                // fp32 dG_t tile [32][64]
 constexpr int G_DCST = G_DGSM + F_SR * 64 * 4;
 constexpr int G_LDS = G_DCST + F_MAXNS * F_SR * G_UN * 4;
-constexpr int G_MAX_WG = 252;                     // one workgroup per CU
+constexpr int G_MAX_WG = 256;                     // design point: one workgroup per CU; capped by coresident_capacity()
 
 __device__ __forceinline__ void seq_bwd_f32_body(const SeqBwdF32Args& p, const int bid, unsigned char* smem, int& s_flag) {
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -477,17 +483,22 @@ __global__ __launch_bounds__(G_NT) void lstm_seq_bwd_f32_persist_kernel(SeqBwdF3
     else seq_bwd_f32_body(pb, blockIdx.x - na, smem, s_flag);
 }
 
+static int bwd_f32_capacity() {
+    const int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_bwd_f32_persist_kernel), G_NT);
+    return cap < G_MAX_WG ? cap : G_MAX_WG;
+}
 int lstm_seq_bwd_f32_persist_supported(int B, int H) {
     if (!(B > 0 && B % F_SR == 0 && H % 4 == 0 && H >= 4 && 4 * H <= 4096)) return 0;
+    const int cap = bwd_f32_capacity();
     const int nC = (H + G_UN - 1) / G_UN;
     int R = B / F_SR, ns = 1;
-    while (R * nC > G_MAX_WG / 2 && ns < F_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }
-    return (R * nC <= G_MAX_WG / 2 && R <= 64) ? ns : 0;
+    while (R * nC > cap / 2 && ns < F_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }
+    return (R * nC <= cap / 2 && R <= 64) ? ns : 0;
 }
 
 static int prep_g(SeqBwdF32Args& a) {
     const int ns = lstm_seq_bwd_f32_persist_supported(a.B, a.H);
-    S2VT_REQUIRE(ns > 0, "lstm_seq_bwd_f32_persist: unsupported shape (B %% 32, H %% 4, H <= 1024, <= 126 workgroups)");
+    S2VT_REQUIRE(ns > 0, "lstm_seq_bwd_f32_persist: unsupported shape (B %% 32, H %% 4, H <= 1024) or it does not fit the device's resident capacity");
     S2VT_REQUIRE(a.T > 0 && a.t1 > a.t0 && a.t0 >= 0 && a.t1 <= a.T && a.w_hh_t && a.stash_dg && a.c_all && a.dc && a.sync && a.err,
                  "lstm_seq_bwd_f32_persist: bad arguments");
     S2VT_REQUIRE(a.ldwt % 4 == 0 && (reinterpret_cast<uintptr_t>(a.w_hh_t) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.stash_dg) & 15) == 0,
@@ -506,7 +517,8 @@ int lstm_seq_bwd_f32_persist2(hipStream_t stream, SeqBwdF32Args a, const SeqBwdF
         S2VT_REQUIRE(bb.sync != a.sync, "lstm_seq_bwd_f32_persist: paired layers need their own counters");
     }
     const int na = (a.B / a.RB) * cdiv(a.H, G_UN), nb = b ? (bb.B / bb.RB) * cdiv(bb.H, G_UN) : 0;
-    S2VT_REQUIRE(na + nb <= G_MAX_WG, "lstm_seq_bwd_f32_persist: %d workgroups would not be co-resident", na + nb);
+    S2VT_REQUIRE(na + nb <= bwd_f32_capacity(), "lstm_seq_bwd_f32_persist: %d workgroups would not be co-resident (device capacity %d)",
+                 na + nb, bwd_f32_capacity());
     S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
     if (b) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
     hipLaunchKernelGGL(lstm_seq_bwd_f32_persist_kernel, dim3(na + nb), dim3(G_NT), 0, stream, a, bb, na);

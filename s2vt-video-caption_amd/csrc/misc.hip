@@ -334,6 +334,24 @@ int zero_pad_cols_u16(hipStream_t s, unsigned short* p, int64_t rows, int64_t ld
     return 0;
 }
 
+// Test support: `workgroups` workgroups that each hold `lds_bytes` of LDS and spin for `microseconds` of wall clock.  The
+// co-residency tests of the persistent recurrence use it as the foreign kernel (an RCCL kernel on a communication stream,
+// another tenant of the device) that takes LDS away from under a launch whose workgroups wait for each other.
+__global__ __launch_bounds__(64) void occupy_kernel(unsigned long long ticks_100mhz, int lds_bytes) {
+    extern __shared__ unsigned char occ_lds[];
+    if (lds_bytes > 0) occ_lds[(threadIdx.x * 64) % lds_bytes] = (unsigned char)threadIdx.x;      // the allocation is used
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz) __builtin_amdgcn_s_sleep(8);
+}
+int occupy_cus(hipStream_t s, int workgroups, int lds_bytes, long long microseconds) {
+    S2VT_REQUIRE(workgroups > 0 && lds_bytes >= 0 && lds_bytes <= 160 * 1024 && microseconds >= 0 && microseconds <= 5000000,
+                 "s2vt_test_occupy_cus: bad arguments");
+    S2VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(occupy_kernel, dim3(workgroups), dim3(64), lds_bytes, s, (unsigned long long)microseconds * 100ull, lds_bytes);
+    S2VT_LAUNCH_CHECK("occupy_kernel");
+    return 0;
+}
+
 int fill_zero(hipStream_t s, void* p, size_t bytes) {
     if (bytes == 0) return 0;
     S2VT_HIP(hipMemsetAsync(p, 0, bytes, s));

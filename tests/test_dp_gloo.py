@@ -86,8 +86,8 @@ def _plateau_worker(rank, world, port, out_dir):
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from s2vt_video_caption_amd import dp
-    # what train.py does per epoch: rank-local validation sums (different on every rank: each rank sees its own shard and
-    # its own random caption choice), reduced to ONE number that drives ReduceLROnPlateau on every rank
+    # dp.global_mean: rank-local sums (different on every rank) reduced to ONE number that can drive ReduceLROnPlateau on
+    # every rank (train.py itself now validates unsharded and broadcasts rank 0's loss: the single-process value)
     w = torch.nn.Parameter(torch.ones(3))
     opt = torch.optim.Adam([w], lr=1e-2)
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, patience=1)

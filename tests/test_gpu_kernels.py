@@ -1,5 +1,7 @@
 """GPU: each HIP kernel behind the C ABI against a plain fp32 restatement of the same op
 (torch-CPU / the oracle's cell).  Tolerances are absolute fp32 bounds written next to each check."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -300,6 +302,43 @@ def test_beam_step_matches_cell_and_topk(lib):
     assert (tlp - logp.gather(1, rix)).abs().max() < 5e-6
 
 
+def test_beam_step_at_config5_size(lib):
+    """s2vt_beam_step at the size BASELINE configs[4] runs it at - R = 128 samples x beam 5 = 640 rows, H = E = 1000,
+    V = 12000 (the 64-row step-kernel instantiation, the split-K logits GEMM, the 640-row top-20 kernel) - against torch-CPU
+    fp32: cell states, the 20 token ids per row (ascending) and their log-probs.  A token may only differ from torch's
+    top-20 where the 20th and 21st log-probs are closer than the stated log-prob tolerance."""
+    from s2vt_video_caption_amd import ops, synth, capi
+    B, L, F, H, E, V = 128, 80, 4096, 1000, 1000, 12000
+    sd = synth.make_state_dict(V, F, H, E, seed=13, out_scale=16.0)
+    params = [sd[k] for k in capi.PARAM_KEYS]
+    g = torch.Generator().manual_seed(7)
+    R, S = 640, 640
+    row_b = torch.arange(B, dtype=torch.int32).repeat_interleave(5)
+    row_state = torch.randperm(S, generator=g).to(torch.int32)
+    tok = torch.randint(0, V, (R,), generator=g, dtype=torch.int32)
+    vid_h, vid_c = _r(B, H, seed=1, scale=0.5), _r(B, H, seed=2, scale=0.5)
+    word_h, word_c = _r(S, H, seed=3, scale=0.5), _r(S, H, seed=4, scale=0.5)
+    out = ops.beam_step([p.to(DEV) for p in params], (B, L, F, H, E, V), row_b.to(DEV), row_state.to(DEV), tok.to(DEV),
+                        vid_h.to(DEV), vid_c.to(DEV), word_h.to(DEV), word_c.to(DEV))
+    vh, vc, wh, wc, tix, tlp = [t.cpu() for t in out]
+    w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, w_f, b_f, w_o, b_o, emb = params
+    rvh, rvc = orc.lstm_cell(torch.zeros(B, H), vid_h, vid_c, w_ih1, w_hh1, b_ih1, b_hh1)          # S2VTModel.py:208-210
+    x = torch.cat([emb[tok.long()], rvh[row_b.long()]], dim=1)
+    rwh, rwc = orc.lstm_cell(x, word_h[row_state.long()], word_c[row_state.long()], w_ih2, w_hh2, b_ih2, b_hh2)   # :211-212
+    logp = torch.log_softmax(rwh @ w_o.t() + b_o, dim=1)                                           # :213-214
+    assert (vh - rvh).abs().max() < 5e-6 and (vc - rvc).abs().max() < 5e-6
+    assert (wh - rwh).abs().max() < 5e-6 and (wc - rwc).abs().max() < 5e-6
+    top21 = logp.topk(21, dim=1)
+    rix = top21.indices[:, :20].sort(dim=1).values
+    tol = 5e-5                      # |logits| reach ~25 at out_scale 16: 2e-6 relative
+    cut_gap = top21.values[:, 19] - top21.values[:, 20]
+    same = (tix.long() == rix).all(dim=1)
+    assert bool((cut_gap[~same] < tol).all()), (int((~same).sum()), cut_gap[~same])
+    assert int((~same).sum()) <= 2
+    assert (tix[:, 1:] > tix[:, :-1]).all()                                                        # ascending token order
+    assert (tlp - logp.gather(1, tix.long())).abs().max() < tol
+
+
 # ---------------------------------------------------------------------------------------------- config-3 (bf16) kernels
 def _bf16r(x):
     return x.to(torch.bfloat16).to(torch.float64)
@@ -375,6 +414,57 @@ def test_persistent_bf16_recurrence_under_load(lib):
     for a, b in zip(quiet, loaded):
         assert torch.equal(a, b)
     _check_seq_bf16_teacher_forced(*loaded, gx, n_gx, bias, w, T, B, H)
+
+
+_CORESIDENCY_CHILD = r"""
+import ctypes, sys, time
+import torch
+sys.path.insert(0, sys.argv[1])
+from s2vt_video_caption_amd import capi, ops
+hold_us = int(sys.argv[2])
+lib = capi.load()
+DEV = "cuda:0"
+def r(*shape, seed, scale=1.0):
+    return (torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale).to(DEV)
+T, B, H, n_gx = 10, 256, 1000, 5
+a = (r(T * B, 4 * H, seed=1), r(T * B, 4 * H, seed=2), n_gx, r(4 * H, seed=3, scale=0.3), r(4 * H, seed=4, scale=0.3),
+     r(4 * H, H, seed=5, scale=H ** -0.5), r(4 * H, H, seed=6, scale=H ** -0.5), T, B, H)
+quiet = ops.lstm_seq_fwd_bf16_pair(*a, block=5)          # 504 workgroups, two per compute unit
+torch.cuda.synchronize()
+side = torch.cuda.Stream()
+# one workgroup per compute unit holding 84 KB of LDS (two do not fit one CU; 84 + 74 KB leave room for ONE workgroup of
+# the persistent launch beside it instead of two): half of the launch cannot become resident while this kernel runs
+capi.check(lib.s2vt_test_occupy_cus(256, 84 * 1024, hold_us, ctypes.c_void_p(side.cuda_stream)), "occupy")
+time.sleep(0.005)
+t0 = time.time()
+try:
+    loaded = ops.lstm_seq_fwd_bf16_pair(*a, block=5)
+    torch.cuda.synchronize()
+except capi.S2VTHipError as e:
+    print("CLEAN_TIMEOUT after %.2f s: %s" % (time.time() - t0, e))
+    torch.cuda.synchronize()
+    sys.exit(3)
+same = all(torch.equal(x, y) for p, q in zip(quiet, loaded) for x, y in zip(p, q))
+print("COMPLETED in %.2f s, identical=%s" % (time.time() - t0, same))
+sys.exit(0 if same else 4)
+"""
+
+
+@pytest.mark.parametrize("hold_ms,allowed", [(30, (0,)), (2500, (0, 3))])
+def test_persistent_launch_beside_an_lds_holding_kernel(lib, hold_ms, allowed):
+    """A persistent launch whose workgroups cannot all become resident: a foreign kernel (the stand-in for an RCCL kernel
+    on a communication stream) holds 84 KB of LDS on every compute unit, so only one of the two workgroups per CU fits.
+    Short hold (30 ms, far below the 1-s spin bound): the launch must complete with the bits of the quiet run once the
+    foreign kernel has left.  Long hold (2.5 s): either that, or a CLEAN time-out - the library reports S2VT_ERR_TIMEOUT
+    (the child exits 3) - never a hang and never a silently wrong result.  Runs in a child process under a hard time limit,
+    once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _CORESIDENCY_CHILD, root, str(hold_ms * 1000)], capture_output=True, text=True,
+                       timeout=180)
+    print(r.stdout, r.stderr[-2000:])
+    assert r.returncode in allowed, (r.returncode, r.stdout, r.stderr[-2000:])
 
 
 def test_persistent_bf16_recurrence_two_layers_one_launch(lib):

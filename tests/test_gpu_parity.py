@@ -146,8 +146,8 @@ def test_c2_train_with_fp32_persistent_recurrence(lib, golden):
 def test_c4_shard_full_size_against_reference_golden(lib, golden):
     """BASELINE configs[3] per-GPU shard: B=128 at full dims (the batch one rank of the 8-way data-parallel run trains on),
     two fp32 train steps of the reference (tests/golden/c4.npz): loss within 1e-4, logits slice, every gradient by norm,
-    sum and leading entries.  (Greedy / beam ids at B=128 are test_c5_dims_...; the all-reduce above the shard is
-    tests/test_gpu_dp_two_ranks.py.)"""
+    sum and leading entries.  (Greedy / beam ids at B=128: test_c5_full_batch_greedy_and_beam_against_reference_golden;
+    the all-reduce above the shard: tests/test_gpu_dp_two_ranks.py.)"""
     g = golden("c4")
     d, sd, feats, caps, mask = _setup(g, "c4")
     _c2_body(g, d, sd, feats, caps, mask, greedy=False)
@@ -176,14 +176,18 @@ def _c2_body(g, d, sd, feats, caps, mask, greedy=True):
 
 
 @pytest.mark.parametrize("name,cfg,gemm_mode,bound", [("c1long", "c1", 3, 1e-4), ("mid64long", "mid64", 3, 1e-4),
-                                                      ("mid64long", "mid64", 0, 1e-4), ("mid64long", "mid64", 1, 5e-2)])
+                                                      ("mid64long", "mid64", 0, 1e-4), ("mid64long", "mid64", 1, 5e-2),
+                                                      ("c3long", "c3", 1, 2e-2)])
 def test_long_loss_trajectory_against_reference(lib, golden, name, cfg, gemm_mode, bound):
     """FORTY Adam steps on one fixed batch at ten times train.py's learning rate (the reference's loss falls from 4.6 to
     0.007 at c1 dims, from 7.0 to 2.1 at B=64): every step runs on weights that carry the rounding history of all earlier
     steps, Adam's division included.  north_star's bound - training loss within 1e-4 - must hold at EVERY step for the
     fp32 paths (measured 5e-7: B=4 takes the fp32-MFMA driver, B=64 the split-precision two-stream driver, mode 0 its
     fp32-MFMA twin); the bf16 configuration (mode 1, persistent recurrence kernels) stays within 5e-2 of the same fp32
-    trajectory.  Final parameter norms within 1e-4 (fp32) / 2e-2 (bf16) relative."""
+    trajectory.  Final parameter norms within 1e-4 (fp32) / 2e-2 (bf16) relative.
+    c3long: BASELINE configs[2] AT ITS OWN SIZE (B=256, H=E=1000, V=12000): TEN fp32 Adam steps of the reference (lr 1e-3,
+    one batch; train.py:116-127) against the bf16 configuration - persistent recurrence, bf16 batched GEMMs - step by step:
+    |loss - reference| < 2e-2 at every step while the reference's loss moves by far more than that, final norms within 2 %."""
     import utils
     g = golden(name)
     d = synth.CONFIGS[cfg]
@@ -306,6 +310,40 @@ def test_c5_dims_beam_and_greedy_against_reference_golden(lib, golden):
     np.testing.assert_array_equal(ids, g["greedy_ids"])
     for b, s in enumerate(out):
         assert [int(t.item()) for t in s] == [int(x) for x in g["beam_ids"][b] if x >= 0], b
+
+
+def test_c5_full_batch_greedy_and_beam_against_reference_golden(lib, golden):
+    """BASELINE configs[4] AT ITS OWN SIZE: B=128, H=E=1000, V=12000, beam_size 5, depth 30 (S2VTModel.py:56-61,149-240;
+    eval.py:81-96) and the greedy decode of the same 128 samples (S2VTModel.py:82-110), against the reference's own output
+    for every row (tests/golden/c5full.npz, oracle/make_golden.py c5full: 128 per-sample Python beam searches of the
+    reference, ~17 s each).
+    Greedy: all 128 x 79 ids bit-exact; the fixture's weakest top-2 margin is asserted here (>= 1e-3 at its out_scale).
+    Beam: 31 non-cumulative score decisions per sample; among 128 samples some rest on near-ties of two log-probs, which no
+    fp32 implementation with another summation order can be asked to reproduce.  The fixture records every sample's
+    weakest decision gap (oracle replay); rows whose gap is below GATE are excused, everything else must be bit-exact, and
+    the number of excused rows is asserted (<= 2 % of the batch, as is the number of rows that really differ)."""
+    g = golden("c5full")
+    d = dict(synth.CONFIGS["c5"])
+    assert int(g["dims"][0]) == d["B"] == 128
+    seed, scale = int(g["seed"]), float(g["out_scale"])
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed, out_scale=scale)
+    feats, _, _ = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
+    m = _model(d, sd).eval()
+    with torch.no_grad():
+        ids = m(feats.to(DEV), mode="test").cpu().numpy()
+        out = m(feats.to(DEV), mode="beam_search", beam_width=int(g["beam_width"]), max_beam_depth=30)
+    assert float(g["greedy_margin"].min()) >= 1e-3
+    np.testing.assert_array_equal(ids, g["greedy_ids"])
+    GATE = 1e-5                                  # score units at out_scale 16 (|logits| ~ 20: 5e-7 relative)
+    gap = g["beam_gap"]
+    excused = gap < GATE
+    assert int(excused.sum()) <= 2, int(excused.sum())                       # <= 2 % of 128, a property of the fixture
+    differ = []
+    for b, s in enumerate(out):
+        if [int(t.item()) for t in s] != [int(x) for x in g["beam_ids"][b] if x >= 0]:
+            differ.append(b)
+    assert all(excused[b] for b in differ), [(b, float(gap[b])) for b in differ if not excused[b]]
+    assert len(differ) <= 2
 
 
 def test_c3_full_size_bf16_against_reference_golden(lib, golden):
@@ -525,12 +563,30 @@ def test_bf16_mode_config3_arithmetic(lib):
         assert torch.equal(ids_bf16_mode, oids)
 
 
-@pytest.mark.parametrize("cfg,B", [("tiny", 3), ("c2", 64)])
-def test_dp_overlapped_allreduce_single_rank_rccl(lib, cfg, B):
+@pytest.mark.parametrize("cfg,B,gemm_mode", [("tiny", 3, None), ("c2", 64, None), ("c3", 256, 1)])
+def test_dp_overlapped_allreduce_single_rank_rccl(lib, cfg, B, gemm_mode):
     """dp.FlatGradAllReducer.attach(): the backward writes its gradients straight into the flat buffer and the
     all-reduce of each gradient group is issued on a side stream behind s2vt_backward_wait_grads.  With one rank
     (RCCL world_size 1: sum == identity) two steps must leave exactly the parameters of the plain single-GPU loop;
-    the c2 case (B=64) goes through the split-precision / two-lane driver, tiny through the fp32-MFMA one."""
+    the c2 case (B=64) goes through the split-precision / two-lane driver, tiny through the fp32-MFMA one, and the c3 case
+    (B=256, s2vt_set_gemm_mode(1)) through the PERSISTENT bf16 recurrence with the reducer attached - the combination in
+    which "gradient group 0 is final" is re-recorded behind the last persistent BPTT launch, so that no communication
+    kernel starts beside a launch that needs all of its workgroups resident (csrc/api.hip)."""
+    import socket
+    import torch.distributed as dist
+    import utils
+    from s2vt_video_caption_amd import capi, dp
+    if gemm_mode is not None:
+        prev_mode = lib.s2vt_set_gemm_mode(gemm_mode)
+    try:
+        _dp_overlapped_body(lib, cfg, B)
+        capi.check_async_error()
+    finally:
+        if gemm_mode is not None:
+            lib.s2vt_set_gemm_mode(prev_mode)
+
+
+def _dp_overlapped_body(lib, cfg, B):
     import socket
     import torch.distributed as dist
     import utils

@@ -146,3 +146,24 @@ def test_c5_dims_greedy_matches_reference(golden):
     feats, _, _ = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
     ids = orc.greedy_decode(sd, feats)
     np.testing.assert_array_equal(ids.numpy(), g["greedy_ids"])
+
+
+def test_c5_full_batch_fixture_pins_the_oracle(golden):
+    """BASELINE configs[4] at its own size (B=128): the oracle's greedy decode of the whole batch equals the reference's
+    128 x 79 ids, and its beam search (beam 5, depth 30) equals the reference's for the four rows of the fixture whose
+    weakest decision gap is widest (the oracle ran all 128 rows against the reference when the fixture was generated -
+    128/128 equal, recorded in beam_oracle_equal; 50 s of CPU here would buy nothing more)."""
+    g = golden("c5full")
+    d = synth.CONFIGS["c5"]
+    seed, scale = int(g["seed"]), float(g["out_scale"])
+    assert tuple(g["greedy_ids"].shape) == (128, 79) and g["beam_ids"].shape[0] == 128
+    assert bool(g["beam_oracle_equal"].all()) and bool(g["greedy_oracle_equal"].all())
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed, out_scale=scale)
+    feats, _, _ = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
+    ids, marg = orc.greedy_decode(sd, feats, return_margins=True)
+    np.testing.assert_array_equal(ids.numpy(), g["greedy_ids"])
+    np.testing.assert_allclose(marg.numpy(), g["greedy_margin"], atol=2e-4)
+    rows = np.argsort(-g["beam_gap"])[:4]
+    sents = orc.beam_search(sd, feats[rows], beam_width=int(g["beam_width"]), max_depth=30)
+    for r, s in zip(rows, sents):
+        assert s == [int(x) for x in g["beam_ids"][r] if x >= 0], int(r)

@@ -81,9 +81,12 @@ def run(opt):
     train_loader = torch.utils.data.DataLoader(trainset, batch_size=opt.batch_size, shuffle=shuffle and sampler is None,
                                                sampler=sampler, drop_last=world > 1, num_workers=opt.workers,
                                                persistent_workers=opt.workers > 0)
-    # validation is sharded over the ranks too; its loss is reduced over all of them below (one number for every rank)
-    vsampler = torch.utils.data.distributed.DistributedSampler(validset, shuffle=False) if world > 1 else None
-    valid_loader = torch.utils.data.DataLoader(validset, batch_size=opt.batch_size, shuffle=False, sampler=vsampler,
+    # Validation is NOT sharded: every rank runs the whole split in the reference's batch composition (train.py:136-146), so
+    # the number that drives ReduceLROnPlateau / EarlyStopping is the single-process one whatever the world size.  (A
+    # DistributedSampler pads the split with duplicated samples and a mean of per-rank batch means weights the ragged last
+    # batches differently: LR cuts and the stop epoch could then differ from a 1-GPU run.)  The split is small (MSVD: 100
+    # videos); rank 0's value is broadcast so that every replica steps its schedulers on the same bits.
+    valid_loader = torch.utils.data.DataLoader(validset, batch_size=opt.batch_size, shuffle=False,
                                                num_workers=opt.workers, persistent_workers=opt.workers > 0)
     word2ix = trainset.word2ix
 
@@ -125,7 +128,11 @@ def run(opt):
                 probs = model(feats, targets=targets[:, :-1], mode='train')                    # train.py:141-143
                 running += float(criterion(probs, targets, masks))
                 count += 1
-        valid_loss = dp.global_mean(running, count, dev)   # identical on every rank: the schedulers below stay in step
+        valid_loss = running / max(count, 1)                                                   # train.py:147
+        if world > 1:
+            vl = torch.tensor([valid_loss], dtype=torch.float64, device=dev)
+            dist.broadcast(vl, 0)
+            valid_loss = float(vl[0])
         hist["train_loss"].append(train_loss)
         hist["valid_loss"].append(valid_loss)
         if rank == 0:
