@@ -6,12 +6,20 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 
 
 def fam(n):
-    return ("gemm" if ("gemm_f32" in n or "gemm_x3" in n or "gemm_bf16" in n) else "split" if "split_" in n else
-            "splitk" if "splitk" in n else "step_fwd" if "lstm_step_fwd" in n else "step_bwd" if "lstm_step_bwd" in n else
+    return ("gemm" if ("gemm_f32" in n or "gemm_x3" in n or "gemm_bf16" in n or "gemm_b1" in n) else "split" if "split_" in n else
+            "splitk" if "splitk" in n else "step_fwd" if ("lstm_step_fwd" in n or "lstm_seq_fwd" in n) else "step_bwd" if ("lstm_step_bwd" in n or "lstm_seq_bwd" in n) else
             "argmax" if "logits_argmax" in n else "ce" if "ce_" in n else "adam" if "multi_tensor" in n else "other")
 
 
-ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), fam(r["Kernel_Name"]), r["Kernel_Name"], r.get("Queue_Id", "?")) for r in rows)
+def grid(r):
+    try:
+        return "%sx%s/%s" % (int(r.get("Grid_Size_X", 0)) // max(int(r.get("Workgroup_Size_X", 1)), 1),
+                             int(r.get("Grid_Size_Y", 0)) // max(int(r.get("Workgroup_Size_Y", 1)), 1), r.get("Workgroup_Size_X", "?"))
+    except Exception:
+        return "?"
+
+
+ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), fam(r["Kernel_Name"]), r["Kernel_Name"] + " [" + grid(r) + "]", r.get("Queue_Id", "?")) for r in rows)
 ce = [e[0] for e in ev if "ce_row" in e[3]]
 lo, hi = ce[-2], ce[-1]
 ev = [e for e in ev if e[0] >= lo and e[0] < hi]
@@ -41,5 +49,5 @@ if len(sys.argv) > 2:       # dump the sequence of long kernels / gaps
     prev_end = lo
     for s, e, f, n, q in ev:
         if f in ("gemm", "split", "ce", "other", "splitk") or s - prev_end > 20000:
-            print("%9.1f us +%7.1f us gap %6.1f  q%s %s" % ((s - lo) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, q, n[:60]))
+            print("%9.1f us +%7.1f us gap %6.1f  q%s %s" % ((s - lo) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, q, (n[:48] + " " + n[n.rindex("["):]) if "[" in n else n[:60]))
         prev_end = max(prev_end, e)
