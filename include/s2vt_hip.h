@@ -262,6 +262,13 @@ int s2vt_lstm_seq_bwd_persist(int32_t T, int32_t B, int32_t H, const float* w_hh
 int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, const float* w_out, const float* b_out,
                             unsigned long long* packed, void* stream);
 
+/* The same decode step on the bf16 matrix cores with fp32-equivalent arithmetic (three bf16 planes per operand, six plane
+ * products: csrc/argmax_x3.hip) - what s2vt_greedy_decode runs per step when the batch is a multiple of 64.  h and w_out are
+ * split into plane images in `workspace` (s2vt_decode_step_argmax_x3_workspace_bytes) by this call. */
+size_t s2vt_decode_step_argmax_x3_workspace_bytes(int32_t B, int32_t H, int32_t V);
+int s2vt_decode_step_argmax_x3(int32_t B, int32_t H, int32_t V, const float* h, const float* w_out, const float* b_out,
+                               unsigned long long* packed, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Arithmetic of the batched GEMMs inside the whole-path train drivers: 0 = fp32-input MFMA (exact fp32 products),
  * 3 = split precision (3 bf16 planes per operand, six plane products on the bf16 matrix cores: fp32-equivalent to
  * ~2^-23 relative; default when B % 64 == 0, env S2VT_GEMM_MODE).  Returns the previous mode; a negative argument only queries.  Call it between a

@@ -91,6 +91,8 @@ SIGNATURES = {
                                   [c_void_p] * 8 + [c_int32, c_void_p, c_size_t, c_void_p]),
     "s2vt_set_recurrence_mode": (c_int32, [c_int32]),
     "s2vt_decode_step_argmax": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5),
+    "s2vt_decode_step_argmax_x3_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "s2vt_decode_step_argmax_x3": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "s2vt_set_gemm_mode": (c_int32, [c_int32]),
     "s2vt_set_pipeline_block": (c_int32, [c_int32]),
     "s2vt_pipeline_overlaps": (c_int32, []),

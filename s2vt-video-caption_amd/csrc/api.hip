@@ -1149,6 +1149,7 @@ struct DecodeWS {
     size_t gws_floats;
     unsigned long long* packed;
     PB feats, wf, px1, wih1, ph1, wv;      // packed planes (split-precision mode only)
+    PB wo, ph2;                            // out_linear planes (once per call) and the decode step's h_t planes
     size_t bytes;
 };
 static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
@@ -1179,6 +1180,7 @@ static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
         };
         w.feats = mk(B * L, F); w.wf = mk(H, F); w.px1 = mk(L * B, H); w.wih1 = mk(4 * H, H);
         w.ph1 = mk(T * B, H);   w.wv = mk(4 * H, H);
+        w.wo = mk(d.V, H);      w.ph2 = mk(B, H);
     }
     w.bytes = align_up(c.off, 256);
     return w;
@@ -1292,7 +1294,13 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
     if ((rc = fill_zero(st, w.packed, sizeof(unsigned long long) * (size_t)(L - 1) * B))) return rc;
     if ((rc = handoff(st, sx, ev++))) return rc;
     // feature projection + vid_rnn input GEMM                                  S2VTModel.py:54, 64-67
+    static const bool argmax_f32 = getenv("S2VT_ARGMAX_F32") && atoi(getenv("S2VT_ARGMAX_F32")) != 0;   // A/B switch: the fp32-MFMA kernel
+    const bool ax3 = x3 && !argmax_f32;
     if (x3) {
+        if (ax3) {      // W_o planes: constant over the 79 decode steps; h_t planes: written by the decode steps themselves, k padding zeroed here
+            if ((rc = psplit(lb, w.wo, 0, p->out_w, H, ID, V, H))) return rc;
+            if ((rc = fill_zero(sx, w.ph2.p, rows64((size_t)B) * (size_t)w.ph2.ld * sizeof(unsigned short)))) return rc;
+        }
         if ((rc = psplit(lb, w.wv, 0, p->word_w_ih + E, E + H, ID, 4 * H, H))) return rc;
         if ((rc = psplit(la, w.feats, 0, feats, F, ID, B * L, F))) return rc;
         if ((rc = psplit(la, w.wf, 0, p->feat_w, F, ID, H, F))) return rc;
@@ -1355,9 +1363,20 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
                 a.c_prev = t ? w.c2 : nullptr; a.ldc = H;
                 a.h_out = w.h2 + (t & 1) * BH; a.ldho = H;
                 a.c_out = w.c2; a.ldco = H;
+                if (t >= L && ax3) { a.h_planes = w.ph2.p; a.ldhp = w.ph2.ld; }
                 if ((rc = lstm_step_fwd(sx, a))) return rc;
             }
-            if (t >= L) {  // out_linear + argmax (:95-96, :105-106)
+            if (t >= L && ax3) {  // out_linear + argmax (:95-96, :105-106) on the bf16 matrix cores (argmax_x3.hip); the
+                ProfScope ps(sx, K_ARGMAX, 1);      // step kernel above wrote h_t as planes (StepFwdArgs::h_planes)
+                ArgmaxX3Args ax;
+                ax.B = B; ax.V = V; ax.K = w.wo.kpad;
+                ax.W = w.wo.p; ax.ldw = w.wo.ld;
+                ax.Hp = w.ph2.p; ax.ldh = w.ph2.ld;
+                ax.bias = p->out_b;
+                ax.packed = w.packed + (int64_t)(t - L) * B;
+                ax.dbg = 0; ax.stamps = nullptr;
+                if ((rc = logits_argmax_x3(sx, ax))) return rc;
+            } else if (t >= L) {  // the same on the fp32-input MFMA (lstm.hip), for batches the plane path does not take
                 ProfScope ps(sx, K_ARGMAX, 1);
                 LogitsArgmaxArgs la2;
                 la2.B = B; la2.H = H; la2.V = V;
@@ -1771,6 +1790,42 @@ int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, con
 #endif
     ProfScope ps((hipStream_t)stream, K_ARGMAX, 1);
     return logits_argmax((hipStream_t)stream, la);
+}
+
+// The same decode step on the bf16 matrix cores (argmax_x3.hip): both operands are split into blocked 3-plane images in the
+// caller's workspace first (inside s2vt_greedy_decode W_o is split once per call, h_t once per step).
+static size_t argmax_x3_ws_bytes(int B, int H, int V) {
+    const size_t kp = (size_t)pad64(H);
+    return (rows64((size_t)V) + rows64((size_t)B)) * 3 * kp * sizeof(unsigned short) + 512;
+}
+size_t s2vt_decode_step_argmax_x3_workspace_bytes(int32_t B, int32_t H, int32_t V) {
+    return (B > 0 && H > 0 && V > 0) ? argmax_x3_ws_bytes(B, H, V) : 0;
+}
+int s2vt_decode_step_argmax_x3(int32_t B, int32_t H, int32_t V, const float* h, const float* w_out, const float* b_out,
+                               unsigned long long* packed, void* workspace, size_t workspace_bytes, void* stream) {
+    S2VT_REQUIRE(B > 0 && H > 0 && V > 0 && h && w_out && packed && workspace, "s2vt_decode_step_argmax_x3: bad arguments");
+    S2VT_REQUIRE(workspace_bytes >= argmax_x3_ws_bytes(B, H, V), "s2vt_decode_step_argmax_x3: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int kp = pad64(H);
+    Carver c{reinterpret_cast<char*>(workspace), 0, 0};
+    unsigned short* wp = c.take<unsigned short>(rows64((size_t)V) * 3 * kp);
+    unsigned short* hp = c.take<unsigned short>(rows64((size_t)B) * 3 * kp);
+    int rc;
+    if ((rc = split_planes(st, 3, false, w_out, H, ID, V, H, wp, 3 * (int64_t)kp, kp, (int)rows64((size_t)V)))) return rc;
+    if ((rc = split_planes(st, 3, false, h, H, ID, B, H, hp, 3 * (int64_t)kp, kp, (int)rows64((size_t)B)))) return rc;
+    ArgmaxX3Args ax;
+    ax.B = B; ax.V = V; ax.K = kp;
+    ax.W = wp; ax.ldw = 3 * (int64_t)kp;
+    ax.Hp = hp; ax.ldh = 3 * (int64_t)kp;
+    ax.bias = b_out;
+    ax.packed = packed;
+    ax.dbg = 0;
+    ax.stamps = nullptr;
+#ifdef S2VT_EXPERIMENT_STAMPS
+    ax.stamps = g_xstamps;
+#endif
+    ProfScope ps(st, K_ARGMAX, 1);
+    return logits_argmax_x3(st, ax);
 }
 
 int s2vt_set_gemm_mode(int32_t mode) {

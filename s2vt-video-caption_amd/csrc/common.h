@@ -72,4 +72,20 @@ static __device__ __attribute__((aligned(16))) float g_zero4[4] = {0.f, 0.f, 0.f
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f / (1.0f + __expf(2.0f * x)); }
 
+// fp32 -> bf16 (round to nearest even; NaN stays NaN) and the three-plane split x = p0 + p1 + p2 (24 mantissa bits) of the
+// split-precision operands (split.hip, gemm_x3.hip)
+__device__ __forceinline__ unsigned short bf16_rn_bits(float x) {
+    unsigned int u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void split3_bits(float x, unsigned short (&o)[3]) {
+    o[0] = bf16_rn_bits(x);
+    const float r1 = x - __uint_as_float((unsigned int)o[0] << 16);          // exact
+    o[1] = bf16_rn_bits(r1);
+    const float r2 = r1 - __uint_as_float((unsigned int)o[1] << 16);         // exact
+    o[2] = bf16_rn_bits(r2);
+}
+
 }  // namespace s2vt

@@ -50,6 +50,10 @@ struct StepFwdArgs {
     float* h_out2; int64_t ldho2;            // optional second copy (batch-major view)
     float* c_out; int64_t ldco;
     float* stash; int64_t ldst;              // [B,4H] activated gates i,f,g,o (train only)
+    // optional: h_t also as three bf16 planes in the blocked operand layout of gemm_x3.hip / argmax_x3.hip (rows = batch,
+    // k = hidden unit, ld = 3 * kpad elements): the decode step hands its h_t to the plane-path argmax kernel without a
+    // split launch in between.  Columns H..kpad of the image must have been zeroed by the caller.
+    unsigned short* h_planes; int64_t ldhp;
 };
 int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a);
 int lstm_step_fwd2(hipStream_t stream, const StepFwdArgs& a, const StepFwdArgs* b);   // two independent steps, one launch
@@ -171,6 +175,18 @@ struct LogitsArgmaxArgs {
     unsigned long long* stamps;              // timing experiments only (experiment.h); null in the product
 };
 int logits_argmax(hipStream_t stream, const LogitsArgmaxArgs& a);
+
+// ---- argmax_x3.hip: the same decode step on the bf16 matrix cores (operands as blocked 3-plane images, split.hip)
+struct ArgmaxX3Args {
+    int B, V, K;                                    // K: H zero-padded to a multiple of 64
+    const unsigned short* W; int64_t ldw;           // planes of W_o [rows64(V)][3K] (written once per decode call)
+    const unsigned short* Hp; int64_t ldh;          // planes of h_t [rows64(B)][3K] (re-split every step)
+    const float* bias;                              // b_o [V] (nullable)
+    unsigned long long* packed;                     // [B] zero-initialised; atomicMax of (ordered logit << 32 | ~index)
+    int dbg;                                        // timing experiments only (S2VT_AX_DBG): 0 in the product
+    unsigned long long* stamps;                     // timing experiments only (experiment.h); null in the product
+};
+int logits_argmax_x3(hipStream_t stream, const ArgmaxX3Args& a);
 
 // ---- misc.hip
 int add_vectors(hipStream_t s, const float* a, const float* b, float* out, int n);

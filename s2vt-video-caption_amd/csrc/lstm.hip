@@ -300,6 +300,19 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
             st[(int64_t)2 * p.H] = gg;
             st[(int64_t)3 * p.H] = og;
         }
+        if (p.h_planes) {
+            // blocked plane layout (split.hip): element (row b, k = unit, plane pl) at
+            //   (b/64)*(64*ld) + (k/16)*3072 + (pl*2 + (k%16)/8)*512 + (b%64)*8 + k%8.
+            // The 8 threads of a row hold the 8 consecutive units u0..u0+7 (u0 % 8 == 0): their 2-byte stores fill one 16-byte
+            // slot, the rows of the tile consecutive slots of the same piece
+            unsigned short pl3[3];
+            split3_bits(h, pl3);
+            unsigned short* q = p.h_planes + (int64_t)(b >> 6) * (64 * p.ldhp) + (int64_t)(unit >> 4) * 3072 +
+                                ((unit >> 3) & 1) * 512 + (b & 63) * 8 + (unit & 7);
+            q[0] = pl3[0];
+            q[1024] = pl3[1];
+            q[2048] = pl3[2];
+        }
     }
 }
 

@@ -366,37 +366,58 @@ static int persist_capacity() {
 // through LDS and is stored write-through by wave 0, which then drains and signals the chain's counter.
 constexpr int Q_NSLOT = 4;                           // ring slots per wave
 constexpr int Q_RING = Q_NSLOT * 4096;               // 16 KB per wave
-constexpr int Q_RLD = 18;                            // row stride of a partial tile (floats)
-constexpr int Q_DGSM = 4 * Q_RING;                   // bf16 dG_t tile [32][64]
-constexpr int Q_DCST = Q_DGSM + P_SR * 64 * 2;       // fp32 dc of the workgroup's cells, per chain [32][16]
-constexpr int Q_LDS = Q_DCST + P_MAXNS * P_SR * P_UN * 4;
-constexpr int Q_KCH = 64;                            // k chunks of 64 (4H padded <= 4096), 16 per wave
+constexpr int Q_KCH = 64;                            // k chunks of 64 (4H padded <= 4096)
 
-template <int DUMMY>
+// Two shapes of the same kernel (template parameters NW = waves, UN = hidden units per workgroup):
+//   <4, 16>: round 2's - 16 units, 4 waves (16 k chunks each), 76 KB of LDS, TWO workgroups per compute unit;
+//   <8, 32>: 32 units, 8 waves (8 k chunks each, two 16-unit MFMA column tiles per wave), 152 KB of LDS, ONE per compute unit.
+// What a sub-step costs is the dG_{t+1} rows a workgroup takes in (32 rows x 4H bf16 = 258 KB, whatever UN is): with twice the
+// units per workgroup the layer needs half as many workgroups, so half as many bytes cross the L2 -> LDS paths per timestep
+// (B x 4H x 2 B x H/UN: 130 MB per layer timestep at B = 256 with UN = 16 - at the ~16 TB/s all L2s deliver together that
+// alone is 7.8 us - and 65 MB with UN = 32).  The W_hh^T slice of a workgroup (UN x 4H bf16 = 258 KB at UN = 32) still fits the
+// registers of its waves (128 VGPRs each).
+template <int NW, int UN>
+struct BwdCfg {
+    static constexpr int NT = NW * 64;                       // threads
+    static constexpr int CPW = Q_KCH / NW;                   // k chunks per wave
+    static constexpr int NTU = UN / 16;                      // 16-unit MFMA column tiles
+    static constexpr int RLD = UN + 2;                       // row stride of a partial tile (floats)
+    static constexpr int DGSM = NW * Q_RING;                 // bf16 dG_t tile [32][4 * UN]
+    static constexpr int DCST = DGSM + P_SR * 4 * UN * 2;    // fp32 dc of the workgroup's cells, per chain [32][UN]
+    static constexpr int LDS = DCST + P_MAXNS * P_SR * UN * 4;
+    static_assert(CPW * 2 * NTU == 32, "the W_hh^T slice of a wave is 32 bf16x8 registers");
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+template <int NW, int UN>
 __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int bid, unsigned char* smem, int& s_flag) {
+    typedef BwdCfg<NW, UN> C;
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lm = lane & 15, lq = lane >> 4;
     const int H = p.H, B = p.B;
-    const int nC = (H + P_UN - 1) / P_UN;
+    const int nC = (H + UN - 1) / UN;
     const int cs = bid % nC, rg = bid / nC;
-    const int u0 = cs * P_UN, row0 = rg * p.RB;
+    const int u0 = cs * UN, row0 = rg * p.RB;
     const int nch = p.Kp >> 6;
-    const int c0 = wave * 16;                          // this wave's chunks [c0, c0 + 16)
+    const int c0 = wave * C::CPW;                      // this wave's chunks [c0, c0 + CPW)
     const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero4);
 
-    // ---- this wave's quarter of W_hh^T for the workgroup's 16 units: B operand of step (chunk j, half ks)
+    // ---- this wave's k range of W_hh^T for the workgroup's units: B operand of step (chunk j, k half ks, unit tile ut)
     bf16x8 wreg[32];
     {
-        const int unit = u0 + lm;
-        const unsigned short* wrow = p.wtb + (int64_t)unit * p.ldwtb + lq * 8;
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
+        for (int ut = 0; ut < C::NTU; ++ut) {
+            const int unit = u0 + ut * 16 + lm;
+            const unsigned short* wrow = p.wtb + (int64_t)unit * p.ldwtb + lq * 8;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const unsigned short* q = (unit < H && c0 + j < nch) ? wrow + (c0 + j) * 64 + ks * 32 : zero;
-                wreg[j * 2 + ks] = *reinterpret_cast<const bf16x8*>(q);
-            }
+            for (int j = 0; j < C::CPW; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const unsigned short* q = (unit < H && c0 + j < nch) ? wrow + (c0 + j) * 64 + ks * 32 : zero;
+                    wreg[(j * 2 + ks) * C::NTU + ut] = *reinterpret_cast<const bf16x8*>(q);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wreg[i]));
     }
@@ -419,19 +440,19 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
             fa[rt][ks] = lbase + (unsigned)(wave * Q_RING + row * 128 + (((ks * 4 + lq) ^ ((row >> 1) & 7)) * 16));
         }
 
-    // ---- epilogue role: 2 adjacent units of one row per thread
-    const int erow = tid >> 3, eul = (tid & 7) * 2;
+    // ---- epilogue role: 2 adjacent units of one row per thread (32 rows x UN / 2 pairs = NT threads)
+    const int erow = tid / (UN / 2), eul = (tid % (UN / 2)) * 2;
     const int eunit = u0 + eul;
     const bool e_ok = eunit + 1 < H;                   // H % 8 == 0: a pair is valid or not as a whole
-    float* dcst = reinterpret_cast<float*>(smem + Q_DCST);
+    float* dcst = reinterpret_cast<float*>(smem + C::DCST);
     const bool last_block = (p.t1 == p.T);
     for (int s = 0; s < p.NS; ++s) {
         const int b = row0 + s * P_SR + erow;
         f32x2 d0 = {0.f, 0.f};
         if (!last_block && e_ok && b < B) d0 = *reinterpret_cast<const f32x2*>(p.dc + (int64_t)b * H + eunit);
-        *reinterpret_cast<f32x2*>(dcst + (s * P_SR + erow) * P_UN + eul) = d0;
+        *reinterpret_cast<f32x2*>(dcst + (s * P_SR + erow) * UN + eul) = d0;
     }
-    unsigned short* dgsm = reinterpret_cast<unsigned short*>(smem + Q_DGSM);
+    unsigned short* dgsm = reinterpret_cast<unsigned short*>(smem + C::DGSM);
     const int64_t H4 = 4 * (int64_t)H;
 
     for (int t = p.t1 - 1; t >= p.t0; --t) {
@@ -466,9 +487,11 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
                                                            ? p.dh_out + ((int64_t)(t - p.dh_first) * B + eb) * H + eunit : g_zero4);
             }
 
-            f32x4 acc[2];
-            acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc[2][C::NTU];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                for (int ut = 0; ut < C::NTU; ++ut) acc[rt][ut] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (t < p.T - 1) {
                 const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.dgb + ((int64_t)(t + 1) * B + rbase) * p.lddgb);
                 // a chunk index past the end (the 64th of 63) re-reads the last chunk: its W registers are zero, and every
@@ -480,26 +503,35 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
                     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
                         glds16_sc1(sb + voff[i], ring + ((J) % Q_NSLOT) * 4096 + i * 1024);                   \
                 }
+#define Q_MFMA(J, KS, A0, A1)                                                                                \
+                _Pragma("unroll") for (int ut = 0; ut < C::NTU; ++ut) {                                       \
+                    acc[0][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A0, wreg[((J) * 2 + (KS)) * C::NTU + ut], acc[0][ut], 0, 0, 0); \
+                    acc[1][ut] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, wreg[((J) * 2 + (KS)) * C::NTU + ut], acc[1][ut], 0, 0, 0); \
+                }
 #define Q_STEP(J, VM)                                                                                        \
-                if ((J) + 3 < 16) Q_ISSUE((J) + 3)                                                            \
-                asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                        \
-                {                                                                                             \
+                if ((J) < C::CPW) {                                                                           \
+                    if ((J) + 3 < C::CPW) Q_ISSUE((J) + 3)                                                    \
+                    asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                    \
                     bf16x8 a00, a01, a10, a11;                                                                \
                     P_DSR(a00, fa[0][0], ((J) % Q_NSLOT) * 4096); P_DSR(a10, fa[1][0], ((J) % Q_NSLOT) * 4096); \
                     P_DSR(a01, fa[0][1], ((J) % Q_NSLOT) * 4096); P_DSR(a11, fa[1][1], ((J) % Q_NSLOT) * 4096); \
                     asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a00), "+v"(a10));                              \
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a00, wreg[(J) * 2], acc[0], 0, 0, 0);    \
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a10, wreg[(J) * 2], acc[1], 0, 0, 0);    \
+                    Q_MFMA(J, 0, a00, a10)                                                                    \
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01), "+v"(a11));                              \
-                    acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a01, wreg[(J) * 2 + 1], acc[0], 0, 0, 0); \
-                    acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a11, wreg[(J) * 2 + 1], acc[1], 0, 0, 0); \
+                    Q_MFMA(J, 1, a01, a11)                                                                    \
                 }
                 Q_ISSUE(0) Q_ISSUE(1) Q_ISSUE(2)
                 // chunk J landed when at most the requests of the younger chunks (3 of them, fewer at the end) are out
-                Q_STEP(0, 12) Q_STEP(1, 12) Q_STEP(2, 12) Q_STEP(3, 12) Q_STEP(4, 12) Q_STEP(5, 12) Q_STEP(6, 12)
-                Q_STEP(7, 12) Q_STEP(8, 12) Q_STEP(9, 12) Q_STEP(10, 12) Q_STEP(11, 12) Q_STEP(12, 12)
-                Q_STEP(13, 8) Q_STEP(14, 4) Q_STEP(15, 0)
+                if (C::CPW == 16) {
+                    Q_STEP(0, 12) Q_STEP(1, 12) Q_STEP(2, 12) Q_STEP(3, 12) Q_STEP(4, 12) Q_STEP(5, 12) Q_STEP(6, 12)
+                    Q_STEP(7, 12) Q_STEP(8, 12) Q_STEP(9, 12) Q_STEP(10, 12) Q_STEP(11, 12) Q_STEP(12, 12)
+                    Q_STEP(13, 8) Q_STEP(14, 4) Q_STEP(15, 0)
+                } else {
+                    Q_STEP(0, 12) Q_STEP(1, 12) Q_STEP(2, 12) Q_STEP(3, 12) Q_STEP(4, 12)
+                    Q_STEP(5, 8) Q_STEP(6, 4) Q_STEP(7, 0)
+                }
 #undef Q_STEP
+#undef Q_MFMA
 #undef Q_ISSUE
             }
             // partial tile of this wave -> its own (idle) ring
@@ -508,7 +540,9 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) rp[(rt * 16 + 4 * lq + r) * Q_RLD + lm] = acc[rt][r];
+                    for (int ut = 0; ut < C::NTU; ++ut)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rp[(rt * 16 + 4 * lq + r) * C::RLD + ut * 16 + lm] = acc[rt][ut][r];
             }
             P_BARRIER();
 
@@ -516,9 +550,9 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
             {
                 f32x2 dh = dhov;
 #pragma unroll
-                for (int w = 0; w < 4; ++w)
-                    dh += *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(smem + w * Q_RING) + erow * Q_RLD + eul);
-                f32x2* dp = reinterpret_cast<f32x2*>(dcst + (s * P_SR + erow) * P_UN + eul);
+                for (int w = 0; w < NW; ++w)
+                    dh += *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(smem + w * Q_RING) + erow * C::RLD + eul);
+                f32x2* dp = reinterpret_cast<f32x2*>(dcst + (s * P_SR + erow) * UN + eul);
                 const f32x2 dcv = *dp;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
@@ -535,19 +569,23 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
                 *dp = dcn;
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<unsigned int*>(dgsm + erow * 64 + g * 16 + eul) =
+                    *reinterpret_cast<unsigned int*>(dgsm + erow * (4 * UN) + g * UN + eul) =
                         ok ? ((unsigned int)f2bf_rn(dg[g][0]) | ((unsigned int)f2bf_rn(dg[g][1]) << 16)) : 0u;
             }
             P_BARRIER();
-            if (wave == 0) {   // bf16 dG_t tile: 4 gates x (32 rows x 32 B): four 16-byte write-through store instructions
-                const int rl = lane >> 1, part = lane & 1;
-                if (rbase + rl < B && u0 + part * 8 < H) {
-                    unsigned short* drow = p.dgb + ((int64_t)t * B + rbase + rl) * p.lddgb + u0 + part * 8;
+            if (wave == 0) {   // bf16 dG_t tile: 4 gates x (32 rows x UN*2 B): 16-byte write-through stores of ONE wave
+                constexpr int PPR = UN / 8;                                  // 16-byte parts per (row, gate)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(dgsm + rl * 64 + g * 16 + part * 8);
-                        unsigned short* dst = drow + (int64_t)g * H;
-                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                for (int pass = 0; pass < (P_SR * PPR) / 64; ++pass) {
+                    const int idx = pass * 64 + lane, rl = idx / PPR, part = idx % PPR;
+                    if (rbase + rl < B && u0 + part * 8 < H) {
+                        unsigned short* drow = p.dgb + ((int64_t)t * B + rbase + rl) * p.lddgb + u0 + part * 8;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(dgsm + rl * (4 * UN) + g * UN + part * 8);
+                            unsigned short* dst = drow + (int64_t)g * H;
+                            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                        }
                     }
                 }
             }
@@ -566,37 +604,54 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
     }
 }
 
-__global__ __launch_bounds__(P_NT, 2) void lstm_seq_bwd_bf16_persist_kernel(SeqBwdBf16Args pa, SeqBwdBf16Args pb, int na) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[Q_LDS];
+template <int NW, int UN>
+__global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : 1) void lstm_seq_bwd_bf16_persist_kernel(SeqBwdBf16Args pa, SeqBwdBf16Args pb, int na) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[BwdCfg<NW, UN>::LDS];
     __shared__ int s_flag;
-    if ((int)blockIdx.x < na) seq_bwd_body<0>(pa, blockIdx.x, smem, s_flag);
-    else seq_bwd_body<0>(pb, blockIdx.x - na, smem, s_flag);
+    if ((int)blockIdx.x < na) seq_bwd_body<NW, UN>(pa, blockIdx.x, smem, s_flag);
+    else seq_bwd_body<NW, UN>(pb, blockIdx.x - na, smem, s_flag);
 }
 
-// chains per workgroup such that TWO layers of this shape fit `cap` co-resident workgroups (0: they do not)
-static int chains_for(int B, int H, int cap) {
-    const int nC = cdiv(H, P_UN);
+// chains per workgroup such that TWO layers of this shape (un hidden units per workgroup) fit `cap` co-resident workgroups
+// (0: they do not)
+static int chains_for(int B, int H, int cap, int un) {
+    const int nC = cdiv(H, un);
     int R = B / P_SR;                       // row groups (one 32-row chain each) ...
     int ns = 1;
     while (R * nC > cap / 2 && ns < P_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }   // ... merged until a layer fits half
     return (R * nC <= cap / 2 && R <= 64) ? ns : 0;                               // the device (two layers co-run)
 }
 
-int lstm_seq_bwd_bf16_persist_supported(int B, int H, int Kp4) {
-    if (!(B > 0 && B % P_SR == 0 && H % 8 == 0 && Kp4 % 64 == 0 && Kp4 >= 4 * H && Kp4 <= 64 * Q_KCH)) return 0;
-    int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_bwd_bf16_persist_kernel), P_NT);
-    if (cap > P_MAX_WG) cap = P_MAX_WG;
-    return chains_for(B, H, cap);
-}
-static int bwd_capacity() {
-    const int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_bwd_bf16_persist_kernel), P_NT);
-    return cap < P_MAX_WG ? cap : P_MAX_WG;
+// Which shape of the BPTT kernel a layer of (B, H) runs with: 32 units per workgroup (one workgroup per compute unit)
+// wherever two such layers fit the device, else 16 units (two per compute unit).  S2VT_BPTT_UNITS=16|32 pins one (tests,
+// A/B timing).
+struct BwdPlan { int un, ns, cap; };
+static BwdPlan bwd_plan(int B, int H, int Kp4) {
+    BwdPlan none = {0, 0, 0};
+    if (!(B > 0 && B % P_SR == 0 && H % 8 == 0 && Kp4 % 64 == 0 && Kp4 >= 4 * H && Kp4 <= 64 * Q_KCH)) return none;
+    static int pref = -1;
+    if (pref < 0) { const char* e = getenv("S2VT_BPTT_UNITS"); pref = e ? atoi(e) : 0; }
+    if (pref != 16) {
+        int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_bwd_bf16_persist_kernel<8, 32>), 512);
+        if (cap > P_MAX_WG / 2) cap = P_MAX_WG / 2;
+        const int ns = chains_for(B, H, cap, 32);
+        if (ns > 0) return BwdPlan{32, ns, cap};
+    }
+    if (pref != 32) {
+        int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_bwd_bf16_persist_kernel<4, 16>), 256);
+        if (cap > P_MAX_WG) cap = P_MAX_WG;
+        const int ns = chains_for(B, H, cap, 16);
+        if (ns > 0) return BwdPlan{16, ns, cap};
+    }
+    return none;
 }
 
-static int prep_bwd(SeqBwdBf16Args& a) {
-    const int ns = lstm_seq_bwd_bf16_persist_supported(a.B, a.H, a.Kp);
-    S2VT_REQUIRE(ns > 0, "lstm_seq_bwd_bf16_persist: unsupported shape (B %% 32, H %% 8, 4H <= 4096) or two layers of it do not "
-                 "fit the %d workgroups this device keeps resident", bwd_capacity());
+int lstm_seq_bwd_bf16_persist_supported(int B, int H, int Kp4) { return bwd_plan(B, H, Kp4).ns; }
+
+static int prep_bwd(SeqBwdBf16Args& a, BwdPlan* plan) {
+    *plan = bwd_plan(a.B, a.H, a.Kp);
+    S2VT_REQUIRE(plan->ns > 0, "lstm_seq_bwd_bf16_persist: unsupported shape (B %% 32, H %% 8, 4H <= 4096) or two layers of it do not "
+                 "fit the workgroups this device keeps resident");
     S2VT_REQUIRE(a.T > 0 && a.t1 > a.t0 && a.t0 >= 0 && a.t1 <= a.T && a.wtb && a.dgb && a.stash_dg && a.c_all && a.dc && a.sync && a.err,
                  "lstm_seq_bwd_bf16_persist: bad arguments");
     S2VT_REQUIRE(a.lddgb % 8 == 0 && a.ldwtb % 8 == 0 && a.lddgb >= a.Kp && a.ldwtb >= a.Kp &&
@@ -604,34 +659,40 @@ static int prep_bwd(SeqBwdBf16Args& a) {
                      (reinterpret_cast<uintptr_t>(a.stash_dg) & 7) == 0 && (reinterpret_cast<uintptr_t>(a.c_all) & 7) == 0 &&
                      (reinterpret_cast<uintptr_t>(a.dc) & 7) == 0 && (!a.dh_out || (reinterpret_cast<uintptr_t>(a.dh_out) & 7) == 0),
                  "lstm_seq_bwd_bf16_persist: operands must be aligned bf16 rows zero-padded to Kp / 8-byte aligned fp32 rows");
-    a.NS = ns;
-    a.RB = ns * P_SR;
+    a.NS = plan->ns;
+    a.RB = plan->ns * P_SR;
     return 0;
 }
 
 int lstm_seq_bwd_bf16_persist2(hipStream_t stream, SeqBwdBf16Args a, const SeqBwdBf16Args* b) {
     int rc;
-    if ((rc = prep_bwd(a))) return rc;
+    BwdPlan pa, pb;
+    if ((rc = prep_bwd(a, &pa))) return rc;
     SeqBwdBf16Args bb = b ? *b : a;
+    pb = pa;
     if (b) {
-        if ((rc = prep_bwd(bb))) return rc;
+        if ((rc = prep_bwd(bb, &pb))) return rc;
         S2VT_REQUIRE(bb.sync != a.sync, "lstm_seq_bwd_bf16_persist: paired layers need their own counters");
+        S2VT_REQUIRE(pb.un == pa.un, "lstm_seq_bwd_bf16_persist: paired layers must run the same kernel shape");
     }
-    const int na = (a.B / a.RB) * cdiv(a.H, P_UN), nb = b ? (bb.B / bb.RB) * cdiv(bb.H, P_UN) : 0;
-    S2VT_REQUIRE(na + nb <= bwd_capacity(), "lstm_seq_bwd_bf16_persist: %d workgroups would not be co-resident (device capacity %d)",
-                 na + nb, bwd_capacity());
+    const int na = (a.B / a.RB) * cdiv(a.H, pa.un), nb = b ? (bb.B / bb.RB) * cdiv(bb.H, pb.un) : 0;
+    S2VT_REQUIRE(na + nb <= pa.cap, "lstm_seq_bwd_bf16_persist: %d workgroups would not be co-resident (device capacity %d)",
+                 na + nb, pa.cap);
     // the hand-off counters count finished timesteps of the whole sequence: zeroed with its first block only (a memset
     // is a 5-us kernel of its own on this stream: 28 of them per train step when every launch zeroed its counters)
     if (a.t1 == a.T) S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
     if (b && bb.t1 == bb.T) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
-    hipLaunchKernelGGL(lstm_seq_bwd_bf16_persist_kernel, dim3(na + nb), dim3(P_NT), 0, stream, a, bb, na);
+    if (pa.un == 32)
+        hipLaunchKernelGGL((lstm_seq_bwd_bf16_persist_kernel<8, 32>), dim3(na + nb), dim3(512), 0, stream, a, bb, na);
+    else
+        hipLaunchKernelGGL((lstm_seq_bwd_bf16_persist_kernel<4, 16>), dim3(na + nb), dim3(256), 0, stream, a, bb, na);
     S2VT_LAUNCH_CHECK("lstm_seq_bwd_bf16_persist_kernel");
     return 0;
 }
 
 int lstm_seq_fwd_bf16_persist_supported(int B, int H, int Kp) {
     if (!(B > 0 && B % P_SR == 0 && Kp % 64 == 0 && Kp >= H && Kp <= 64 * P_KCH)) return 0;
-    return chains_for(B, H, persist_capacity());
+    return chains_for(B, H, persist_capacity(), P_UN);
 }
 
 size_t lstm_persist_sync_bytes() { return (size_t)64 * P_MAXNS * 32 * sizeof(unsigned int); }   // <= 64 row groups

@@ -162,8 +162,9 @@ def lstm_seq_bwd(T, B, w_hh, dh_out, dh_first, c_all, stash):
     return stash
 
 
-def decode_step_argmax(h, w_out, b_out):
-    """token ids int64 [B] = argmax_v (h·w_out^T + b_out), lowest index on ties."""
+def decode_step_argmax(h, w_out, b_out, planes=False):
+    """token ids int64 [B] = argmax_v (h·w_out^T + b_out), lowest index on ties.  planes: the bf16-matrix-core kernel on
+    3-plane operands (s2vt_decode_step_argmax_x3) instead of the fp32-input MFMA one."""
     lib = capi.load()
     h, w_out = _f32c(h, "h"), _f32c(w_out, "w_out")
     B, H = h.shape
@@ -171,6 +172,12 @@ def decode_step_argmax(h, w_out, b_out):
     dev = h.device
     with torch.cuda.device(dev):
         packed = torch.zeros(B, dtype=torch.int64, device=dev)
+        if planes:
+            nbytes = lib.s2vt_decode_step_argmax_x3_workspace_bytes(B, H, V)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            capi.check(lib.s2vt_decode_step_argmax_x3(B, H, V, _ptr(h), _ptr(w_out), _ptr(b_out), _ptr(packed), _ptr(ws), nbytes,
+                                                      _stream(dev)), "s2vt_decode_step_argmax_x3")
+            return 0xFFFFFFFF - (packed & 0xFFFFFFFF)
         capi.check(lib.s2vt_decode_step_argmax(B, H, V, _ptr(h), _ptr(w_out), _ptr(b_out), _ptr(packed), _stream(dev)),
                    "s2vt_decode_step_argmax")
         return 0xFFFFFFFF - (packed & 0xFFFFFFFF)

@@ -210,8 +210,12 @@ def test_mean_ce_fwd_bwd(lib, B, Lm1, V):
     assert (x.grad.cpu() - lg.grad).abs().max().item() < 1e-7 + 2e-6 / (B * Lm1)
 
 
-def test_decode_argmax_first_max_wins(lib):
-    from s2vt_video_caption_amd import ops
+@pytest.mark.parametrize("planes", [False, True])
+def test_decode_argmax_first_max_wins(lib, planes):
+    from s2vt_video_caption_amd import ops as _ops
+
+    class ops:      # both kernels behind one name: fp32-input MFMA (lstm.hip) / bf16 x 3 planes (argmax_x3.hip)
+        decode_step_argmax = staticmethod(lambda h, w, b: _ops.decode_step_argmax(h, w, b, planes=planes))
     B, H, V = 37, 16, 1000
     h = torch.zeros(B, H); h[:, 0] = 1.0
     w = torch.zeros(V, H)
@@ -234,11 +238,16 @@ def test_decode_argmax_first_max_wins(lib):
     assert torch.equal(ids[safe], ref.argmax(1)[safe])
 
 
-@pytest.mark.parametrize("B,H,V", [(128, 1000, 12000), (100, 72, 1000), (48, 500, 97), (300, 128, 530)])
-def test_decode_argmax_at_decode_sizes(lib, B, H, V):
-    """logits_argmax_kernel at decode sizes (B = 128, V = 12000, H = 1000) and ragged B / V / H: planted ties resolve to the
-    lowest index, random logits give the fp64 argmax wherever the top-2 gap exceeds fp32 rounding."""
-    from s2vt_video_caption_amd import ops
+@pytest.mark.parametrize("planes", [False, True])
+@pytest.mark.parametrize("B,H,V", [(128, 1000, 12000), (100, 72, 1000), (48, 500, 97), (300, 128, 530), (64, 1000, 12000)])
+def test_decode_argmax_at_decode_sizes(lib, B, H, V, planes):
+    """logits_argmax_kernel / logits_argmax_x3_kernel at decode sizes (B = 128, V = 12000, H = 1000) and ragged B / V / H:
+    planted ties resolve to the lowest index, random logits give the fp64 argmax wherever the top-2 gap exceeds fp32
+    rounding."""
+    from s2vt_video_caption_amd import ops as _ops
+
+    class ops:
+        decode_step_argmax = staticmethod(lambda h, w, b: _ops.decode_step_argmax(h, w, b, planes=planes))
     h = torch.zeros(B, H); h[:, 0] = 1.0
     w = torch.zeros(V, H)
     g = torch.Generator().manual_seed(3)

@@ -30,4 +30,4 @@ if decode:
     with torch.no_grad():
         m.eval()(feats, mode="test")
 torch.cuda.synchronize()
-print("loss", float(loss))
+print("loss", float(loss) if iters else None)
