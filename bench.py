@@ -461,13 +461,22 @@ def main():
                 capi.check(lib.s2vt_prof_reset(), "prof_reset")
             am_us = am_ms * 1e3 / max(am_n, 1)
             am_bytes = 4 * V * H + 4 * V + 4 * Bd * H + 8 * Bd         # W_o + b_o + h + packed argmax words
+            am_gflop = 2.0 * Bd * V * H / 1e9
+            planes = (mode != 0) and Bd % 64 == 0                      # the plane-path kernel (csrc/argmax_x3.hip)
+            am_peak = (MFMA_BF16_PEAK_TF / 6.0) if planes else MFMA_F32_PEAK_TF
             decode = {"metric": "greedy-decode captions/sec", "value": round(Bd / ddt, 1), "unit": "captions/s",
                       "batch": Bd, "ms_per_call": round(ddt * 1e3, 2), "n_gpus": 1, "calls_timed": nd,
-                      "roofline_logits_argmax": {"kernel": "logits_argmax_kernel", "bound": "hbm", "achieved": round(am_bytes / (am_us * 1e-6) / 1e9, 1),
-                                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(am_bytes / (am_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                                                 "avg_launch_us": round(am_us, 2), "launches_per_call": am_n,
-                                                 "algorithmic_bytes_per_launch": am_bytes,
-                                                 "gflop_per_launch": round(2.0 * Bd * V * H / 1e9, 2), "traffic": None}}
+                      "roofline_logits_argmax": {
+                          "kernel": "logits_argmax_x3_kernel" if planes else "logits_argmax_kernel", "bound": "mfma",
+                          "achieved": round(am_gflop / (am_us * 1e-6) / 1e3, 1), "peak": round(am_peak, 1), "unit": "TFLOP/s",
+                          "frac": round(am_gflop / (am_us * 1e-6) / 1e3 / am_peak, 4),
+                          "avg_launch_us": round(am_us, 2), "launches_per_call": am_n,
+                          "gflop_per_launch": round(am_gflop, 2), "traffic": None,
+                          "algorithmic_bytes_per_launch": am_bytes,
+                          "hbm_frac_by_algorithmic_bytes": round(am_bytes / (am_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                          "note": ("fp32-equivalent FLOP/s of h W_o^T against the bf16 dense MFMA peak / 6 plane products (3 bf16 planes "
+                                   "per operand); W_o planes are written once per decode call, h_t planes by the decode step kernel"
+                                   if planes else "fp32-input MFMA kernel (batches that are not multiples of 64)")}}
             # ---- beam search (BASELINE configs[4]: B=128, beam_size 5, depth 30)
             with torch.no_grad():
                 model(dfe, mode="beam_search", beam_width=5, max_beam_depth=30)

@@ -18,8 +18,8 @@ for tag in ("fetch", "write", "l2"):
             for key in ("gemm_x3_kernel", "gemm_f32_kernel", "gemm_b1_kernel", "lstm_step_fwd_kernel", "lstm_step_bwd_kernel",
                         "lstm_step_fwd_bf16_kernel", "lstm_step_bwd_bf16_kernel", "lstm_seq_fwd_bf16_persist_kernel",
                         "lstm_seq_bwd_bf16_persist_kernel", "lstm_seq_fwd_f32_persist_kernel", "lstm_seq_bwd_f32_persist_kernel",
-                        "split_dual_kernel", "logits_argmax_kernel", "ce_row_kernel", "ce_bwd_kernel"):
-                if key in n:
+                        "split_dual_kernel", "logits_argmax_x3_kernel", "logits_argmax_kernel", "ce_row_kernel", "ce_bwd_kernel"):
+                if key in n and fam is None:
                     fam = key
             if fam:
                 acc[fam][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -45,6 +45,7 @@ for fam, c in acc.items():
         e["hbm_bytes_per_layer_timestep"] = e["hbm_bytes_per_launch"] * e["launches"] / (318.0 * iters)
     out[fam] = e
 what = sys.argv[2] if len(sys.argv) > 2 else "c2"
-print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum (separate passes), tools/prof_path.py %s "
+commit = os.environ.get("S2VT_COMMIT", "unrecorded")
+print(json.dumps({"commit": commit, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum (separate passes), tools/prof_path.py %s "
                             "(train forward+backward passes), FETCH_SIZE doubled per MI355X_MICROARCH.md" % what,
                   "kernels": out}, indent=1))
