@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define S2VT_ABI_VERSION 4
+#define S2VT_ABI_VERSION 5
 
 /* negative return codes (positive ones are hipError_t values) */
 #define S2VT_ERR_ARG (-1)      /* bad argument */
@@ -143,6 +143,14 @@ int s2vt_mean_ce_forward(int32_t B, int32_t Lm1, int32_t V, const float* logits,
 /* dlogits = (softmax(logits) - onehot(target)) * gout[0] / (B*(L-1)); gout is a device scalar. */
 int s2vt_mean_ce_backward(int32_t B, int32_t Lm1, int32_t V, const float* logits, const int64_t* target,
                           int64_t target_ld, const float* lse, const float* gout, float* dlogits, void* stream);
+
+/* The same gradient handed to s2vt_train_backward WITHOUT an fp32 dlogits tensor (utils.py:22 under loss.backward(), train.py:124):
+ * evaluates (softmax(logits) - onehot(target)) * gout[0] / (B*(L-1)) inside the plane-split pass of the TRAIN workspace the
+ * logits came from - the operand planes and bias-gradient partial sums the backward's first kernel would otherwise produce from
+ * dlogits, bit for bit - and marks the workspace so that the following s2vt_train_backward may be called with dlogits == NULL.
+ * Plane-driver workspaces only (B % 64 == 0, gemm mode 1 or 3); lse from s2vt_mean_ce_forward. */
+int s2vt_mean_ce_backward_fused(const s2vt_dims* d, const float* logits, const int64_t* target, int64_t target_ld, const float* lse,
+                                const float* gout, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------- per-op entry points
  * (the pieces the whole-path drivers are built from; exported for tests, profiling and reuse) */

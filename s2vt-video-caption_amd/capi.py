@@ -33,7 +33,7 @@ class Grads(ctypes.Structure):
 
 
 # name -> (restype, argtypes): every symbol include/s2vt_hip.h declares
-ABI_VERSION = 4          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
+ABI_VERSION = 5          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
 
 SIGNATURES = {
     "s2vt_abi_version": (c_int32, []),
@@ -93,6 +93,8 @@ SIGNATURES = {
     "s2vt_decode_step_argmax": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5),
     "s2vt_decode_step_argmax_x3_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "s2vt_decode_step_argmax_x3": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5 + [c_size_t, c_void_p]),
+    "s2vt_mean_ce_backward_fused": (c_int32, [POINTER(Dims), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
+                                              c_void_p]),
     "s2vt_set_gemm_mode": (c_int32, [c_int32]),
     "s2vt_set_pipeline_block": (c_int32, [c_int32]),
     "s2vt_pipeline_overlaps": (c_int32, []),

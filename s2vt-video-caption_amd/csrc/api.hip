@@ -596,7 +596,7 @@ static SeqBwdF32Args persist_bwd_f32_args(int T, int t0, int t1, int B, int H, c
 // What a forward was run with, keyed by its workspace: s2vt_train_backward must find the same arithmetic mode and
 // recurrence schedule (they decide how the workspace is carved and which images the forward left in it), otherwise it
 // refuses instead of reading a differently carved workspace.  Host-side only.
-struct FwdRecord { s2vt_dims d; int gemm_mode, planes, persist; unsigned long long seq; };
+struct FwdRecord { s2vt_dims d; int gemm_mode, planes, persist; unsigned long long seq; bool dlog_ready; };
 static std::map<const void*, FwdRecord> g_fwd_records;
 static std::mutex g_fwd_mutex;          // autograd runs the backward on its own thread
 static unsigned long long g_fwd_seq = 0;
@@ -608,9 +608,9 @@ static void record_forward(const void* ws, const s2vt_dims& d, bool planes) {
             if (it->second.seq < oldest->second.seq) oldest = it;
         g_fwd_records.erase(oldest);
     }
-    g_fwd_records[ws] = FwdRecord{d, gemm_mode(), planes ? ((gemm_mode() == 1) ? 1 : 3) : 0, persist_mode(), ++g_fwd_seq};
+    g_fwd_records[ws] = FwdRecord{d, gemm_mode(), planes ? ((gemm_mode() == 1) ? 1 : 3) : 0, persist_mode(), ++g_fwd_seq, false};
 }
-static int check_forward_record(const void* ws, const s2vt_dims& d, bool planes) {
+static int check_forward_record(const void* ws, const s2vt_dims& d, bool planes, bool* dlog_ready = nullptr) {
     FwdRecord r;
     {
         std::lock_guard<std::mutex> lock(g_fwd_mutex);
@@ -619,6 +619,7 @@ static int check_forward_record(const void* ws, const s2vt_dims& d, bool planes)
         r = it->second;
         g_fwd_records.erase(it);
     }
+    if (dlog_ready) *dlog_ready = r.dlog_ready;
     S2VT_REQUIRE(memcmp(&r.d, &d, sizeof(d)) == 0, "s2vt_train_backward: dims differ from the forward that filled this workspace");
     const int planes_now = planes ? ((gemm_mode() == 1) ? 1 : 3) : 0;
     S2VT_REQUIRE(r.gemm_mode == gemm_mode() && r.planes == planes_now && r.persist == persist_mode(),
@@ -774,7 +775,7 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
 
 static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
                              const s2vt_grads* g, float* dfeats, const TrainWS& w, const PlaneWS& q, hipStream_t st,
-                             const float* out_mask) {
+                             const float* out_mask, bool dlog_ready) {
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1, R = (L - 1) * B;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
     const int blk = pipe_block();
@@ -792,7 +793,8 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = handoff(st, sx, ev++))) return rc;
     // lane A: dlogits planes in both orientations + its column sums (one read), gradient into the decode-step
     // hidden states (k = V), then word_rnn BPTT.  (W^T planes were written by the forward.)
-    if ((rc = pdual(la, dlogits, V, ID, R, V, &q.dlog, 0, &q.dlogT, 0, w.colsum_c))) return rc;
+    // (dlog_ready: s2vt_mean_ce_backward_fused wrote these planes and partial sums straight from the logits)
+    if (!dlog_ready && (rc = pdual(la, dlogits, V, ID, R, V, &q.dlog, 0, &q.dlogT, 0, w.colsum_c))) return rc;
     if ((rc = handoff(st, sx, ev++))) return rc;
     if ((rc = pgemm(la, R, H, V, q.dlog, 0, 0, q.woT, 0, 0, w.dh2dec, H, perm(L - 1, B), nullptr, false))) return rc;
     if (out_mask && (rc = mul_vectors(st, w.dh2dec, out_mask, w.dh2dec, (int64_t)R * H))) return rc;      // autograd of out_drop
@@ -1038,21 +1040,23 @@ int s2vt_check_async_error(int32_t wait) { return poll_async_error(wait != 0); }
 static int train_backward_impl(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
                                const s2vt_grads* g, float* dfeats, void* workspace, size_t workspace_bytes, void* stream,
                                const float* out_mask) {
-    S2VT_REQUIRE(dims_ok(d) && p && feats && dlogits && g && workspace, "s2vt_train_backward: null/invalid argument");
+    S2VT_REQUIRE(dims_ok(d) && p && feats && g && workspace, "s2vt_train_backward: null/invalid argument");
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
+    bool dlog_ready = false;
     {
         int rc0 = poll_async_error(false);          // flags of the forward, if they have arrived already
         if (rc0) return rc0;
-        if ((rc0 = check_forward_record(workspace, *d, planes_ok(*d)))) return rc0;
+        if ((rc0 = check_forward_record(workspace, *d, planes_ok(*d), &dlog_ready))) return rc0;
     }
+    S2VT_REQUIRE(dlogits || dlog_ready, "s2vt_train_backward: dlogits is null and s2vt_mean_ce_backward_fused has not run on this workspace");
     if (planes_ok(*d)) {
         XP = (gemm_mode() == 1) ? 1 : 3;
         const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
         S2VT_REQUIRE(workspace_bytes >= w.bytes + q.bytes, "s2vt_train_backward: workspace %zu < %zu bytes",
                      workspace_bytes, w.bytes + q.bytes);
-        int rc0 = train_backward_x3(d, p, feats, dlogits, g, dfeats, w, q, st, out_mask);
+        int rc0 = train_backward_x3(d, p, feats, dlogits, g, dfeats, w, q, st, out_mask, dlog_ready);
         return rc0 ? rc0 : post_async_error(st, w.err, 1);
     }
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
@@ -1419,6 +1423,41 @@ int s2vt_mean_ce_backward(int32_t B, int32_t Lm1, int32_t V, const float* logits
     S2VT_REQUIRE(B > 0 && Lm1 > 0 && V > 0, "s2vt_mean_ce_backward: bad dims");
     ProfScope ps((hipStream_t)stream, K_CE, 1);
     return mean_ce_bwd((hipStream_t)stream, logits, (int64_t)B * Lm1, V, target, Lm1, target_ld, lse, gout, dlogits);
+}
+
+// MaskCriterion's backward FUSED into the hand-over to s2vt_train_backward (utils.py:22 under train.py:124): the mean-CE gradient
+// is evaluated from the logits inside the plane-split pass of the train workspace - row planes, transposed planes and the
+// out_linear bias-gradient partial sums of dlogits, exactly what the backward's first kernel would write from an fp32
+// dlogits tensor - so that tensor is never materialised.  Only for workspaces of the plane drivers (B % 64 == 0, gemm mode 1 / 3).
+int s2vt_mean_ce_backward_fused(const s2vt_dims* d, const float* logits, const int64_t* target, int64_t target_ld, const float* lse,
+                                const float* gout, void* workspace, size_t workspace_bytes, void* stream) {
+    S2VT_REQUIRE(dims_ok(d) && logits && target && lse && gout && workspace, "s2vt_mean_ce_backward_fused: null/invalid argument");
+    S2VT_REQUIRE(planes_ok(*d), "s2vt_mean_ce_backward_fused: the workspace is not a plane-driver workspace (B %% 64, gemm mode 1 or 3)");
+    const TrainWS w = carve_train(*d, workspace);
+    {
+        std::lock_guard<std::mutex> lock(g_fwd_mutex);
+        auto it = g_fwd_records.find(workspace);
+        S2VT_REQUIRE(it != g_fwd_records.end() && memcmp(&it->second.d, d, sizeof(*d)) == 0 && it->second.gemm_mode == gemm_mode() &&
+                         !it->second.dlog_ready,
+                     "s2vt_mean_ce_backward_fused: no matching s2vt_train_forward has run on this workspace");
+    }
+    XP = (gemm_mode() == 1) ? 1 : 3;
+    const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
+    S2VT_REQUIRE(workspace_bytes >= w.bytes + q.bytes, "s2vt_mean_ce_backward_fused: workspace %zu < %zu bytes", workspace_bytes, w.bytes + q.bytes);
+    const int R = (d->L - 1) * d->B, V = d->V;
+    CeGradArgs ce;
+    ce.lse = lse; ce.target = target; ce.gout = gout; ce.Lm1 = d->L - 1; ce.ldt = target_ld;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    {
+        ProfScope ps(st, K_CE, 1);
+        if ((rc = split_planes_dual(st, XP, logits, V, ID, R, V, q.dlog.p, q.dlog.ld, q.dlog.kpad, q.dlogT.p + koff(0), q.dlogT.ld, pad64(R),
+                                    w.colsum_c, &ce)))
+            return rc;
+    }
+    std::lock_guard<std::mutex> lock(g_fwd_mutex);
+    g_fwd_records[workspace].dlog_ready = true;
+    return 0;
 }
 
 // ------------------------------------------------------------------ per-op entry points

@@ -25,9 +25,17 @@ int gemm_b1(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
 int split_planes(hipStream_t s, int nplanes, bool transpose, const float* in, int64_t ld, RowMap imap, int rows, int cols,
                  unsigned short* out, int64_t ldo, int kpad, int out_rows_pad);
 
+// optional input transform of split_planes_dual: the input is the logits [B*(L-1)][V] (batch-major rows) and what is split is
+// the mean-CE gradient (exp(logit - lse[r]) - onehot(target)) * gout / rows (ce.hip: ce_bwd_kernel's expression)
+struct CeGradArgs {
+    const float* lse;            // [rows] from mean_ce_fwd
+    const int64_t* target;       // [B][ldt]: row r = b*Lm1 + j reads target[b*ldt + j + 1]
+    const float* gout;           // device scalar
+    int Lm1; int64_t ldt;
+};
 int split_planes_dual(hipStream_t s, int nplanes, const float* in, int64_t ld, RowMap imap, int rows, int cols,
                       unsigned short* out_r, int64_t ldo_r, int kpad_r, unsigned short* out_t, int64_t ldo_t, int kpad_t,
-                      float* colpart);
+                      float* colpart, const CeGradArgs* ce = nullptr);
 int colsum_finish(hipStream_t s, const float* partial, int nchunks, int cols, float* out, bool accumulate);
 
 // ---- lstm.hip

@@ -115,18 +115,43 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const float* in, i
 // partial[tile_row][col] (the bias gradients: summed afterwards in a fixed order by colsum_final_kernel).
 // Tensors that feed both a data-gradient GEMM (row planes) and a weight-gradient GEMM (transposed planes) — dG,
 // dlogits, h, x1, the weights themselves — are read from HBM once.
-template <int NP>
+// CE = true: the input is the LOGITS and the value that is split is the mean-CE gradient (utils.py:22 under loss.backward())
+//   d[r][c] = (exp(logit[r][c] - lse[r]) - [c == target(r)]) * gout / rows
+// - the expression of ce_bwd_kernel (ce.hip), evaluated here so that the fp32 dlogits tensor is never written and re-read
+// (971 MB each way at B = 256): the planes and the bias-gradient partial sums come out bit for bit as from the two-kernel route.
+template <int NP, bool CE>
 __global__ __launch_bounds__(256) void split_dual_kernel(const float* in, int64_t ld, RowMap imap, int rows, int cols,
                                                          unsigned short* out_r, int64_t ldo_r, int kpad_r,
                                                          unsigned short* out_t, int64_t ldo_t, int kpad_t,
-                                                         float* colpart) {
+                                                         float* colpart, CeGradArgs ce) {
     __shared__ float tile[64][65];
+    __shared__ float row_lse[64];          // CE only: per tile row, fetched once (the index arithmetic of a target is two
+    __shared__ int row_tgt[64];            // integer divisions: per ELEMENT they cost more than the split itself)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float ce_scale = 0.f;
+    if (CE) {
+        if (threadIdx.x < 64) {
+            const int r = r0 + (int)threadIdx.x;
+            int64_t t = 0;
+            float l = 0.f;
+            if (r < rows) {
+                t = ce.target[(int64_t)(r / ce.Lm1) * ce.ldt + (r % ce.Lm1) + 1];
+                t = t < 0 ? 0 : (t >= cols ? cols - 1 : t);
+                l = ce.lse[r];
+            }
+            row_tgt[threadIdx.x] = (int)t;
+            row_lse[threadIdx.x] = l;
+        }
+        ce_scale = ce.gout[0] / (float)rows;
+        __syncthreads();
+    }
     for (int i = ty; i < 64; i += 4) {
         const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < rows && c < cols) ? in[(int64_t)map_row(imap, r) * ld + c] : 0.f;
+        float x = (r < rows && c < cols) ? in[(int64_t)map_row(imap, r) * ld + c] : 0.f;
+        if (CE && r < rows && c < cols) x = (expf(x - row_lse[i]) - (c == row_tgt[i] ? 1.f : 0.f)) * ce_scale;
+        tile[i][tx] = x;
     }
     __syncthreads();
     if (colpart && threadIdx.x < 64 && c0 + (int)threadIdx.x < cols) {
@@ -183,7 +208,7 @@ __global__ __launch_bounds__(256) void split_dual_kernel(const float* in, int64_
 // as kpad_r <= 64*cdiv(cols,64) and kpad_t <= 64*cdiv(rows,64), which holds for kpad = pad64(.).
 int split_planes_dual(hipStream_t s, int nplanes, const float* in, int64_t ld, RowMap imap, int rows, int cols,
                       unsigned short* out_r, int64_t ldo_r, int kpad_r, unsigned short* out_t, int64_t ldo_t, int kpad_t,
-                      float* colpart) {
+                      float* colpart, const CeGradArgs* ce) {
     S2VT_REQUIRE(nplanes == 1 || nplanes == 3, "split_planes_dual: planes must be 1 or 3");
     if (rows <= 0 || cols <= 0) return 0;
     S2VT_REQUIRE(!out_r || (kpad_r % 64 == 0 && kpad_r >= cols && kpad_r <= 64 * cdiv(cols, 64) && ldo_r >= (int64_t)nplanes * kpad_r),
@@ -191,12 +216,22 @@ int split_planes_dual(hipStream_t s, int nplanes, const float* in, int64_t ld, R
     S2VT_REQUIRE(!out_t || (kpad_t % 64 == 0 && kpad_t >= rows && kpad_t <= 64 * cdiv(rows, 64) && ldo_t >= (int64_t)nplanes * kpad_t),
                  "split_planes_dual: bad transposed-plane geometry");
     const dim3 grid(cdiv(cols, 64), cdiv(rows, 64));
-    if (nplanes == 3)
-        hipLaunchKernelGGL((split_dual_kernel<3>), grid, dim3(256), 0, s, in, ld, imap, rows, cols, out_r, ldo_r, kpad_r, out_t,
-                           ldo_t, kpad_t, colpart);
+    CeGradArgs none = {nullptr, nullptr, nullptr, 1, 0};
+    if (ce) {
+        S2VT_REQUIRE(ce->lse && ce->target && ce->gout && ce->Lm1 > 0 && imap.idx == nullptr && imap.inner == 0,
+                     "split_planes_dual: bad CE-gradient arguments");
+        if (nplanes == 3)
+            hipLaunchKernelGGL((split_dual_kernel<3, true>), grid, dim3(256), 0, s, in, ld, imap, rows, cols, out_r, ldo_r, kpad_r,
+                               out_t, ldo_t, kpad_t, colpart, *ce);
+        else
+            hipLaunchKernelGGL((split_dual_kernel<1, true>), grid, dim3(256), 0, s, in, ld, imap, rows, cols, out_r, ldo_r, kpad_r,
+                               out_t, ldo_t, kpad_t, colpart, *ce);
+    } else if (nplanes == 3)
+        hipLaunchKernelGGL((split_dual_kernel<3, false>), grid, dim3(256), 0, s, in, ld, imap, rows, cols, out_r, ldo_r, kpad_r, out_t,
+                           ldo_t, kpad_t, colpart, none);
     else
-        hipLaunchKernelGGL((split_dual_kernel<1>), grid, dim3(256), 0, s, in, ld, imap, rows, cols, out_r, ldo_r, kpad_r, out_t,
-                           ldo_t, kpad_t, colpart);
+        hipLaunchKernelGGL((split_dual_kernel<1, false>), grid, dim3(256), 0, s, in, ld, imap, rows, cols, out_r, ldo_r, kpad_r, out_t,
+                           ldo_t, kpad_t, colpart, none);
     S2VT_LAUNCH_CHECK("split_dual_kernel");
     return 0;
 }
@@ -214,8 +249,8 @@ int split_planes(hipStream_t s, int nplanes, bool transpose, const float* in, in
     if (rows <= 0 || cols <= 0) return 0;
     if (nplanes == 3) {     // blocked layout: the tiled kernel writes whole 1-KB pieces in either orientation
         S2VT_REQUIRE(kpad >= (transpose ? rows : cols) && out_rows_pad >= (transpose ? cols : rows), "split_planes: output too small");
-        return transpose ? split_planes_dual(s, 3, in, ld, imap, rows, cols, nullptr, 0, 0, out, ldo, kpad, nullptr)
-                         : split_planes_dual(s, 3, in, ld, imap, rows, cols, out, ldo, kpad, nullptr, 0, 0, nullptr);
+        return transpose ? split_planes_dual(s, 3, in, ld, imap, rows, cols, nullptr, 0, 0, out, ldo, kpad, nullptr, nullptr)
+                         : split_planes_dual(s, 3, in, ld, imap, rows, cols, out, ldo, kpad, nullptr, 0, 0, nullptr, nullptr);
     }
     if (!transpose) {
         S2VT_REQUIRE(kpad >= cols && out_rows_pad >= rows, "split_planes: output too small");

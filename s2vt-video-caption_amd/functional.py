@@ -13,6 +13,12 @@ import torch
 from . import capi
 
 
+# MaskCriterion's backward fused into the model's (s2vt_mean_ce_backward_fused): on by default wherever the plane drivers run
+# (B % 64 == 0).  The fp32 dlogits tensor then never exists - `logits.retain_grad()` / tensor hooks on the logits see a stride-0
+# tensor of zeros; set this to False to get the materialised gradient back.
+FUSE_CE = True
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -85,6 +91,8 @@ class _TrainForward(torch.autograd.Function):
         ctx.out_mask = out_mask
         ctx.save_for_backward(feats, *params)
         ctx.ws, ctx.d, ctx.used, ctx.grad_sink = ws, d, False, grad_sink
+        ctx.dlog_fused = False      # set by _MeanCE.backward when it wrote the dlogits planes into ctx.ws itself (fused CE)
+        ctx.fusable = bool(FUSE_CE and d.B % 64 == 0 and lib.s2vt_set_gemm_mode(-1) in (1, 3))
         return logits
 
     @staticmethod
@@ -97,7 +105,15 @@ class _TrainForward(torch.autograd.Function):
         feats, *params = ctx.saved_tensors
         d, ws = ctx.d, ctx.ws
         dev = feats.device
-        dlogits = _f32c(dlogits, "dlogits")
+        if ctx.dlog_fused:
+            # the criterion's backward already turned the logits into dlogits operand planes inside ctx.ws; what arrives here is
+            # its stride-0 placeholder.  Anything else means a second consumer of the logits added its own gradient
+            if not (dlogits.dim() == 3 and all(st == 0 for st in dlogits.stride())):
+                raise capi.S2VTHipError("the logits of this forward fed the fused MaskCriterion backward AND another consumer: set "
+                                        "s2vt_video_caption_amd.functional.FUSE_CE = False to materialise dlogits")
+            dlogits = None
+        else:
+            dlogits = _f32c(dlogits, "dlogits")
         with torch.cuda.device(dev):
             sink = ctx.grad_sink
             if sink is not None:
@@ -187,6 +203,11 @@ class _MeanCE(torch.autograd.Function):
             capi.check(lib.s2vt_mean_ce_forward(B, Lm1, V, _ptr(logits), _ptr(target), target.stride(0), _ptr(lse),
                                                 _ptr(rowloss), _ptr(loss), _stream(dev)), "s2vt_mean_ce_forward")
         ctx.save_for_backward(logits, target, lse)
+        # fused route: the logits come straight from S2VT.forward(mode='train') on the plane drivers -> the backward below
+        # writes the dlogits operand planes into that forward's workspace instead of a [B, L-1, V] fp32 tensor
+        node = getattr(logits, "grad_fn", None)
+        ctx.train_node = node if (node is not None and getattr(node, "fusable", False) and getattr(node, "ws", None) is not None
+                                  and logits.is_contiguous()) else None
         return loss.reshape(())
 
     @staticmethod
@@ -196,6 +217,14 @@ class _MeanCE(torch.autograd.Function):
         B, Lm1, V = logits.shape
         dev = logits.device
         gout = _f32c(gout.reshape(1), "grad_output")
+        node = ctx.train_node
+        if node is not None and node.ws is not None and not node.used and not node.dlog_fused and FUSE_CE:
+            with torch.cuda.device(dev):
+                capi.check(lib.s2vt_mean_ce_backward_fused(ctypes.byref(node.d), _ptr(logits), _ptr(target), target.stride(0),
+                                                           _ptr(lse), _ptr(gout), _ptr(node.ws), node.ws.numel(), _stream(dev)),
+                           "s2vt_mean_ce_backward_fused")
+            node.dlog_fused = True
+            return torch.zeros((), dtype=logits.dtype, device=dev).expand(B, Lm1, V), None     # placeholder: no memory behind it
         with torch.cuda.device(dev):
             dlogits = torch.empty_like(logits)
             capi.check(lib.s2vt_mean_ce_backward(B, Lm1, V, _ptr(logits), _ptr(target), target.stride(0), _ptr(lse),

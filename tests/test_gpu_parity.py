@@ -616,3 +616,48 @@ def _dp_overlapped_body(lib, cfg, B):
     assert losses == ref_losses
     for k in ref_sd:
         assert torch.equal(got[k], ref_sd[k]), k
+
+
+@pytest.mark.parametrize("cfg,gemm_mode", [("mid64", 3), ("mid64", 1), ("c2", 3)])
+def test_fused_criterion_backward_is_bitwise_the_unfused_one(lib, cfg, gemm_mode):
+    """MaskCriterion's backward fused into the model's (s2vt_mean_ce_backward_fused: the mean-CE gradient is evaluated from the
+    logits inside the plane-split pass of the train workspace, no fp32 dlogits tensor; utils.py:22 under train.py:124) against the
+    two-kernel route (functional.FUSE_CE = False): loss and all 13 gradients of two Adam steps bit for bit, in the split-precision
+    and in the bf16 configuration.  And the guard: a second consumer of the logits is refused, not silently dropped."""
+    import utils
+    from s2vt_video_caption_amd import capi, functional
+    d = synth.CONFIGS[cfg]
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=21)
+    feats, caps, mask = (t.to(DEV) for t in synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=22))
+    crit = utils.MaskCriterion()
+    prev = lib.s2vt_set_gemm_mode(gemm_mode)
+    keep = functional.FUSE_CE
+    try:
+        def run(fuse):
+            functional.FUSE_CE = fuse
+            m = _model(d, sd)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+            out = []
+            for _ in range(2):
+                opt.zero_grad()
+                logits = m(feats, targets=caps[:, :-1], mode="train")
+                loss = crit(logits, caps, mask)
+                loss.backward()
+                out.append((float(loss), {n: p.grad.clone() for n, p in m.named_parameters()}))
+                opt.step()
+            capi.check_async_error()
+            return out
+        ref, got = run(False), run(True)
+        for (l0, g0), (l1, g1) in zip(ref, got):
+            assert l0 == l1
+            for n in g0:
+                assert torch.equal(g0[n], g1[n]), n
+        functional.FUSE_CE = True
+        m = _model(d, sd)
+        logits = m(feats, targets=caps[:, :-1], mode="train")
+        loss = crit(logits, caps, mask) + 1e-3 * logits.sum()          # a second consumer of the logits
+        with pytest.raises(capi.S2VTHipError):
+            loss.backward()
+    finally:
+        functional.FUSE_CE = keep
+        lib.s2vt_set_gemm_mode(prev)
