@@ -566,6 +566,9 @@ static SeqBwdBf16Args seq_bwd_bf16_args(int T, int t0, int t1, int B, int H, con
     a.dh_out = dh_out; a.dh_first = dh_first;
     a.stash_dg = stash_dg; a.c_all = c_all; a.dc = dc;
     a.sync = sync; a.err = err;
+#ifdef S2VT_EXPERIMENT_STAMPS
+    a.stamps = g_xstamps; a.stamp_block = g_xstamp_block;
+#endif
     return a;
 }
 static SeqFwdF32Args persist_fwd_f32_args(int t0, int t1, int B, int H, float* gx_stash, int n_gx, const float* bias,

@@ -144,6 +144,7 @@ struct SeqBwdBf16Args {
     float* dc;                                      // [B][H] dL/dc carried between launches (ignored when t1 == T)
     unsigned int* sync; int* err;
     int RB, NS;                                     // set by the launcher
+    unsigned long long* stamps; int stamp_block;    // timing experiments only (experiment.h); null in the product
 };
 int lstm_seq_bwd_bf16_persist_supported(int B, int H, int Kp4);
 int lstm_seq_bwd_bf16_persist2(hipStream_t stream, SeqBwdBf16Args a, const SeqBwdBf16Args* b);

@@ -73,9 +73,14 @@ __device__ __forceinline__ unsigned short f2bf_rn(float x) {
 __device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float fast_tanh(float x) { return 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * x)) - 1.0f; }
 
+#ifdef S2VT_EXPERIMENT_PLAIN_LOADS      // timing experiment only (tools/bench_bptt_stamps.py): what would hand-off loads without sc1 cost?
+#define P_LOAD_AUX 0
+#else
+#define P_LOAD_AUX 16 /* sc1 */
+#endif
 __device__ __forceinline__ void glds16_sc1(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 16 /* sc1 */);
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, P_LOAD_AUX);
 }
 
 // one lane waits for *cnt >= target (relaxed agent-scope = sc1 loads); false on time-out
@@ -462,6 +467,8 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
             unsigned int* cnt = p.sync + (rg * P_MAXNS + s) * 32;
             const int done = p.t1 - 1 - t;             // steps of this launch already finished by every workgroup?
             const int done_all = p.T - 1 - t;          // ... and of the whole sequence: the counters run on from launch to launch
+            const int xrec = (bid == p.stamp_block) ? done * p.NS + s : -1;
+            XSTAMP(p.stamps, xrec, 0);
             if (done > 0) {
                 if (tid == 0) {
                     const bool ok = spin_until(cnt, (unsigned int)(nC * done_all));
@@ -472,6 +479,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
                 if (s_flag == 0) return;
             }
 
+            XSTAMP(p.stamps, xrec, 1);
             // epilogue operands requested now (older than every ring request: they never hold a counted wait up)
             const int eb = rbase + erow;
             const bool ok = e_ok && eb < B;
@@ -521,6 +529,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
                     Q_MFMA(J, 1, a01, a11)                                                                    \
                 }
                 Q_ISSUE(0) Q_ISSUE(1) Q_ISSUE(2)
+                XSTAMP(p.stamps, xrec, 2);
                 // chunk J landed when at most the requests of the younger chunks (3 of them, fewer at the end) are out
                 if (C::CPW == 16) {
                     Q_STEP(0, 12) Q_STEP(1, 12) Q_STEP(2, 12) Q_STEP(3, 12) Q_STEP(4, 12) Q_STEP(5, 12) Q_STEP(6, 12)
@@ -534,6 +543,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
 #undef Q_MFMA
 #undef Q_ISSUE
             }
+            XSTAMP(p.stamps, xrec, 3);
             // partial tile of this wave -> its own (idle) ring
             {
                 float* rp = reinterpret_cast<float*>(ring);
@@ -545,6 +555,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
                         for (int r = 0; r < 4; ++r) rp[(rt * 16 + 4 * lq + r) * C::RLD + ut * 16 + lm] = acc[rt][ut][r];
             }
             P_BARRIER();
+            XSTAMP(p.stamps, xrec, 4);
 
             f32x2 dg[4], dcn;
             {
@@ -572,7 +583,9 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
                     *reinterpret_cast<unsigned int*>(dgsm + erow * (4 * UN) + g * UN + eul) =
                         ok ? ((unsigned int)f2bf_rn(dg[g][0]) | ((unsigned int)f2bf_rn(dg[g][1]) << 16)) : 0u;
             }
+            XSTAMP(p.stamps, xrec, 5);
             P_BARRIER();
+            XSTAMP(p.stamps, xrec, 6);
             if (wave == 0) {   // bf16 dG_t tile: 4 gates x (32 rows x UN*2 B): 16-byte write-through stores of ONE wave
                 constexpr int PPR = UN / 8;                                  // 16-byte parts per (row, gate)
 #pragma unroll
@@ -595,10 +608,13 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
                 for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x2*>(st + (int64_t)g * H) = dg[g];
                 if (t == p.t0) *reinterpret_cast<f32x2*>(p.dc + (int64_t)eb * H + eunit) = dcn;      // carried to the next launch
             }
+            XSTAMP(p.stamps, xrec, 7);
             if (wave == 0) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                XSTAMP(p.stamps, xrec, 8);
                 if (lane == 0) __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            XSTAMP(p.stamps, xrec, 9);
             P_BARRIER();       // rings (partial tiles), dG tile and dc state are free again
         }
     }
