@@ -149,6 +149,8 @@ def main():
                     help="only the timed steps and the live kernel timing of the headline workload (no B=128 shard, isolated "
                          "pass, decode, beam, config3, CPU baseline): what tools/profile_round2.sh runs under rocprofv3, so "
                          "that the kernel-stats averages are those of the headline workload alone")
+    ap.add_argument("--graphs", type=int, default=None, choices=[0, 1],
+                    help="s2vt_set_graph_mode: replay the forward / backward launch sequences as hipGraphs (default: the library's, off)")
     ap.add_argument("--selftest-launcher", action="store_true",
                     help="CPU-only rehearsal of the N-rank launch path (gloo); prints n_gpus")
     args = ap.parse_args()
@@ -182,6 +184,8 @@ def main():
     if args.gemm_mode is not None:
         lib.s2vt_set_gemm_mode(args.gemm_mode)
     mode = lib.s2vt_set_gemm_mode(-1)
+    if args.graphs is not None:
+        lib.s2vt_set_graph_mode(args.graphs)
 
     L, F, H, E, V = 80, 4096, 1000, 1000, 12000
     B = args.batch
@@ -574,7 +578,7 @@ def main():
                                     "hidden=embed=1000, vocab=12000, fp32, Adam" % (B, world)),
                        "global_batch": B * world, "frames": L, "parallelism": "dp%d" % world},
             "final_loss": round(final_loss, 6), "host_enqueue_ms_per_step": round(host_ms, 3),
-            "host_enqueue_ms_by_phase": host_phases,
+            "host_enqueue_ms_by_phase": host_phases, "graph_mode": int(lib.s2vt_set_graph_mode(-1)),
             "pipeline_streams_overlap": int(lib.s2vt_pipeline_overlaps()),
             "roofline": roofline,
             "roofline_min": roofline_min,

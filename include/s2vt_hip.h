@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define S2VT_ABI_VERSION 5
+#define S2VT_ABI_VERSION 6
 
 /* negative return codes (positive ones are hipError_t values) */
 #define S2VT_ERR_ARG (-1)      /* bad argument */
@@ -291,6 +291,15 @@ int s2vt_set_pipeline_block(int32_t steps);
  * one-time calibration at the first pipelined call: HIP may map two streams onto one hardware queue), 0 if no
  * candidate overlapped (the drivers still run, serially), -1 before the first pipelined call. */
 int s2vt_pipeline_overlaps(void);
+
+/* Launch-sequence capture: with on = 1 (or env S2VT_GRAPH=1) the ~350 launches of an s2vt_train_forward / s2vt_train_backward
+ * call of the plane drivers (B % 64 == 0) are captured into a hipGraph the second time the same argument set - every pointer,
+ * dims, modes, stream - is seen, and replayed with one hipGraphLaunch from then on (at most 8 executables are cached).  Results
+ * are those of the eager sequence bit for bit; s2vt_backward_wait_grads(0 / 1) then completes with the whole backward (the
+ * gradient all-reduce follows it instead of overlapping it).  Off by default; not active while s2vt_prof_enable(1).  Returns the previous
+ * setting; a negative argument only queries.  s2vt_graph_stats: graphs captured / launches replayed so far. */
+int s2vt_set_graph_mode(int32_t on);
+int s2vt_graph_stats(int64_t* captures, int64_t* replays);
 
 /* Test support (tests/test_gpu_kernels.py: co-residency of the persistent recurrence): launches `workgroups` one-wave
  * workgroups that each hold `lds_bytes` (<= 160 KB) of LDS and spin for `microseconds` (<= 5 s) - a stand-in for a foreign

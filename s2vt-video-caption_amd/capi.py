@@ -33,7 +33,7 @@ class Grads(ctypes.Structure):
 
 
 # name -> (restype, argtypes): every symbol include/s2vt_hip.h declares
-ABI_VERSION = 5          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
+ABI_VERSION = 6          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
 
 SIGNATURES = {
     "s2vt_abi_version": (c_int32, []),
@@ -99,6 +99,8 @@ SIGNATURES = {
     "s2vt_set_pipeline_block": (c_int32, [c_int32]),
     "s2vt_pipeline_overlaps": (c_int32, []),
     "s2vt_test_occupy_cus": (c_int32, [c_int32, c_int32, c_int64, c_void_p]),
+    "s2vt_set_graph_mode": (c_int32, [c_int32]),
+    "s2vt_graph_stats": (c_int32, [POINTER(c_int64), POINTER(c_int64)]),
     "s2vt_prof_enable": (c_int32, [c_int32]),
     "s2vt_prof_read": (c_int32, [c_int32, POINTER(c_double), POINTER(c_int64)]),
     "s2vt_prof_read_busy": (c_int32, [c_int32, POINTER(c_double)]),

@@ -121,6 +121,71 @@ struct ProfScope {
     }
 };
 
+// ------------------------------------------------------------------ launch-sequence capture (hipGraph)
+// s2vt_set_graph_mode(1) / S2VT_GRAPH=1: the launch sequence of a whole-path call of the plane drivers (s2vt_train_forward /
+// s2vt_train_backward at B % 64 == 0: ~350 launches on two streams each) is captured ONCE per distinct argument set - every
+// pointer, the dims, the modes and the stream are the key - and replayed with one hipGraphLaunch afterwards.  The first
+// sighting of a key runs eagerly (lazy initialisations: side-stream calibration, occupancy queries, event pool), the second
+// is captured, later ones replay.  A training loop presents the same pointers every step once torch's caching allocator
+// has settled (parameters, the flat gradient buffer and the batch ring are fixed; workspace and logits come back at the same
+// addresses); a key that never repeats simply stays eager.  Not used while live timing is on (the event brackets are not
+// capturable).  At most 8 executables are kept (least recently used goes).
+static int g_graph_mode = -1;
+static bool g_capturing = false;
+struct GraphEntry { hipGraphExec_t exec; unsigned long long last_use; int seen; };
+static std::map<std::vector<uint64_t>, GraphEntry> g_graphs;
+static std::mutex g_graph_mutex;
+static unsigned long long g_graph_tick = 0, g_graph_replays = 0, g_graph_captures = 0;
+static bool graph_on() {
+    if (g_graph_mode < 0) { const char* e = getenv("S2VT_GRAPH"); g_graph_mode = (e && atoi(e) != 0) ? 1 : 0; }
+    return g_graph_mode == 1 && !g_prof;
+}
+template <typename F>
+static int run_graphed(hipStream_t st, const std::vector<uint64_t>& key, F&& enqueue, bool* graphed = nullptr) {
+    if (graphed) *graphed = false;
+    if (!graph_on()) return enqueue(st);
+    std::lock_guard<std::mutex> lock(g_graph_mutex);
+    GraphEntry& e = g_graphs[key];                  // (a new key: exec = nullptr, seen = 0)
+    e.last_use = ++g_graph_tick;
+    if (e.exec) {
+        ++g_graph_replays;
+        S2VT_HIP(hipGraphLaunch(e.exec, st));
+        if (graphed) *graphed = true;
+        return 0;
+    }
+    if (++e.seen < 2) return enqueue(st);
+    if (graphed) *graphed = true;
+    // captured on a stream of the library's own: the caller's may be the legacy default stream (torch's current stream
+    // unless told otherwise), which cannot be captured; graph nodes carry no stream identity
+    static hipStream_t cap = nullptr;
+    if (!cap) S2VT_HIP(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    S2VT_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeRelaxed));
+    g_capturing = true;
+    const int rc = enqueue(cap);
+    g_capturing = false;
+    const hipError_t ce = hipStreamEndCapture(cap, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    S2VT_HIP(ce);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    S2VT_HIP(ie);
+    e.exec = exec;
+    ++g_graph_captures;
+    while (g_graphs.size() > 8) {
+        auto oldest = g_graphs.end();
+        for (auto it = g_graphs.begin(); it != g_graphs.end(); ++it)
+            if (&it->second != &e && (oldest == g_graphs.end() || it->second.last_use < oldest->second.last_use)) oldest = it;
+        if (oldest == g_graphs.end()) break;
+        if (oldest->second.exec) (void)hipGraphExecDestroy(oldest->second.exec);
+        g_graphs.erase(oldest);
+    }
+    S2VT_HIP(hipGraphLaunch(exec, st));
+    return 0;
+}
+static void key_ptr(std::vector<uint64_t>& k, const void* p) { k.push_back((uint64_t)(uintptr_t)p); }
+
 static const RowMap ID = {nullptr, 0, 0};
 static inline RowMap perm(int inner, int outer) { return RowMap{nullptr, inner, outer}; }
 static inline RowMap gather(const int32_t* idx) { return RowMap{idx, 0, 0}; }
@@ -400,7 +465,10 @@ static hipEvent_t g_grad_ev[2] = {nullptr, nullptr};
 static bool g_grad_ev_set[2] = {false, false};
 static int grads_ready(int group, hipStream_t s) {
     if (!g_grad_ev[group]) S2VT_HIP(hipEventCreateWithFlags(&g_grad_ev[group], hipEventDisableTiming));
-    S2VT_HIP(hipEventRecord(g_grad_ev[group], s));
+    // inside a capture nothing is recorded (an event recorded on a capturing stream cannot be waited for from outside, and
+    // external event-record nodes are refused by this runtime): the backward driver records both groups behind the graph
+    // launch instead, so under s2vt_set_graph_mode(1) the gradient all-reduce follows the backward rather than overlapping it
+    if (!g_capturing) S2VT_HIP(hipEventRecord(g_grad_ev[group], s));
     g_grad_ev_set[group] = true;
     return 0;
 }
@@ -975,7 +1043,17 @@ static int train_forward_impl(const s2vt_dims* d, const s2vt_params* p, const fl
         const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
         S2VT_REQUIRE(workspace_bytes >= w.bytes + q.bytes, "s2vt_train_forward: workspace %zu < %zu bytes",
                      workspace_bytes, w.bytes + q.bytes);
-        int rc0 = train_forward_x3(d, p, feats, targets, targets_ld, logits, w, q, st, out_mask);
+        std::vector<uint64_t> key;
+        if (graph_on()) {
+            key.reserve(32);
+            key.push_back(0xF0);
+            for (int v : {d->B, d->L, d->F, d->H, d->E, d->V, gemm_mode(), persist_mode(), pipe_block()}) key.push_back((uint64_t)v);
+            const float* const* pp = reinterpret_cast<const float* const*>(p);
+            for (size_t i = 0; i < sizeof(s2vt_params) / sizeof(void*); ++i) key_ptr(key, pp[i]);
+            key_ptr(key, feats); key_ptr(key, targets); key.push_back((uint64_t)targets_ld); key_ptr(key, logits);
+            key_ptr(key, workspace); key_ptr(key, out_mask); key_ptr(key, st);
+        }
+        int rc0 = run_graphed(st, key, [&](hipStream_t s_) { return train_forward_x3(d, p, feats, targets, targets_ld, logits, w, q, s_, out_mask); });
         return rc0 ? rc0 : post_async_error(st, w.err);
     }
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
@@ -1059,7 +1137,25 @@ static int train_backward_impl(const s2vt_dims* d, const s2vt_params* p, const f
         const PlaneWS q = carve_planes(*d, reinterpret_cast<char*>(workspace) + w.bytes);
         S2VT_REQUIRE(workspace_bytes >= w.bytes + q.bytes, "s2vt_train_backward: workspace %zu < %zu bytes",
                      workspace_bytes, w.bytes + q.bytes);
-        int rc0 = train_backward_x3(d, p, feats, dlogits, g, dfeats, w, q, st, out_mask, dlog_ready);
+        std::vector<uint64_t> key;
+        if (graph_on()) {
+            key.reserve(48);
+            key.push_back(0xB0 + (dlog_ready ? 1 : 0));
+            for (int v : {d->B, d->L, d->F, d->H, d->E, d->V, gemm_mode(), persist_mode(), pipe_block()}) key.push_back((uint64_t)v);
+            const float* const* pp = reinterpret_cast<const float* const*>(p);
+            for (size_t i = 0; i < sizeof(s2vt_params) / sizeof(void*); ++i) key_ptr(key, pp[i]);
+            float* const* gp = reinterpret_cast<float* const*>(g);
+            for (size_t i = 0; i < sizeof(s2vt_grads) / sizeof(void*); ++i) key_ptr(key, gp[i]);
+            key_ptr(key, feats); key_ptr(key, dlogits); key_ptr(key, dfeats); key_ptr(key, workspace); key_ptr(key, out_mask);
+            key_ptr(key, st);
+        }
+        bool graphed = false;
+        int rc0 = run_graphed(st, key, [&](hipStream_t s_) { return train_backward_x3(d, p, feats, dlogits, g, dfeats, w, q, s_, out_mask, dlog_ready); },
+                              &graphed);
+        if (!rc0 && graphed) {       // (see grads_ready) every gradient group is final behind the graph
+            if ((rc0 = grads_ready(0, st))) return rc0;
+            if ((rc0 = grads_ready(1, st))) return rc0;
+        }
         return rc0 ? rc0 : post_async_error(st, w.err, 1);
     }
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
@@ -1877,6 +1973,17 @@ int s2vt_set_gemm_mode(int32_t mode) {
 }
 
 int s2vt_pipeline_overlaps(void) { return g_side_overlaps; }
+
+int s2vt_set_graph_mode(int32_t on) {
+    const int prev = graph_on() || g_graph_mode == 1 ? 1 : 0;
+    if (on >= 0) g_graph_mode = on ? 1 : 0;
+    return prev;
+}
+int s2vt_graph_stats(int64_t* captures, int64_t* replays) {
+    if (captures) *captures = (int64_t)g_graph_captures;
+    if (replays) *replays = (int64_t)g_graph_replays;
+    return 0;
+}
 
 int s2vt_test_occupy_cus(int32_t workgroups, int32_t lds_bytes, int64_t microseconds, void* stream) {
     return occupy_cus((hipStream_t)stream, workgroups, lds_bytes, microseconds);

@@ -661,3 +661,41 @@ def test_fused_criterion_backward_is_bitwise_the_unfused_one(lib, cfg, gemm_mode
     finally:
         functional.FUSE_CE = keep
         lib.s2vt_set_gemm_mode(prev)
+
+
+@pytest.mark.parametrize("cfg,gemm_mode", [("mid64", 3), ("c2", 3), ("mid64", 1)])
+def test_graph_replay_is_bitwise_the_eager_sequence(lib, cfg, gemm_mode):
+    """s2vt_set_graph_mode(1): the launch sequences of s2vt_train_forward / s2vt_train_backward are captured into hipGraphs
+    (second sighting of an argument set) and replayed; six Adam steps of train.py:116-127 must leave exactly the losses and
+    parameters of the eager loop, and the later steps must really have been replays (the caching allocator hands the workspace,
+    logits and gradient tensors back at the same addresses once the loop has settled)."""
+    import ctypes
+    import utils
+    from s2vt_video_caption_amd import capi, dp
+    d = synth.CONFIGS[cfg]
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=31)
+    feats, caps, mask = (t.to(DEV) for t in synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=32))
+    crit = utils.MaskCriterion()
+    prev = lib.s2vt_set_gemm_mode(gemm_mode)
+    try:
+        def run(graphs):
+            lib.s2vt_set_graph_mode(1 if graphs else 0)
+            m = _model(d, sd)
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+            losses = [float(dp.train_step(m, crit, opt, feats, caps, mask, None)) for _ in range(6)]
+            torch.cuda.synchronize()
+            capi.check_async_error()
+            return losses, {k: v.detach().clone() for k, v in m.state_dict().items()}
+        c0, r0 = ctypes.c_int64(0), ctypes.c_int64(0)
+        lib.s2vt_graph_stats(ctypes.byref(c0), ctypes.byref(r0))
+        ref_losses, ref_sd = run(False)
+        losses, got = run(True)
+        c1, r1 = ctypes.c_int64(0), ctypes.c_int64(0)
+        lib.s2vt_graph_stats(ctypes.byref(c1), ctypes.byref(r1))
+        assert losses == ref_losses
+        for k in ref_sd:
+            assert torch.equal(got[k], ref_sd[k]), k
+        assert c1.value - c0.value >= 2 and r1.value - r0.value >= 4, (c1.value - c0.value, r1.value - r0.value)
+    finally:
+        lib.s2vt_set_graph_mode(0)
+        lib.s2vt_set_gemm_mode(prev)
