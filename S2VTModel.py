@@ -81,7 +81,7 @@ class S2VT(nn.Module):
                 out_mask = keep.transpose(0, 1).reshape((self.length - 1) * B, H).contiguous()
             return _F.train_forward(feats, targets, params, grad_sink=_F.grad_sink_for(self), out_mask=out_mask)
         elif mode == 'test':
-            return _F.greedy_decode(feats, params, self.sos_ix)
+            return _F.greedy_decode(feats, params, self.sos_ix, owner=self)
         return None                                        # the reference falls through for unknown modes
 
     @staticmethod

@@ -33,7 +33,7 @@ class Grads(ctypes.Structure):
 
 
 # name -> (restype, argtypes): every symbol include/s2vt_hip.h declares
-ABI_VERSION = 6          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
+ABI_VERSION = 7          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
 
 SIGNATURES = {
     "s2vt_abi_version": (c_int32, []),
@@ -54,6 +54,9 @@ SIGNATURES = {
     "s2vt_decode_workspace_bytes": (c_size_t, [POINTER(Dims)]),
     "s2vt_greedy_decode": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_int32, c_void_p, c_void_p, c_size_t,
                                      c_void_p]),
+    "s2vt_decode_cache_bytes": (c_size_t, [POINTER(Dims)]),
+    "s2vt_greedy_decode_cached": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_int32, c_void_p, c_void_p, c_size_t,
+                                            c_void_p, c_size_t, c_int32, c_void_p]),
     "s2vt_mean_ce_forward": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
     "s2vt_mean_ce_backward": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,

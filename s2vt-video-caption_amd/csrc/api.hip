@@ -1251,8 +1251,9 @@ struct DecodeWS {
     float *bsum1, *bsum2, *x1, *gx1, *h1, *c1, *gx2, *h2, *c2, *gws_a, *gws_b;
     size_t gws_floats;
     unsigned long long* packed;
-    PB feats, wf, px1, wih1, ph1, wv;      // packed planes (split-precision mode only)
-    PB wo, ph2;                            // out_linear planes (once per call) and the decode step's h_t planes
+    PB feats, px1, ph1;                    // packed planes of per-call activations (split-precision mode only)
+    PB ph2;                                // the decode step's h_t planes
+    PB embp, wep;                          // planes of the embedding table and of W_e (scratch of the per-token table's GEMM)
     size_t bytes;
 };
 static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
@@ -1281,12 +1282,36 @@ static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
             b.p = c.take<unsigned short>(rows64(rows) * (size_t)b.ld);
             return b;
         };
-        w.feats = mk(B * L, F); w.wf = mk(H, F); w.px1 = mk(L * B, H); w.wih1 = mk(4 * H, H);
-        w.ph1 = mk(T * B, H);   w.wv = mk(4 * H, H);
-        w.wo = mk(d.V, H);      w.ph2 = mk(B, H);
+        w.feats = mk(B * L, F); w.px1 = mk(L * B, H);
+        w.ph1 = mk(T * B, H);   w.ph2 = mk(B, H);
+        w.embp = mk(d.V, d.E);  w.wep = mk(4 * H, d.E);
     }
     w.bytes = align_up(c.off, 256);
     return w;
+}
+// What a decode derives from the WEIGHTS alone (plane images of W_f, W_ih1, W_v, W_o and the per-token gate-input table):
+// carved from the tail of the call's workspace, or from a caller-kept cache that outlives the call (s2vt_greedy_decode_cached)
+struct DecodeConst { PB wf, wih1, wv, wo; float* gtab; size_t bytes; };
+static DecodeConst carve_decode_const(const s2vt_dims& d, void* base) {
+    const size_t F = d.F, H = d.H;
+    Carver c{reinterpret_cast<char*>(base), 0, 0};
+    DecodeConst k;
+    k.gtab = nullptr;
+    k.wf = k.wih1 = k.wv = k.wo = PB{nullptr, 0, 0};
+    if (planes_ok(d)) {
+        XP = 3;
+        auto mk = [&](size_t rows, size_t kk) {
+            PB b;
+            b.kpad = pad64((int)kk);
+            b.ld = (int64_t)XP * b.kpad;
+            b.p = c.take<unsigned short>(rows64(rows) * (size_t)b.ld);
+            return b;
+        };
+        k.wf = mk(H, F); k.wih1 = mk(4 * H, H); k.wv = mk(4 * H, H); k.wo = mk(d.V, H);
+        k.gtab = c.take<float>((size_t)d.V * 4 * H);
+    }
+    k.bytes = align_up(c.off, 256);
+    return k;
 }
 
 // ---------------------------------------------------------------------------------- batched beam-search depth
@@ -1371,15 +1396,40 @@ int s2vt_backward_wait_grads(int32_t group, void* stream) {
 
 size_t s2vt_decode_workspace_bytes(const s2vt_dims* d) {
     if (!dims_ok(d)) return 0;
-    return carve_decode(*d, nullptr).bytes;
+    return carve_decode(*d, nullptr).bytes + carve_decode_const(*d, nullptr).bytes;
+}
+size_t s2vt_decode_cache_bytes(const s2vt_dims* d) {
+    if (!dims_ok(d)) return 0;
+    return carve_decode_const(*d, nullptr).bytes;
 }
 
+static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
+                              void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, bool cache_valid,
+                              void* stream);
 int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
                        void* workspace, size_t workspace_bytes, void* stream) {
+    return greedy_decode_impl(d, p, feats, sos_ix, ids, workspace, workspace_bytes, nullptr, 0, false, stream);
+}
+int s2vt_greedy_decode_cached(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
+                              void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, int32_t cache_valid,
+                              void* stream) {
+    S2VT_REQUIRE(cache, "s2vt_greedy_decode_cached: null cache");
+    return greedy_decode_impl(d, p, feats, sos_ix, ids, workspace, workspace_bytes, cache, cache_bytes, cache_valid != 0, stream);
+}
+static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
+                              void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, bool cache_valid,
+                              void* stream) {
     S2VT_REQUIRE(dims_ok(d) && p && feats && ids && workspace, "s2vt_greedy_decode: null/invalid argument");
     S2VT_REQUIRE(sos_ix >= 0 && sos_ix < d->V, "s2vt_greedy_decode: sos_ix %d outside vocabulary %d", sos_ix, d->V);
     const DecodeWS w = carve_decode(*d, workspace);
-    S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_greedy_decode: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+    const size_t kbytes = carve_decode_const(*d, nullptr).bytes;
+    S2VT_REQUIRE(workspace_bytes >= w.bytes + (cache ? 0 : kbytes), "s2vt_greedy_decode: workspace %zu < %zu bytes", workspace_bytes,
+                 w.bytes + (cache ? 0 : kbytes));
+    S2VT_REQUIRE(!cache || cache_bytes >= kbytes, "s2vt_greedy_decode_cached: cache %zu < %zu bytes", cache_bytes, kbytes);
+    // weight-derived images: in the caller's cache (filled by a call with cache_valid == 0, reused while the weights stand) or
+    // behind the per-call part of the workspace (rebuilt by every call)
+    const DecodeConst kc = carve_decode_const(*d, cache ? cache : reinterpret_cast<char*>(workspace) + w.bytes);
+    const bool fill = !(cache && cache_valid);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
@@ -1399,18 +1449,27 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
     // feature projection + vid_rnn input GEMM                                  S2VTModel.py:54, 64-67
     static const bool argmax_f32 = getenv("S2VT_ARGMAX_F32") && atoi(getenv("S2VT_ARGMAX_F32")) != 0;   // A/B switch: the fp32-MFMA kernel
     const bool ax3 = x3 && !argmax_f32;
+    // per-token gate-input table instead of the embedding K segment of the 79 decode steps: one V x 4H x E GEMM (0.5 ms at
+    // V = 12000) against B x 4H x E of MFMA work and E/(E+H) of the operand traffic in EVERY decode step - pays from B ~ 64
+    static const bool no_tab = getenv("S2VT_DECODE_TABLE") && atoi(getenv("S2VT_DECODE_TABLE")) == 0;
+    const bool use_tab = x3 && !no_tab;
     if (x3) {
         if (ax3) {      // W_o planes: constant over the 79 decode steps; h_t planes: written by the decode steps themselves, k padding zeroed here
-            if ((rc = psplit(lb, w.wo, 0, p->out_w, H, ID, V, H))) return rc;
+            if (fill && (rc = psplit(lb, kc.wo, 0, p->out_w, H, ID, V, H))) return rc;
             if ((rc = fill_zero(sx, w.ph2.p, rows64((size_t)B) * (size_t)w.ph2.ld * sizeof(unsigned short)))) return rc;
         }
-        if ((rc = psplit(lb, w.wv, 0, p->word_w_ih + E, E + H, ID, 4 * H, H))) return rc;
+        if (use_tab && fill) {  // gtab[v] = Emb[v]·W_e^T for every token (S2VTModel.py:90-93,100-103: embedding + the embed columns of word_rnn's W_ih)
+            if ((rc = psplit(lb, w.embp, 0, p->emb_w, E, ID, V, E))) return rc;
+            if ((rc = psplit(lb, w.wep, 0, p->word_w_ih, E + H, ID, 4 * H, E))) return rc;
+            if ((rc = pgemm(lb, V, 4 * H, E, w.embp, 0, 0, w.wep, 0, 0, kc.gtab, 4 * H, ID, nullptr, false))) return rc;
+        }
+        if (fill && (rc = psplit(lb, kc.wv, 0, p->word_w_ih + E, E + H, ID, 4 * H, H))) return rc;
         if ((rc = psplit(la, w.feats, 0, feats, F, ID, B * L, F))) return rc;
-        if ((rc = psplit(la, w.wf, 0, p->feat_w, F, ID, H, F))) return rc;
-        if ((rc = psplit(la, w.wih1, 0, p->vid_w_ih, H, ID, 4 * H, H))) return rc;
-        if ((rc = pgemm(la, B * L, H, F, w.feats, 0, 0, w.wf, 0, 0, w.x1, H, perm(L, B), p->feat_b, false))) return rc;
+        if (fill && (rc = psplit(la, kc.wf, 0, p->feat_w, F, ID, H, F))) return rc;
+        if (fill && (rc = psplit(la, kc.wih1, 0, p->vid_w_ih, H, ID, 4 * H, H))) return rc;
+        if ((rc = pgemm(la, B * L, H, F, w.feats, 0, 0, kc.wf, 0, 0, w.x1, H, perm(L, B), p->feat_b, false))) return rc;
         if ((rc = psplit(la, w.px1, 0, w.x1, H, ID, L * B, H))) return rc;
-        if ((rc = pgemm(la, L * B, 4 * H, H, w.px1, 0, 0, w.wih1, 0, 0, w.gx1, 4 * H, ID, w.bsum1, false))) return rc;
+        if ((rc = pgemm(la, L * B, 4 * H, H, w.px1, 0, 0, kc.wih1, 0, 0, w.gx1, 4 * H, ID, w.bsum1, false))) return rc;
     } else {
         if ((rc = lgemm(la, true, true, B * L, H, F, feats, F, ID, p->feat_w, F, ID, w.x1, H, perm(L, B), p->feat_b, false)))
             return rc;
@@ -1440,7 +1499,7 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
         // lane B: vid_out half of the word_rnn gate input for this block (+ biases)
         if (x3) {
             if ((rc = psplit(lb, w.ph1, t0 * B, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H))) return rc;
-            if ((rc = pgemm(lb, (t1 - t0) * B, 4 * H, H, w.ph1, t0 * B, 0, w.wv, 0, 0, w.gx2 + t0 * B4H, 4 * H, ID, w.bsum2,
+            if ((rc = pgemm(lb, (t1 - t0) * B, 4 * H, H, w.ph1, t0 * B, 0, kc.wv, 0, 0, w.gx2 + t0 * B4H, 4 * H, ID, w.bsum2,
                             false)))
                 return rc;
         } else {
@@ -1457,8 +1516,12 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
                 a.h_prev = t ? w.h2 + ((t - 1) & 1) * BH : nullptr; a.ldh = H;
                 a.w_hh = p->word_w_hh; a.ldw = H;
                 if (t >= L) {
-                    a.x2 = p->emb_w; a.ldx2 = E; a.K2 = E;
-                    a.w2 = p->word_w_ih; a.ldw2 = E + H;
+                    if (use_tab) {
+                        a.gx_tab = kc.gtab; a.ldtab = 4 * (int64_t)H;
+                    } else {
+                        a.x2 = p->emb_w; a.ldx2 = E; a.K2 = E;
+                        a.w2 = p->word_w_ih; a.ldw2 = E + H;
+                    }
                     a.tok_packed = (t > L) ? w.packed + (int64_t)(t - L - 1) * B : nullptr;
                     a.tok_const = sos_ix;
                 }
@@ -1472,8 +1535,8 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
             if (t >= L && ax3) {  // out_linear + argmax (:95-96, :105-106) on the bf16 matrix cores (argmax_x3.hip); the
                 ProfScope ps(sx, K_ARGMAX, 1);      // step kernel above wrote h_t as planes (StepFwdArgs::h_planes)
                 ArgmaxX3Args ax;
-                ax.B = B; ax.V = V; ax.K = w.wo.kpad;
-                ax.W = w.wo.p; ax.ldw = w.wo.ld;
+                ax.B = B; ax.V = V; ax.K = kc.wo.kpad;
+                ax.W = kc.wo.p; ax.ldw = kc.wo.ld;
                 ax.Hp = w.ph2.p; ax.ldh = w.ph2.ld;
                 ax.bias = p->out_b;
                 ax.packed = w.packed + (int64_t)(t - L) * B;

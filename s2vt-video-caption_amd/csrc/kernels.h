@@ -62,6 +62,10 @@ struct StepFwdArgs {
     // k = hidden unit, ld = 3 * kpad elements): the decode step hands its h_t to the plane-path argmax kernel without a
     // split launch in between.  Columns H..kpad of the image must have been zeroed by the caller.
     unsigned short* h_planes; int64_t ldhp;
+    // optional: a per-TOKEN gate-input table added to gx in the epilogue, row = the token the x2 segment would gather
+    // (tok_idx / tok_packed / tok_const): gtab[tok][4H] = Emb[tok]·W_e^T computed once per decode call replaces the
+    // E-wide second K segment of every decode step (x2 must then be null)
+    const float* gx_tab; int64_t ldtab;
 };
 int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a);
 int lstm_step_fwd2(hipStream_t stream, const StepFwdArgs& a, const StepFwdArgs* b);   // two independent steps, one launch

@@ -230,6 +230,17 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
         const float* q = (evalid && p.c_prev) ? p.c_prev + (int64_t)eb * p.ldc + eunit : g_zero4;
         cpv = *q;
     }
+    float gtv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.gx_tab) {       // embedded-word half of the gate input from the per-token table (two dependent loads, behind the K loop)
+        int64_t tok = p.tok_const;
+        if (evalid) {
+            if (p.tok_idx) tok = p.tok_idx[eb];
+            else if (p.tok_packed) tok = (int64_t)(0xFFFFFFFFu - (uint32_t)(p.tok_packed[eb] & 0xFFFFFFFFull));
+        }
+        const float* trow = p.gx_tab + tok * p.ldtab;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gtv[g] = *(evalid ? trow + (int64_t)g * p.H + eunit : g_zero4);
+    }
 
     if (p.h_prev) {
         const float* arow[MT * LPT];
@@ -283,7 +294,7 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
         const int bl = ebl, u = eu, b = eb, unit = eunit;
         float pre[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pre[g] = read_sum<MT, NT, NWAVE, RLD>(red, bl, g * UN + u) + gxv[g];
+        for (int g = 0; g < 4; ++g) pre[g] = read_sum<MT, NT, NWAVE, RLD>(red, bl, g * UN + u) + gxv[g] + gtv[g];
         const float ig = sigmoidf_(pre[0]);
         const float fg = sigmoidf_(pre[1]);
         const float gg = tanhf_(pre[2]);

@@ -165,11 +165,29 @@ def train_forward(feats, targets, params, grad_sink=None, out_mask=None):
     return _TrainForward.apply(feats, targets, grad_sink, out_mask, *params)
 
 
+# Weight-derived images of the decode (plane images of four weight matrices, the per-token gate-input table) kept between
+# mode='test' calls of one model while its parameters stand: key = every parameter's (data_ptr, _version) + dims + library
+# modes + stream.  In-place updates through autograd-visible ops (optimizers, load_state_dict, .to()) change the key; writes
+# through `param.data` do NOT bump a version counter - call clear_decode_cache(model) after such a write, or set
+# DECODE_CACHE = False.  Kept OUT of the module (a WeakKeyDictionary) so that torch.save(model) stays the reference's layout.
+DECODE_CACHE = True
+_DECODE_CACHES = weakref.WeakKeyDictionary()
+
+
+def clear_decode_cache(model=None):
+    if model is None:
+        _DECODE_CACHES.clear()
+    else:
+        _DECODE_CACHES.pop(model, None)
+
+
 @torch.no_grad()
-def greedy_decode(feats, params, sos_ix):
-    """ids int64 [B, L-1] of S2VT.forward(mode='test')."""
+def greedy_decode(feats, params, sos_ix, owner=None):
+    """ids int64 [B, L-1] of S2VT.forward(mode='test').  `owner`: the module the parameters belong to (enables the
+    weight-image cache above)."""
     lib = capi.load()
     feats = _f32c(feats, "feats")
+    raw = params
     params = tuple(_f32c(p.detach(), "parameter") for p in params)
     d = _dims(feats, params)
     dev = feats.device
@@ -178,8 +196,21 @@ def greedy_decode(feats, params, sos_ix):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         ids = torch.empty(d.B, d.L - 1, dtype=torch.int64, device=dev)
         ps = _params_struct(capi.Params, params)
-        capi.check(lib.s2vt_greedy_decode(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), int(sos_ix), _ptr(ids),
-                                          _ptr(ws), nbytes, _stream(dev)), "s2vt_greedy_decode")
+        if owner is not None and DECODE_CACHE and d.B % 64 == 0 and lib.s2vt_set_gemm_mode(-1) != 0:
+            key = (tuple((p.data_ptr(), p._version) for p in raw), (d.L, d.F, d.H, d.E, d.V), lib.s2vt_set_gemm_mode(-1),
+                   str(dev), torch.cuda.current_stream(dev).cuda_stream)
+            entry = _DECODE_CACHES.get(owner)
+            cbytes = lib.s2vt_decode_cache_bytes(ctypes.byref(d))
+            valid = entry is not None and entry[0] == key and entry[1].numel() >= cbytes
+            if not valid:
+                entry = (key, torch.empty(cbytes, dtype=torch.uint8, device=dev))
+                _DECODE_CACHES[owner] = entry
+            capi.check(lib.s2vt_greedy_decode_cached(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), int(sos_ix), _ptr(ids),
+                                                     _ptr(ws), nbytes, _ptr(entry[1]), entry[1].numel(), 1 if valid else 0,
+                                                     _stream(dev)), "s2vt_greedy_decode_cached")
+        else:
+            capi.check(lib.s2vt_greedy_decode(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), int(sos_ix), _ptr(ids),
+                                              _ptr(ws), nbytes, _stream(dev)), "s2vt_greedy_decode")
     return ids
 
 

@@ -699,3 +699,38 @@ def test_graph_replay_is_bitwise_the_eager_sequence(lib, cfg, gemm_mode):
     finally:
         lib.s2vt_set_graph_mode(0)
         lib.s2vt_set_gemm_mode(prev)
+
+
+def test_decode_cache_follows_the_weights(lib, golden):
+    """The weight-image cache of mode='test' (s2vt_greedy_decode_cached; functional._DECODE_CACHES): a second call on unchanged
+    weights reuses the images and must give the ids of the first (= the reference's, c2 fixture); after the weights change - an
+    in-place optimizer-style update, then load_state_dict - the key (data_ptr, _version) changes and the decode must be the one of
+    the new weights, equal to what an uncached call computes."""
+    from s2vt_video_caption_amd import functional
+    g = golden("c2")
+    d, sd, feats, caps, mask = _setup(g, "c2")
+    f = feats.to(DEV)
+    m = _model(d, sd).eval()
+    keep = functional.DECODE_CACHE
+    try:
+        functional.DECODE_CACHE = True
+        functional.clear_decode_cache()
+        with torch.no_grad():
+            a = m(f, mode="test").cpu().numpy()
+            assert m in functional._DECODE_CACHES
+            b = m(f, mode="test").cpu().numpy()                      # cached images
+            np.testing.assert_array_equal(a, g["greedy_ids"])
+            np.testing.assert_array_equal(b, g["greedy_ids"])
+            m.out_linear.bias.add_(torch.linspace(-1.0, 1.0, d["V"], device=DEV))     # in-place update: version bump
+            m.embedding.weight.mul_(0.5)
+            c = m(f, mode="test").cpu()
+            functional.DECODE_CACHE = False
+            c_ref = m(f, mode="test").cpu()
+            assert torch.equal(c, c_ref) and not np.array_equal(c.numpy(), a)
+            functional.DECODE_CACHE = True
+            m.load_state_dict(sd)                                    # back to the fixture's weights (in-place copy)
+            e = m(f, mode="test").cpu().numpy()
+            np.testing.assert_array_equal(e, g["greedy_ids"])
+    finally:
+        functional.DECODE_CACHE = keep
+        functional.clear_decode_cache()
