@@ -40,6 +40,13 @@ __device__ __forceinline__ uint32_t ax_ordered_bits(float x) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// experiment switches (S2VT_AX_DBG; tools/bench_argmax_x3_stamps.py): compiled out of the product
+#ifdef S2VT_EXPERIMENT_STAMPS
+#define AX_DBG(P) ((P).dbg)
+#else
+#define AX_DBG(P) 0
+#endif
+
 template <int NB>
 __global__ __launch_bounds__(256) void logits_argmax_x3_kernel(ArgmaxX3Args p) {
     constexpr int NSEG = 1 + NB;                       // row-block segments of a stage: W_o block, then the h blocks
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(256) void logits_argmax_x3_kernel(ArgmaxX3Args p) {
     const int li = lane & 31, lh = lane >> 5;
     const int vb = blockIdx.x;                         // vocabulary row block (64 rows)
     const int bt = blockIdx.y;                         // batch tile (64 * NB rows)
-    const int nst = (p.dbg & 4) ? 4 : (p.K >> 5);      // k32 stages (K % 64 == 0: an even number >= 2)
+    const int nst = (AX_DBG(p) & 4) ? 4 : (p.K >> 5);      // k32 stages (K % 64 == 0: an even number >= 2)
     const int xrec = p.stamps ? (int)blockIdx.x : -1;
     XSTAMP(p.stamps, xrec, 0);
 #ifdef S2VT_EXPERIMENT_STAMPS
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256) void logits_argmax_x3_kernel(ArgmaxX3Args p) {
     }
     // request j of stage s -> ring slot s % AX_NS (nothing for a stage past the last one)
 #define AX_REQ(S, J)                                                                                         \
-    if ((steady_ || (S) < nst) && !(p.dbg & 1)) ax_glds16(gsrc[J] + (int64_t)(S) * AX_SEG, smem + ((S) % AX_NS) * STAGE + loff[J]);
+    if ((steady_ || (S) < nst) && !(AX_DBG(p) & 1)) ax_glds16(gsrc[J] + (int64_t)(S) * AX_SEG, smem + ((S) % AX_NS) * STAGE + loff[J]);
 
     f32x16 acc[NB];
 #pragma unroll
@@ -241,7 +248,7 @@ __global__ __launch_bounds__(256) void logits_argmax_x3_kernel(ArgmaxX3Args p) {
         const unsigned long long k0 = keys[tid], k1 = keys[64 * NB + tid];
         const unsigned long long best = k0 > k1 ? k0 : k1;
         const int b = bt * 64 * NB + tid;
-        if (b < p.B && best && !(p.dbg & 2)) atomicMax(&p.packed[b], best);
+        if (b < p.B && best && !(AX_DBG(p) & 2)) atomicMax(&p.packed[b], best);
     }
     XSTAMP(p.stamps, xrec, 6);
 }
