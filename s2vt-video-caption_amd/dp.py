@@ -141,9 +141,13 @@ def global_mean(total, count, device="cpu"):
     return float(t[0] / torch.clamp(t[1], min=1.0))
 
 
-def train_step(model, criterion, optimizer, feats, caps, mask, reducer=None):
+def train_step(model, criterion, optimizer, feats, caps, mask, reducer=None, check_errors=False):
     """One optimisation step of train.py:116-127 on this rank's shard; returns the (local) loss tensor.
-    With `reducer`, gradients are averaged over ranks before the optimiser step."""
+    With `reducer`, gradients are averaged over ranks before the optimiser step.
+    `check_errors`: synchronise and raise device-side errors of this step (a caption id outside the vocabulary -> IndexError, as
+    nn.Embedding raises in the reference's forward; a timed-out hand-off) BEFORE optimizer.step(), so that a bad batch never
+    reaches the weights - what the reference's ordering gives for free.  Costs one synchronisation per step; a loop that reads
+    loss.item() every step (train.py:127) pays that anyway."""
     if reducer is not None:
         reducer.zero_grad()
     else:
@@ -154,5 +158,9 @@ def train_step(model, criterion, optimizer, feats, caps, mask, reducer=None):
     loss.backward()
     if reducer is not None:
         reducer.all_reduce()
+    if check_errors:
+        from . import capi
+        torch.cuda.synchronize(loss.device)
+        capi.check_async_error()
     optimizer.step()
     return loss.detach()

@@ -422,6 +422,16 @@ def test_out_of_range_target_raises_index_error(lib):
     logits = m(feats.to(DEV), targets=caps[:, :-1].to(DEV), mode="train")       # a clean call works again
     capi.check_async_error()
     assert torch.isfinite(logits).all()
+    # dp.train_step(check_errors=True), what train.py runs: the error is raised BEFORE optimizer.step() - a bad batch never
+    # reaches the weights, as in the reference, whose nn.Embedding raises in the forward (S2VTModel.py:71, train.py:120-125)
+    from s2vt_video_caption_amd import dp
+    crit = utils.MaskCriterion()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with pytest.raises(IndexError):
+        dp.train_step(m, crit, opt, feats.to(DEV), bad.to(DEV), mask.to(DEV), None, check_errors=True)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k
 
 
 def test_out_of_range_loss_target_raises_index_error(lib):

@@ -116,9 +116,10 @@ def run(opt):
         hist["lr"].append(optimizer.param_groups[0]['lr'])
         running, count = 0.0, 0
         for feats, targets, ids, masks in dataloader.feed_batches(train_loader, dev):
-            loss = dp.train_step(model, criterion, optimizer, feats, targets, masks, reducer)   # train.py:116-127
-            running += float(loss)                      # synchronises: a device-side error of this step is known now
-            capi.check_async_error()                    # e.g. IndexError for a caption id outside the vocabulary
+            # train.py:116-127; check_errors: a device-side error of this step (IndexError for a caption id outside the vocabulary)
+            # is raised BEFORE optimizer.step(), as in the reference, whose nn.Embedding raises in the forward
+            loss = dp.train_step(model, criterion, optimizer, feats, targets, masks, reducer, check_errors=True)
+            running += float(loss)
             count += 1
         train_loss = running / max(count, 1)
         running, count = 0.0, 0
