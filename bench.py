@@ -395,18 +395,24 @@ def main():
             else:
                 bk = "lstm_step_bwd_bf16_kernel" if bf_ else "lstm_step_bwd_kernel"
 
-            def step_rec(kernel, gbs, us, note):
+            def step_rec(kernel, gbs, us, note, busy_ms):
                 tr = traffic_of(kernel)
+                busy_us = busy_ms * 1e3 / (2 * T)          # wall time per layer timestep while at least one lane runs this family
                 return {"kernel": kernel, "bound": "hbm", "achieved": round(gbs, 1),
+                        "busy_us_per_layer_timestep": round(busy_us, 3),
+                        "frac_by_busy_time": round((pair_ / 2) / (busy_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                         "traffic": tr, "traffic_source": pmc_src_ if tr is not None else None,
                         "hbm_gbs_measured": round(tr / (us * 1e-6) / 1e9, 1) if tr is not None else None,
                         "avg_launch_us": round(us, 3), "launches_per_step": 2 * T,
                         "ms_per_step": round(us * 2 * T / 1e3, 3),
                         "algorithmic_bytes_per_launch": pair_ // 2, "timing": how, "note": note}
-            rs = step_rec(fk, step_gbs, step_us, fnote)
+            lane_note = ("; `frac` prices the average LAUNCH (two lanes' launches overlap and stretch each other), `frac_by_busy_time` the "
+                         "wall time per layer timestep while the family runs (union of the lanes' brackets)")
+            rs = step_rec(fk, step_gbs, step_us, fnote + lane_note, pr["step_fwd"][2])
             rb = step_rec(bk, bstep_gbs, bstep_us,
-                          "BPTT timestep: dh = dG_{t+1} W_hh + gate derivatives; same §8(d) byte accounting as the forward timestep")
+                          "BPTT timestep: dh = dG_{t+1} W_hh + gate derivatives; same §8(d) byte accounting as the forward timestep" + lane_note,
+                          pr["step_bwd"][2])
             return rg, rs, rb
 
         live = profile()
