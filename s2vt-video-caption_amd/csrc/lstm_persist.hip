@@ -319,13 +319,39 @@ __device__ __forceinline__ void seq_fwd_body(const SeqFwdBf16Args& p, const int 
     }
 }
 
-// grid = [na workgroups of layer pa | workgroups of layer pb] (nb may be 0)
+// Which role a block plays: (layer, workgroup index inside the layer = rg * nC + cs).  xg == 0: blocks [0, na) are layer A in
+// order, the rest layer B.  xg = G > 0 (XCD-aware, the launchers choose it when 8 % G == 0 and G * nC % 8 == 0): the hardware
+// deals workgroups to the 8 XCDs round-robin (block b -> XCD b % 8, speed only - nothing depends on it for correctness); a GROUP
+// is the nC column slices of one (layer, row group), i.e. the workgroups that read the SAME rows in every sub-step, and group g
+// is dealt to the XCDs {g, g + G, ..}: its rows then enter 8/G L2s instead of all eight, and a line is shared by nC * G / 8
+// readers of one L2 instead of nC / 8.
+__device__ __forceinline__ int persist_role(int bid, int na, int nC, int xg, bool& layer_b) {
+    if (xg <= 0) { layer_b = bid >= na; return layer_b ? bid - na : bid; }
+    const int x = bid & 7, q = bid >> 3, per = 8 / xg;
+    const int g = x % xg, cs = q * per + x / xg;
+    const int rgs = na / nC;                         // row groups of layer A (= of layer B: the launcher checked)
+    layer_b = g >= rgs;
+    return (layer_b ? g - rgs : g) * nC + cs;
+}
+// the launcher's side of it: G groups, or 0 for the plain order
+static int xcd_groups(int na, int nb, int nC) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("S2VT_PERSIST_XCD"); on = e ? atoi(e) : 1; }
+    if (!on || nC <= 0 || na % nC || nb % nC) return 0;
+    if (nb && nb != na) return 0;
+    const int G = (na + nb) / nC;
+    return (G > 0 && 8 % G == 0 && ((na + nb) % 8) == 0) ? G : 0;
+}
+
+// grid = [na workgroups of layer pa | workgroups of layer pb] (nb may be 0), or dealt by persist_role
 template <bool FULL>
-__global__ __launch_bounds__(P_NT, 2) void lstm_seq_fwd_bf16_persist_kernel(SeqFwdBf16Args pa, SeqFwdBf16Args pb, int na) {
+__global__ __launch_bounds__(P_NT, 2) void lstm_seq_fwd_bf16_persist_kernel(SeqFwdBf16Args pa, SeqFwdBf16Args pb, int na, int xg) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[P_LDS];
     __shared__ int s_flag;                 // poll result of the polling lane
-    if ((int)blockIdx.x < na) seq_fwd_body<FULL>(pa, blockIdx.x, smem, s_flag);
-    else seq_fwd_body<FULL>(pb, blockIdx.x - na, smem, s_flag);
+    bool lb;
+    const int vb = persist_role((int)blockIdx.x, na, (pa.H + P_UN - 1) / P_UN, xg, lb);
+    if (!lb) seq_fwd_body<FULL>(pa, vb, smem, s_flag);
+    else seq_fwd_body<FULL>(pb, vb, smem, s_flag);
 }
 
 int lstm_seq_fwd_bf16_persist_supported(int B, int H, int Kp);
@@ -518,7 +544,6 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
                 }
 #define Q_STEP(J, VM)                                                                                        \
                 if ((J) < C::CPW) {                                                                           \
-                    if ((J) + 3 < C::CPW) Q_ISSUE((J) + 3)                                                    \
                     asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                    \
                     bf16x8 a00, a01, a10, a11;                                                                \
                     P_DSR(a00, fa[0][0], ((J) % Q_NSLOT) * 4096); P_DSR(a10, fa[1][0], ((J) % Q_NSLOT) * 4096); \
@@ -526,11 +551,15 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
                     asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a00), "+v"(a10));                              \
                     Q_MFMA(J, 0, a00, a10)                                                                    \
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a01), "+v"(a11));                              \
+                    /* the slot's four fragment reads are in: it takes chunk J + 4 at once, so that FOUR chunks (16 KB per */ \
+                    /* wave, 128 KB per CU at 8 waves) are in flight while the MFMAs run - the dG rows were written by     */ \
+                    /* other XCDs a sub-step ago and come over the fabric: bytes in flight / latency is the ingest rate    */ \
+                    if ((J) + 4 < C::CPW) Q_ISSUE((J) + 4)                                                    \
                     Q_MFMA(J, 1, a01, a11)                                                                    \
                 }
-                Q_ISSUE(0) Q_ISSUE(1) Q_ISSUE(2)
+                Q_ISSUE(0) Q_ISSUE(1) Q_ISSUE(2) Q_ISSUE(3)
                 XSTAMP(p.stamps, xrec, 2);
-                // chunk J landed when at most the requests of the younger chunks (3 of them, fewer at the end) are out
+                // chunk J landed when at most the requests of the younger chunks (J+1..J+3; fewer at the end) are out
                 if (C::CPW == 16) {
                     Q_STEP(0, 12) Q_STEP(1, 12) Q_STEP(2, 12) Q_STEP(3, 12) Q_STEP(4, 12) Q_STEP(5, 12) Q_STEP(6, 12)
                     Q_STEP(7, 12) Q_STEP(8, 12) Q_STEP(9, 12) Q_STEP(10, 12) Q_STEP(11, 12) Q_STEP(12, 12)
@@ -621,11 +650,13 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
 }
 
 template <int NW, int UN>
-__global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : 1) void lstm_seq_bwd_bf16_persist_kernel(SeqBwdBf16Args pa, SeqBwdBf16Args pb, int na) {
+__global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : 1) void lstm_seq_bwd_bf16_persist_kernel(SeqBwdBf16Args pa, SeqBwdBf16Args pb, int na, int xg) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[BwdCfg<NW, UN>::LDS];
     __shared__ int s_flag;
-    if ((int)blockIdx.x < na) seq_bwd_body<NW, UN>(pa, blockIdx.x, smem, s_flag);
-    else seq_bwd_body<NW, UN>(pb, blockIdx.x - na, smem, s_flag);
+    bool lb;
+    const int vb = persist_role((int)blockIdx.x, na, (pa.H + UN - 1) / UN, xg, lb);
+    if (!lb) seq_bwd_body<NW, UN>(pa, vb, smem, s_flag);
+    else seq_bwd_body<NW, UN>(pb, vb, smem, s_flag);
 }
 
 // chains per workgroup such that TWO layers of this shape (un hidden units per workgroup) fit `cap` co-resident workgroups
@@ -698,10 +729,11 @@ int lstm_seq_bwd_bf16_persist2(hipStream_t stream, SeqBwdBf16Args a, const SeqBw
     // is a 5-us kernel of its own on this stream: 28 of them per train step when every launch zeroed its counters)
     if (a.t1 == a.T) S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
     if (b && bb.t1 == bb.T) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
+    const int xg = (!b || (bb.B == a.B && bb.H == a.H)) ? xcd_groups(na, nb, cdiv(a.H, pa.un)) : 0;
     if (pa.un == 32)
-        hipLaunchKernelGGL((lstm_seq_bwd_bf16_persist_kernel<8, 32>), dim3(na + nb), dim3(512), 0, stream, a, bb, na);
+        hipLaunchKernelGGL((lstm_seq_bwd_bf16_persist_kernel<8, 32>), dim3(na + nb), dim3(512), 0, stream, a, bb, na, xg);
     else
-        hipLaunchKernelGGL((lstm_seq_bwd_bf16_persist_kernel<4, 16>), dim3(na + nb), dim3(256), 0, stream, a, bb, na);
+        hipLaunchKernelGGL((lstm_seq_bwd_bf16_persist_kernel<4, 16>), dim3(na + nb), dim3(256), 0, stream, a, bb, na, xg);
     S2VT_LAUNCH_CHECK("lstm_seq_bwd_bf16_persist_kernel");
     return 0;
 }
@@ -742,10 +774,15 @@ int lstm_seq_fwd_bf16_persist2(hipStream_t stream, SeqFwdBf16Args a, const SeqFw
     // (counters: see the BPTT launcher) zeroed with the sequence's first block
     if (a.t0 == 0) S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
     if (b && bb.t0 == 0) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
+    // (no XCD-aware dealing for the forward: with TWO workgroups per compute unit the neighbours on a CU must be out of phase to
+    // hide each other's hand-off latencies, and dealing a group to one XCD makes them members of the same chain - measured
+    // 1.99 vs 1.84 ms per config-3 forward; the one-per-CU BPTT launch gains from it: 2.90 vs 3.12 ms)
+    static const bool fwd_xcd = getenv("S2VT_PERSIST_XCD_FWD") && atoi(getenv("S2VT_PERSIST_XCD_FWD")) != 0;
+    const int xg = (fwd_xcd && (!b || (bb.B == a.B && bb.H == a.H))) ? xcd_groups(na, nb, cdiv(a.H, P_UN)) : 0;
     if (a.Kp == 64 * P_KCH)
-        hipLaunchKernelGGL((lstm_seq_fwd_bf16_persist_kernel<true>), dim3(na + nb), dim3(P_NT), 0, stream, a, bb, na);
+        hipLaunchKernelGGL((lstm_seq_fwd_bf16_persist_kernel<true>), dim3(na + nb), dim3(P_NT), 0, stream, a, bb, na, xg);
     else
-        hipLaunchKernelGGL((lstm_seq_fwd_bf16_persist_kernel<false>), dim3(na + nb), dim3(P_NT), 0, stream, a, bb, na);
+        hipLaunchKernelGGL((lstm_seq_fwd_bf16_persist_kernel<false>), dim3(na + nb), dim3(P_NT), 0, stream, a, bb, na, xg);
     S2VT_LAUNCH_CHECK("lstm_seq_fwd_bf16_persist_kernel");
     return 0;
 }
