@@ -418,7 +418,10 @@ def main():
         live = profile()
         prev_blk = lib.s2vt_set_pipeline_block(0)          # (returns the block in use ...
         lib.s2vt_set_pipeline_block(prev_blk)              # ... and this puts it back)
-        roof_gemm, roof_step, roof_bstep = rooflines(live, "live, layers pipelined (block %d)" % prev_blk, persist_bf16 or persist_f32)
+        eff_blk = prev_blk           # api.hip balanced_block(): the persistent bf16 schedule evens the default 32 out over the L frames
+        if persist_bf16 and prev_blk == 32:
+            eff_blk = -(-L // -(-L // 32))
+        roof_gemm, roof_step, roof_bstep = rooflines(live, "live, layers pipelined (block %d)" % eff_blk, persist_bf16 or persist_f32)
         if args.headline_only:
             alone = live
             roof_gemm_alone = roof_step_alone = roof_bstep_alone = None

@@ -296,8 +296,9 @@ int s2vt_decode_step_argmax_x3(int32_t B, int32_t H, int32_t V, const float* h, 
 int s2vt_set_gemm_mode(int32_t mode);
 
 /* Layer pipelining of the whole-path drivers: the two LSTM layers run as a software pipeline on two streams in
- * blocks of `steps` timesteps (default 32, or env S2VT_PIPE_BLOCK); 0 runs everything on the caller's stream
- * (kernels then never overlap: used to time kernels in isolation).  Returns the previous value. */
+ * blocks of `steps` timesteps (default 32, or env S2VT_PIPE_BLOCK; the persistent bf16 schedule evens the default out over
+ * the L frames - 27 at L = 80 - because its launches pair a block of one layer with a block of the other); 0 runs everything
+ * on the caller's stream (kernels then never overlap: used to time kernels in isolation).  Returns the previous value. */
 int s2vt_set_pipeline_block(int32_t steps);
 /* 1 if the internal side stream was verified to execute concurrently with the caller's stream (it is chosen by a
  * one-time calibration at the first pipelined call: HIP may map two streams onto one hardware queue), 0 if no

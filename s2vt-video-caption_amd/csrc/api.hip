@@ -429,6 +429,16 @@ static int seq_bwd(hipStream_t st, int T, int t0, int t1, int B, int H, const fl
     return 0;
 }
 
+// Block length of the ONE-stream persistent bf16 schedule: a launch of stage k runs block k of one layer next to block k-1 of the
+// other, and lasts as long as the LONGER of the two - with 32-step blocks over L = 80 frames the blocks are 32, 32, 16 | 32, 32, 15
+// and the seven launches of a pass cover 207 timestep slots for 159 timesteps; equal blocks (27, 27, 26 | 27, 27, 25) cover 187
+// (measured: BPTT 2.93 -> 2.65 ms, forward 1.89 -> 1.76 ms per config-3 step).  Only the default block (32) is rebalanced; an
+// explicit S2VT_PIPE_BLOCK / s2vt_set_pipeline_block value is taken as given.
+static int balanced_block(int L, int blk) {
+    if (blk != 32 || L <= 0) return blk;
+    const int n = (L + 31) / 32;
+    return (L + n - 1) / n;
+}
 // Block boundaries over [0, T) with L (first caption step) forced to be a boundary.
 static std::vector<int> pipe_bounds(int T, int L, int blk) {
     std::vector<int> b;
@@ -748,7 +758,8 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
     if ((rc = pgemm(la, B * L, H, F, q.feats, 0, 0, q.wf, 0, 0, w.x1, H, perm(L, B), p->feat_b, false))) return rc;
     if ((rc = pdual(la, w.x1, H, ID, L * B, H, &q.x1, 0, &q.x1T, 0, nullptr))) return rc;
     if ((rc = pgemm(la, L * B, 4 * H, H, q.x1, 0, 0, q.wih1, 0, 0, w.s1, 4 * H, ID, w.bsum1, false))) return rc;
-    const std::vector<int> bd = pipe_bounds(T, L, blk);
+    const bool pbf_fwd = bf && blk > 0 && persist_fwd_ok(B, H, q.whh1, q.h1);
+    const std::vector<int> bd = pipe_bounds(T, L, pbf_fwd ? balanced_block(L, blk) : blk);
     if (!bf && blk > 0 && persist_f32_on() && lstm_seq_fwd_f32_persist_supported(B, H)) {
         // fp32 persistent schedule (lstm_persist_f32.hip), ONE stream: stage k = vid_rnn block k next to word_rnn block k-1
         if ((rc = handoff(sx, st, ev++))) return rc;
@@ -782,7 +793,7 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
         if ((rc = masked_logits_planes(la, w, q, out_mask, B, L, H))) return rc;
         return pgemm(la, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
     }
-    if (bf && persist_fwd_ok(B, H, q.whh1, q.h1) && blk > 0) {
+    if (pbf_fwd) {
         // Persistent schedule, ONE stream: the launch of pipeline stage k runs vid_rnn block k next to word_rnn block k-1
         // (lstm_persist.hip: two workgroups per CU, each layer's W_hh slices resident in registers); between two
         // launches the plane split + input GEMM of the vid block just finished run alone on the chip.
@@ -879,7 +890,8 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = colsum_finish(sx, w.colsum_c, cdiv(R, 64), V, g->out_b, false))) return rc;
     if ((rc = grads_ready(0, sx))) return rc;
     if ((rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
-    const std::vector<int> bd = pipe_bounds(T, L, blk);
+    const bool pbf_bwd = bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad;
+    const std::vector<int> bd = pipe_bounds(T, L, pbf_bwd ? balanced_block(L, blk) : blk);
     if (!bf && blk > 0 && persist_f32_on() && lstm_seq_bwd_f32_persist_supported(B, H)) {
         // fp32 persistent schedule, ONE stream: stage k = word_rnn BPTT of block k next to vid_rnn BPTT of block k+1
         if ((rc = handoff(sx, st, ev++))) return rc;               // W_hh1^T and the out_linear gradients of lane B
@@ -912,7 +924,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
         }
         if ((rc = grads_ready(0, st))) return rc;                  // (see the bf16 branch below)
         if ((rc = handoff(st, sx, ev++))) return rc;
-    } else if (bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad) {
+    } else if (pbf_bwd) {
         // Persistent schedule, ONE stream (mirror of the forward): the launch of stage k runs the word_rnn BPTT of block k
         // next to the vid_rnn BPTT of block k+1 (lstm_persist.hip); between two launches the dG planes / partial column sums
         // of the blocks just finished and the dh1 GEMM of the word block run alone on the chip.

@@ -626,7 +626,11 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
                         for (int g = 0; g < 4; ++g) {
                             const u32x4 v = *reinterpret_cast<const u32x4*>(dgsm + rl * (4 * UN) + g * UN + part * 8);
                             unsigned short* dst = drow + (int64_t)g * H;
+#ifdef S2VT_EXPERIMENT_PLAIN_STORES     // timing experiment only (tools/bench_bptt_stamps.py): hand-off stores that stay in the producer's L2
+                            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+#else
                             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+#endif
                         }
                     }
                 }

@@ -13,7 +13,8 @@ from s2vt_video_caption_amd import build, capi
 
 HERE = os.path.dirname(os.path.abspath(build.__file__))
 xlib = os.path.join(HERE, "libs2vt_hip_stamps.so")
-DEFS = ("S2VT_EXPERIMENT_STAMPS",) + (("S2VT_EXPERIMENT_PLAIN_LOADS",) if os.environ.get("PLAIN_LOADS") == "1" else ())
+DEFS = (("S2VT_EXPERIMENT_STAMPS",) + (("S2VT_EXPERIMENT_PLAIN_LOADS",) if os.environ.get("PLAIN_LOADS") == "1" else ()) +
+        (("S2VT_EXPERIMENT_PLAIN_STORES",) if os.environ.get("PLAIN_STORES") == "1" else ()))
 print("build defines:", DEFS)
 build.build(defines=DEFS, out_path=xlib)          # (an out_path build always recompiles)
 capi.LIB_PATH = xlib
@@ -37,6 +38,9 @@ dh0 = (torch.randn(T * B, H, generator=g) * 0.01).to(DEV)
 dh1 = (torch.randn(T * B, H, generator=g) * 0.01).to(DEV)
 for _ in range(2):
     ops.lstm_seq_bwd_bf16_pair(w0, w1, dh0, dh1, 0, c0, c1, g0, g1, T, B, H, block=0)
+ref = ops.lstm_seq_bwd_bf16(w0, dh0, 0, c0, g0, T, B, H, persistent=False)
+got = ops.lstm_seq_bwd_bf16_pair(w0, w1, dh0, dh1, 0, c0, c1, g0, g1, T, B, H, block=0)[0]
+print("max |dG(persistent pair) - dG(launch per timestep)| = %.3e (scale %.3e)" % ((got - ref).abs().max().item(), ref.abs().max().item()))
 for blockid in (0, 17, 100, 200):
     stamps = torch.zeros(4096 * 16, dtype=torch.int64, device=DEV)
     lib.s2vt_experiment_set_stamps(ctypes.c_void_p(stamps.data_ptr()), blockid)
