@@ -337,11 +337,15 @@ def main():
         elif B == 256 and bf:
             pmc, pmc_src = load_pmc("c3")
 
-        rmode = lib.s2vt_set_recurrence_mode(-1)
-        persist_bf16 = bf and rmode >= 1           # the timed configuration runs the persistent bf16 recurrence kernels
-        persist_f32 = (not bf) and x3 and rmode >= 2
+        plan = capi.recurrence_plan(B, H)          # (forward, BPTT) recurrence kernels of the timed configuration (s2vt_hip.h)
+        persist_bf16 = plan[0] == 1
+        FWD_KERNELS = {0: "lstm_step_fwd_kernel", 1: "lstm_seq_fwd_bf16_persist_kernel", 2: "lstm_seq_fwd_f32_persist_kernel",
+                       3: "lstm_seq_fwd_x3_persist_kernel"}
+        BWD_KERNELS = {0: "lstm_step_bwd_kernel", 1: "lstm_seq_bwd_bf16_persist_kernel", 2: "lstm_seq_bwd_f32_persist_kernel"}
 
         def rooflines(pr, how, persist, B_=B, esz_=esz, bf_=bf, x3_=x3, pmc_=None, pmc_src_=None):
+            # persist: (forward kind, BPTT kind) as s2vt_recurrence_plan reports them, or False for launches per timestep
+            pf, pb = persist if isinstance(persist, tuple) else ((1, 1) if (persist and bf_) else (2, 2) if persist else (0, 0))
             pmc_ = pmc if pmc_ is None else pmc_
             pmc_src_ = pmc_src if pmc_src_ is None else pmc_src_
 
@@ -379,8 +383,8 @@ def main():
                   "frac_by_sum_of_launch_ms": round(gflop_ / gemm_ms / gpeak, 4),
                   "algorithmic_bytes_or_flops_per_launch": round(gflop_ * 1e9 / max(gemm_n, 1)),
                   "algorithmic_gflop_per_step": round(gflop_, 1), "timing": how, "note": gnote}
-            if persist:
-                fk = "lstm_seq_fwd_bf16_persist_kernel" if bf_ else "lstm_seq_fwd_f32_persist_kernel"
+            if pf:
+                fk = FWD_KERNELS[pf]
                 fnote = ("PERSISTENT-WEIGHTS kernel: one launch runs a block of timesteps of BOTH layers with every W_hh slice "
                          "resident in registers, so W is not re-streamed and the fraction may exceed 1 (SURVEY.md §8(d)); "
                          "achieved = §8(d) ALGORITHMIC bytes of a (vid, word) timestep pair / 2 over the average per-layer timestep "
@@ -390,8 +394,8 @@ def main():
                 fk = "lstm_step_fwd_bf16_kernel" if bf_ else "lstm_step_fwd_kernel"
                 fnote = ("bytes per SURVEY.md §8(d) incl. W_ih although the x-part is hoisted into a batched GEMM; avg over vid+word "
                          "launches, loop-bracketed events (includes launch gaps)")
-            if persist:
-                bk = "lstm_seq_bwd_bf16_persist_kernel" if bf_ else "lstm_seq_bwd_f32_persist_kernel"
+            if pb:
+                bk = BWD_KERNELS[pb]
             else:
                 bk = "lstm_step_bwd_bf16_kernel" if bf_ else "lstm_step_bwd_kernel"
 
@@ -419,9 +423,9 @@ def main():
         prev_blk = lib.s2vt_set_pipeline_block(0)          # (returns the block in use ...
         lib.s2vt_set_pipeline_block(prev_blk)              # ... and this puts it back)
         eff_blk = prev_blk           # api.hip balanced_block(): the persistent bf16 schedule evens the default 32 out over the L frames
-        if persist_bf16 and prev_blk == 32:
+        if plan[0] in (1, 3) and prev_blk == 32:
             eff_blk = -(-L // -(-L // 32))
-        roof_gemm, roof_step, roof_bstep = rooflines(live, "live, layers pipelined (block %d)" % eff_blk, persist_bf16 or persist_f32)
+        roof_gemm, roof_step, roof_bstep = rooflines(live, "live, layers pipelined (block %d)" % eff_blk, plan)
         if args.headline_only:
             alone = live
             roof_gemm_alone = roof_step_alone = roof_bstep_alone = None
@@ -540,7 +544,7 @@ def main():
                 pr3 = profile(2, b3)
                 pers = lib.s2vt_set_recurrence_mode(-1) >= 1
                 pmc3, pmc3_src = load_pmc("c3")
-                g3, f3, bw3 = rooflines(pr3, "live, persistent recurrence (block %d)" % prev_blk if pers else "live", pers,
+                g3, f3, bw3 = rooflines(pr3, "live, persistent recurrence (block %d)" % (-(-L // -(-L // 32)) if prev_blk == 32 else prev_blk) if pers else "live", pers,
                                         B_=256, esz_=2, bf_=True, x3_=False, pmc_=pmc3, pmc_src_=pmc3_src)
                 config3 = {"workload": "BASELINE configs[2]: B=256, 80x4096 feats, hidden=embed=1000, vocab=12000, bf16 operands / "
                                        "fp32 accumulate, Adam", "dtype": "bf16", "value": round(256 * L / d3, 1), "unit": "frames/s",

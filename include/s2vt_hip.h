@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define S2VT_ABI_VERSION 7
+#define S2VT_ABI_VERSION 8
 
 /* negative return codes (positive ones are hipError_t values) */
 #define S2VT_ERR_ARG (-1)      /* bad argument */
@@ -257,10 +257,14 @@ int s2vt_lstm_seq_bwd_bf16_pair(int32_t T, int32_t B, int32_t H, const float* w_
                                 float* stash_dg0, float* stash_dg1, void* workspace, size_t workspace_bytes, int32_t block,
                                 void* stream);
 /* Recurrence schedule inside the whole-path train drivers: 0 = one launch per timestep; 1 (default) = persistent
- * kernels for the bf16 configuration (gemm mode 1) where the shape allows, launch per timestep for fp32; 2 = persistent
- * kernels for fp32 as well (measured slower at B = 64, see lstm_persist_f32.hip).  Negative: query.  Returns the
- * previous mode. */
+ * kernels where the shape allows for the bf16 configuration (gemm mode 1: forward and BPTT) and for the FORWARD of the
+ * fp32-equivalent configuration (gemm mode 3: the split-precision kernel of lstm_persist_x3.hip; its BPTT stays one launch per
+ * timestep; env S2VT_PERSIST_X3_FWD=0 turns that forward off); 2 = the exact-fp32 persistent kernels as well (BPTT of gemm
+ * mode 3; measured slower end to end at B = 64, see lstm_persist_f32.hip).  Negative: query.  Returns the previous mode. */
 int s2vt_set_recurrence_mode(int32_t mode);
+/* Which recurrence kernels s2vt_train_forward / s2vt_train_backward would run for (B, H) in the current modes:
+ * *fwd, *bwd = 0 one launch per timestep, 1 persistent bf16, 2 persistent exact-fp32 MFMA, 3 persistent split precision. */
+int s2vt_recurrence_plan(int32_t B, int32_t H, int32_t* fwd, int32_t* bwd);
 
 /* fp32 persistent recurrence (lstm_persist_f32.hip): the same computation as s2vt_lstm_seq_fwd / s2vt_lstm_seq_bwd (exact
  * fp32 products on the matrix cores) with ONE launch per `block` timesteps (0 = all T) and each compute unit's slice of
@@ -269,6 +273,17 @@ int s2vt_set_recurrence_mode(int32_t mode);
  * workspace (s2vt_lstm_persist_workspace_bytes): word 0 (int32) is set to 1 if a hand-off wait timed out. */
 size_t s2vt_lstm_persist_workspace_bytes(void);
 int s2vt_lstm_seq_fwd_persist(int32_t T, int32_t B, int32_t H, float* gx_stash0, float* gx_stash1, int32_t n_gx,
+                              const float* bias0, const float* bias1, const float* w_hh0, const float* w_hh1, float* h_all0,
+                              float* h_all1, float* c_all0, float* c_all1, int32_t block, void* workspace,
+                              size_t workspace_bytes, void* stream);
+/* The same forward in split precision (lstm_persist_x3.hip): both operands of h_{t-1} . W_hh^T as three bf16 planes, six plane
+ * products on the bf16 matrix cores, fp32 accumulate - fp32-equivalent like gemm mode 3, at 6/16 of the exact-fp32 MFMA's
+ * cycles; one workgroup per compute unit keeps its W_hh planes in 384 registers per lane.  H <= 1024, B % 32 == 0.  Same
+ * arguments as s2vt_lstm_seq_fwd_persist; workspace from s2vt_lstm_seq_x3_workspace_bytes (word 0: hand-off time-out flag).
+ * Whole-path use: env S2VT_PERSIST_X3_FWD=1 routes the forward recurrences of s2vt_train_forward (gemm mode 3) through it
+ * (S2VTModel.py:67,77). */
+size_t s2vt_lstm_seq_x3_workspace_bytes(int32_t T, int32_t B, int32_t H);
+int s2vt_lstm_seq_fwd_x3_persist(int32_t T, int32_t B, int32_t H, float* gx_stash0, float* gx_stash1, int32_t n_gx,
                               const float* bias0, const float* bias1, const float* w_hh0, const float* w_hh1, float* h_all0,
                               float* h_all1, float* c_all0, float* c_all1, int32_t block, void* workspace,
                               size_t workspace_bytes, void* stream);

@@ -33,7 +33,7 @@ class Grads(ctypes.Structure):
 
 
 # name -> (restype, argtypes): every symbol include/s2vt_hip.h declares
-ABI_VERSION = 7          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
+ABI_VERSION = 8          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
 
 SIGNATURES = {
     "s2vt_abi_version": (c_int32, []),
@@ -90,9 +90,13 @@ SIGNATURES = {
     "s2vt_lstm_persist_workspace_bytes": (c_size_t, []),
     "s2vt_lstm_seq_fwd_persist": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 8 +
                                   [c_int32, c_void_p, c_size_t, c_void_p]),
+    "s2vt_lstm_seq_x3_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
+    "s2vt_lstm_seq_fwd_x3_persist": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 8 +
+                                  [c_int32, c_void_p, c_size_t, c_void_p]),
     "s2vt_lstm_seq_bwd_persist": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32] +
                                   [c_void_p] * 8 + [c_int32, c_void_p, c_size_t, c_void_p]),
     "s2vt_set_recurrence_mode": (c_int32, [c_int32]),
+    "s2vt_recurrence_plan": (c_int32, [c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
     "s2vt_decode_step_argmax": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5),
     "s2vt_decode_step_argmax_x3_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "s2vt_decode_step_argmax_x3": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5 + [c_size_t, c_void_p]),
@@ -174,3 +178,12 @@ def prof_read(kind):
     ms, n = c_double(0.0), c_int64(0)
     check(load().s2vt_prof_read(kind, ctypes.byref(ms), ctypes.byref(n)), "s2vt_prof_read")
     return ms.value, n.value
+
+
+def recurrence_plan(B, H):
+    """(forward, backward) recurrence kernels the train drivers would run for (B, H) in the current modes:
+    0 launch per timestep, 1 persistent bf16, 2 persistent exact-fp32 MFMA, 3 persistent split precision."""
+    import ctypes
+    f, b = c_int32(0), c_int32(0)
+    check(load().s2vt_recurrence_plan(int(B), int(H), ctypes.byref(f), ctypes.byref(b)), "s2vt_recurrence_plan")
+    return f.value, b.value

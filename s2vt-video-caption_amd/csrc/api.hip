@@ -71,11 +71,15 @@ static int read_record(ErrRecord& r, bool wait) {
 static std::mutex g_async_mutex;        // forward (caller's thread) and backward (autograd's thread) both post and poll
 static int poll_async_error(bool wait) {
     std::lock_guard<std::mutex> lock(g_async_mutex);
-    for (int k = 0; k < 3; ++k) {
-        int rc = read_record(g_async[k], wait);
-        if (rc) return rc;
+    int first = 0;
+    for (int k = 0; k < 3 && !first; ++k) first = read_record(g_async[k], wait);
+    if (first) {               // one bad batch flags the forward's AND the loss's record: it is reported once - the records still
+        char keep[512];        // pending are awaited and dropped with it (the caller is about to raise; the wait costs nothing then)
+        snprintf(keep, sizeof(keep), "%s", s2vt_last_error());
+        for (int k = 0; k < 3; ++k) (void)read_record(g_async[k], true);
+        set_error("%s", keep);
     }
-    return 0;
+    return first;
 }
 static int post_async_error(hipStream_t st, const int* dev_flags, int kind = 0) {
     std::lock_guard<std::mutex> lock(g_async_mutex);
@@ -234,6 +238,8 @@ struct TrainWS {
     int* embws;              // embedding_grad scratch (heavy-token list)
     int* err;                // [0] target id out of range, [1] persistent-recurrence hand-off timed out
     unsigned int *psync_a, *psync_b;     // hand-off counters of the persistent recurrence kernels (one block per lane)
+    unsigned short *xw1, *xw2, *xh1, *xh2;   // split-precision persistent forward (lstm_persist_x3.hip): W_hh planes [3][4H][Kp],
+    int64_t xkp;                             // h_t planes [3][T*B][Kp] per layer; Kp = H rounded up to 64 (0: H > 1024, no images)
     size_t bytes;
 };
 
@@ -259,6 +265,11 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     w.err = c.take<int>(4);
     w.psync_a = c.take<unsigned int>(lstm_persist_sync_bytes() / sizeof(unsigned int));
     w.psync_b = c.take<unsigned int>(lstm_persist_sync_bytes() / sizeof(unsigned int));
+    w.xkp = (H <= 1024) ? (int64_t)((H + 63) / 64 * 64) : 0;
+    w.xw1 = c.take<unsigned short>(3 * 4 * H * w.xkp);
+    w.xw2 = c.take<unsigned short>(3 * 4 * H * w.xkp);
+    w.xh1 = c.take<unsigned short>(3 * T * B * w.xkp);
+    w.xh2 = c.take<unsigned short>(3 * T * B * w.xkp);
     // backward-only scratch (two of everything that the two concurrently running layers touch)
     w.wt1 = c.take<float>(H * 4 * H);
     w.wt2 = c.take<float>(H * 4 * H);
@@ -616,6 +627,33 @@ static int persist_mode() {
 }
 static bool persist_on() { return persist_mode() >= 1; }
 static bool persist_f32_on() { return persist_mode() >= 2; }
+// the fp32 persistent kernels per direction (experiments: S2VT_PERSIST_F32_FWD / S2VT_PERSIST_F32_BWD = 0 | 1 override mode 2's "both")
+static bool persist_f32_dir_on(int dir) {
+    static int ov[2] = {-2, -2};
+    if (ov[dir] == -2) { const char* e = getenv(dir ? "S2VT_PERSIST_F32_BWD" : "S2VT_PERSIST_F32_FWD"); ov[dir] = e ? atoi(e) : -1; }
+    return ov[dir] >= 0 ? ov[dir] > 0 : persist_f32_on();
+}
+// split-precision persistent forward for the fp32-equivalent arithmetic (gemm mode 3): S2VT_PERSIST_X3_FWD = 0 | 1
+static bool persist_x3_fwd_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("S2VT_PERSIST_X3_FWD"); on = e ? (atoi(e) != 0) : 1; }
+    return on && persist_on();
+}
+static SeqFwdX3Args persist_fwd_x3_args(int t0, int t1, int B, int H, int T, int64_t Kp, float* gx_stash, int n_gx, const float* bias,
+                                        const unsigned short* wp, unsigned short* hp, float* h_all, float* c_all,
+                                        unsigned int* sync, int* err) {
+    SeqFwdX3Args a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.H = H; a.Kp = (int)Kp; a.t0 = t0; a.t1 = t1; a.n_gx = n_gx;
+    a.wp = wp; a.wplane = 4 * (int64_t)H * Kp; a.ldw = Kp;
+    a.hp = hp; a.hplane = (int64_t)T * B * Kp; a.ldh = Kp;
+    a.h_all = h_all; a.gx_stash = gx_stash; a.bias = bias; a.c_all = c_all;
+    a.sync = sync; a.err = err;
+#ifdef S2VT_EXPERIMENT_STAMPS
+    a.stamps = g_xstamps; a.stamp_block = g_xstamp_block;
+#endif
+    return a;
+}
 static bool persist_fwd_ok(int B, int H, const PB& wb, const PB& hb) {
     return persist_on() && lstm_seq_fwd_bf16_persist_supported(B, H, hb.kpad) && hb.kpad == wb.kpad;
 }
@@ -744,6 +782,11 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
     }
     if ((rc = handoff(st, sx, ev++))) return rc;
     if (bf && (rc = pdual(lb, p->word_w_hh, H, ID, 4 * H, H, &q.whh2, 0, &q.whh2T, 0, nullptr))) return rc;
+    const bool px3_fwd = !bf && XP == 3 && blk > 0 && w.xkp > 0 && persist_x3_fwd_on() && lstm_seq_fwd_x3_persist_supported(B, H);
+    if (px3_fwd) {   // W_hh of both layers as row-major planes for the persistent split-precision recurrence
+        if ((rc = split3_rows(sx, p->vid_w_hh, H, 4 * H, H, (int)w.xkp, w.xw1, 4 * (int64_t)H * w.xkp))) return rc;
+        if ((rc = split3_rows(sx, p->word_w_hh, H, 4 * H, H, (int)w.xkp, w.xw2, 4 * (int64_t)H * w.xkp))) return rc;
+    }
     // lane B: word_rnn / out_linear weights and the embedded caption words as planes; embedded-word half of gx2
     // (row planes for this forward, transposed planes for the coming backward: one read of each tensor)
     if ((rc = pdual(lb, p->word_w_ih, E + H, ID, 4 * H, E, &q.we, 0, &q.weT, 0, nullptr))) return rc;
@@ -759,22 +802,31 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
     if ((rc = pdual(la, w.x1, H, ID, L * B, H, &q.x1, 0, &q.x1T, 0, nullptr))) return rc;
     if ((rc = pgemm(la, L * B, 4 * H, H, q.x1, 0, 0, q.wih1, 0, 0, w.s1, 4 * H, ID, w.bsum1, false))) return rc;
     const bool pbf_fwd = bf && blk > 0 && persist_fwd_ok(B, H, q.whh1, q.h1);
-    const std::vector<int> bd = pipe_bounds(T, L, pbf_fwd ? balanced_block(L, blk) : blk);
-    if (!bf && blk > 0 && persist_f32_on() && lstm_seq_fwd_f32_persist_supported(B, H)) {
-        // fp32 persistent schedule (lstm_persist_f32.hip), ONE stream: stage k = vid_rnn block k next to word_rnn block k-1
+    const std::vector<int> bd = pipe_bounds(T, L, (pbf_fwd || px3_fwd) ? balanced_block(L, blk) : blk);
+    if (px3_fwd || (!bf && blk > 0 && persist_f32_dir_on(0) && lstm_seq_fwd_f32_persist_supported(B, H))) {
+        // fp32-equivalent persistent schedule (lstm_persist_x3.hip: split precision on the bf16 matrix cores; lstm_persist_f32.hip:
+        // exact-fp32 MFMA), ONE stream: stage k = vid_rnn block k next to word_rnn block k-1
         if ((rc = handoff(sx, st, ev++))) return rc;
         const int nb = (int)bd.size() - 1;
         for (int k = 0; k <= nb; ++k) {
             const bool hv = k < nb, hw = k >= 1;
-            SeqFwdF32Args av, aw;
-            if (hv) av = persist_fwd_f32_args(bd[k], bd[k + 1], B, H, w.s1, L, w.bsum1, p->vid_w_hh, w.h1, w.c1, w.psync_a, w.err + 1);
-            if (hw) aw = persist_fwd_f32_args(bd[k - 1], bd[k], B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, w.psync_b, w.err + 1);
             {
-                ProfScope ps(st, K_STEP_FWD, (hv ? bd[k + 1] - bd[k] : 0) + (hw ? bd[k] - bd[k - 1] : 0));
+            ProfScope ps(st, K_STEP_FWD, (hv ? bd[k + 1] - bd[k] : 0) + (hw ? bd[k] - bd[k - 1] : 0));
+            if (px3_fwd) {
+                SeqFwdX3Args av, aw;
+                if (hv) av = persist_fwd_x3_args(bd[k], bd[k + 1], B, H, T, w.xkp, w.s1, L, w.bsum1, w.xw1, w.xh1, w.h1, w.c1, w.psync_a, w.err + 1);
+                if (hw) aw = persist_fwd_x3_args(bd[k - 1], bd[k], B, H, T, w.xkp, w.s2, T, w.bsum2, w.xw2, w.xh2, w.h2, w.c2, w.psync_b, w.err + 1);
+                if (hv && hw) rc = lstm_seq_fwd_x3_persist2(st, av, &aw);
+                else rc = lstm_seq_fwd_x3_persist2(st, hv ? av : aw, nullptr);
+            } else {
+                SeqFwdF32Args av, aw;
+                if (hv) av = persist_fwd_f32_args(bd[k], bd[k + 1], B, H, w.s1, L, w.bsum1, p->vid_w_hh, w.h1, w.c1, w.psync_a, w.err + 1);
+                if (hw) aw = persist_fwd_f32_args(bd[k - 1], bd[k], B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, w.psync_b, w.err + 1);
                 if (hv && hw) rc = lstm_seq_fwd_f32_persist2(st, av, &aw);
                 else rc = lstm_seq_fwd_f32_persist2(st, hv ? av : aw, nullptr);
-                if (rc) return rc;
             }
+            }
+            if (rc) return rc;
             if (hw) {
                 const int t0 = bd[k - 1], t1 = bd[k];
                 const bool cap = t0 >= L;
@@ -892,7 +944,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     const bool pbf_bwd = bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad;
     const std::vector<int> bd = pipe_bounds(T, L, pbf_bwd ? balanced_block(L, blk) : blk);
-    if (!bf && blk > 0 && persist_f32_on() && lstm_seq_bwd_f32_persist_supported(B, H)) {
+    if (!bf && blk > 0 && persist_f32_dir_on(1) && lstm_seq_bwd_f32_persist_supported(B, H)) {
         // fp32 persistent schedule, ONE stream: stage k = word_rnn BPTT of block k next to vid_rnn BPTT of block k+1
         if ((rc = handoff(sx, st, ev++))) return rc;               // W_hh1^T and the out_linear gradients of lane B
         const int nb = (int)bd.size() - 1;
@@ -1925,6 +1977,24 @@ int s2vt_lstm_seq_bwd_bf16_pair(int32_t T, int32_t B, int32_t H, const float* w_
 extern "C" int s2vt_experiment_set_stamps(unsigned long long* buf, int block) { g_xstamps = buf; g_xstamp_block = block; return 0; }
 #endif
 
+// Which recurrence kernels the whole-path train drivers would run for (B, H) in the current modes:
+// 0 = one launch per timestep, 1 = persistent bf16, 2 = persistent exact-fp32 MFMA, 3 = persistent split precision.
+int s2vt_recurrence_plan(int32_t B, int32_t H, int32_t* fwd, int32_t* bwd) {
+    S2VT_REQUIRE(B > 0 && H > 0 && fwd && bwd, "s2vt_recurrence_plan: bad arguments");
+    *fwd = *bwd = 0;
+    const int gm = gemm_mode();
+    if (pipe_block() <= 0 || gm == 0 || B % 64 != 0) return 0;     // (the plane drivers run at B % 64 == 0 in gemm modes 1 and 3)
+    if (gm == 1) {
+        if (persist_on() && lstm_seq_fwd_bf16_persist_supported(B, H, pad64(H))) *fwd = 1;
+        if (persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, pad64(4 * H))) *bwd = 1;
+        return 0;
+    }
+    if (H <= 1024 && persist_x3_fwd_on() && lstm_seq_fwd_x3_persist_supported(B, H)) *fwd = 3;
+    else if (persist_f32_dir_on(0) && lstm_seq_fwd_f32_persist_supported(B, H)) *fwd = 2;
+    if (persist_f32_dir_on(1) && lstm_seq_bwd_f32_persist_supported(B, H)) *bwd = 2;
+    return 0;
+}
+
 int s2vt_set_recurrence_mode(int32_t mode) {
     const int prev = persist_mode();
     if (mode >= 0) g_persist = mode > 2 ? 2 : mode;
@@ -1958,6 +2028,48 @@ int s2vt_lstm_seq_fwd_persist(int32_t T, int32_t B, int32_t H, float* gx_stash0,
         SeqFwdF32Args a1;
         if (two) a1 = persist_fwd_f32_args(t0, t1, B, H, gx_stash1, n_gx, bias1, w_hh1, h_all1, c_all1, sb, err);
         if ((rc = lstm_seq_fwd_f32_persist2(st, a0, two ? &a1 : nullptr))) return rc;
+    }
+    return 0;
+}
+// split-precision persistent forward (lstm_persist_x3.hip) as its own entry point.
+// workspace: [err int x64][sync A][sync B][W planes 0][W planes 1][h planes 0][h planes 1]
+size_t s2vt_lstm_seq_x3_workspace_bytes(int32_t T, int32_t B, int32_t H) {
+    if (T <= 0 || B <= 0 || H <= 0 || H > 1024) return 0;
+    const size_t Kp = (size_t)(H + 63) / 64 * 64;
+    return 256 + 2 * lstm_persist_sync_bytes() + 2 * align_up(3 * 4 * (size_t)H * Kp * 2, 256) + 2 * align_up(3 * (size_t)T * B * Kp * 2, 256);
+}
+int s2vt_lstm_seq_fwd_x3_persist(int32_t T, int32_t B, int32_t H, float* gx_stash0, float* gx_stash1, int32_t n_gx,
+                                 const float* bias0, const float* bias1, const float* w_hh0, const float* w_hh1, float* h_all0,
+                                 float* h_all1, float* c_all0, float* c_all1, int32_t block, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    S2VT_REQUIRE(T > 0 && B > 0 && H > 0 && gx_stash0 && w_hh0 && h_all0 && c_all0 && workspace && n_gx >= 0 && n_gx <= T &&
+                     (n_gx == T || bias0), "s2vt_lstm_seq_fwd_x3_persist: bad arguments");
+    S2VT_REQUIRE(H <= 1024 && lstm_seq_fwd_x3_persist_supported(B, H), "s2vt_lstm_seq_fwd_x3_persist: shape not supported");
+    S2VT_REQUIRE(workspace_bytes >= s2vt_lstm_seq_x3_workspace_bytes(T, B, H), "s2vt_lstm_seq_fwd_x3_persist: workspace too small");
+    const bool two = gx_stash1 != nullptr;
+    S2VT_REQUIRE(!two || (w_hh1 && h_all1 && c_all1 && (n_gx == T || bias1)), "s2vt_lstm_seq_fwd_x3_persist: second layer incomplete");
+    const int64_t Kp = (H + 63) / 64 * 64;
+    const size_t wbytes = align_up(3 * 4 * (size_t)H * Kp * 2, 256), hbytes = align_up(3 * (size_t)T * B * Kp * 2, 256);
+    char* base = reinterpret_cast<char*>(workspace);
+    int* err = reinterpret_cast<int*>(base);
+    unsigned int* sa = reinterpret_cast<unsigned int*>(base + 256);
+    unsigned int* sb = reinterpret_cast<unsigned int*>(base + 256 + lstm_persist_sync_bytes());
+    char* q = base + 256 + 2 * lstm_persist_sync_bytes();
+    unsigned short* wp[2] = {reinterpret_cast<unsigned short*>(q), reinterpret_cast<unsigned short*>(q + wbytes)};
+    unsigned short* hp[2] = {reinterpret_cast<unsigned short*>(q + 2 * wbytes), reinterpret_cast<unsigned short*>(q + 2 * wbytes + hbytes)};
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = fill_zero(st, err, 256))) return rc;
+    if ((rc = split3_rows(st, w_hh0, H, 4 * H, H, (int)Kp, wp[0], 4 * (int64_t)H * Kp))) return rc;
+    if (two && (rc = split3_rows(st, w_hh1, H, 4 * H, H, (int)Kp, wp[1], 4 * (int64_t)H * Kp))) return rc;
+    const int blk = block > 0 ? block : T;
+    for (int t0 = 0; t0 < T; t0 += blk) {
+        const int t1 = (t0 + blk < T) ? t0 + blk : T;
+        ProfScope ps(st, K_STEP_FWD, (two ? 2 : 1) * (t1 - t0));
+        const SeqFwdX3Args a0 = persist_fwd_x3_args(t0, t1, B, H, T, Kp, gx_stash0, n_gx, bias0, wp[0], hp[0], h_all0, c_all0, sa, err);
+        SeqFwdX3Args a1;
+        if (two) a1 = persist_fwd_x3_args(t0, t1, B, H, T, Kp, gx_stash1, n_gx, bias1, wp[1], hp[1], h_all1, c_all1, sb, err);
+        if ((rc = lstm_seq_fwd_x3_persist2(st, a0, two ? &a1 : nullptr))) return rc;
     }
     return 0;
 }

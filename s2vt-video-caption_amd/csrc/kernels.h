@@ -166,6 +166,21 @@ struct SeqFwdF32Args {
 };
 int lstm_seq_fwd_f32_persist_supported(int B, int H);
 int lstm_seq_fwd_f32_persist2(hipStream_t stream, SeqFwdF32Args a, const SeqFwdF32Args* b);
+// split-precision (three bf16 planes per operand, six plane products: fp32-equivalent) persistent forward, lstm_persist_x3.hip
+struct SeqFwdX3Args {
+    int B, H, Kp;                                   // Kp = H rounded up to 64 (<= 1024): row length of the plane images
+    int t0, t1, n_gx;
+    const unsigned short* wp; int64_t wplane, ldw;  // W_hh as planes [3][4H][ldw] (split3_rows; columns >= H zero)
+    unsigned short* hp; int64_t hplane, ldh;        // h_t as planes [3][T*B][ldh], time-major: the hand-off payload
+    float* h_all;                                   // [T*B][H] fp32 h_t (output only)
+    float* gx_stash; const float* bias; float* c_all;
+    unsigned int* sync; int* err;
+    int RB, NS;                                     // set by the launcher
+    unsigned long long* stamps; int stamp_block;    // timing experiments only (experiment.h); null in the product
+};
+int lstm_seq_fwd_x3_persist_supported(int B, int H);
+int lstm_seq_fwd_x3_persist2(hipStream_t stream, SeqFwdX3Args a, const SeqFwdX3Args* b);
+int split3_rows(hipStream_t stream, const float* src, int64_t ld, int R, int C, int Cp, unsigned short* dst, int64_t plane);
 struct SeqBwdF32Args {
     int B, H;                                       // H % 4 == 0, H <= 1024
     int T, t0, t1;

@@ -1,0 +1,463 @@
+// Persistent SPLIT-PRECISION LSTM forward recurrence for gfx950 (BASELINE config 2: B = 64, fp32-equivalent arithmetic):
+// the third member of the family lstm_persist.hip (bf16) / lstm_persist_f32.hip (exact-fp32 MFMA).  One launch runs a block of
+// timesteps of one layer - or of both layers side by side (S2VTModel.py:67 / :77 -> nn.LSTM over the steps) - with every
+// workgroup's slice of W_hh resident in registers and the same cross-workgroup hand-off protocol.
+//
+// Arithmetic.  The contraction h_{t-1} . W_hh^T runs on the bf16 matrix cores in the split-precision form of gemm_x3.hip:
+// both operands are three bf16 planes (x = p0 + p1 + p2, 24 mantissa bits) and the six plane products >= 2^-16 are summed in the
+// fp32 accumulator (h0w0, h0w1, h1w0, h1w1, h0w2, h2w0): fp32-equivalent (error of the fp32-MFMA kernel) at 6/16 of the exact-fp32
+// MFMA's cycles - the exact-fp32 persistent kernel is MFMA-bound (4.6 us of K loop in an 8.6-us timestep).
+//
+// Decomposition.  Workgroup (rg, cs) = 32-row chains x 16 hidden units (64 gate columns {i,f,g,o} x 16: complete cells), FOUR
+// waves, ONE workgroup per compute unit: W_hh[64 gate columns][K] as three planes is 384 KB - three quarters of the CU's register
+// file - so a wave owns a k QUARTER (256 k) of both 32-column halves: 96 B operands of v_mfma_f32_32x32x16_bf16 = 384 registers
+// (arch + accumulation VGPRs; one wave per SIMD may use all 512).  Each wave streams ITS k quarter of the three h_{t-1} plane
+// images (32 rows x 256 k x 3 planes = 48 KB per sub-step) through a private 3-slot LDS ring of 12-KB chunks (k64 x 3 planes;
+// LDS-DMA, XOR-swizzled like the bf16 kernel's image): the contraction has no workgroup barrier, three A-fragment reads feed
+// twelve MFMAs, the reads of k16 step i+1 and the next chunk's requests are issued between the MFMA groups (one wave per SIMD
+// issues in order: nothing may sit in a burst in front of the matrix pipe).  192 MFMAs per wave and sub-step = 6144 cycles,
+// against 3 us of ingest (192 KB per sub-step at ~65 GB/s per CU).
+// Hand-off: the epilogue (two adjacent cells per thread) splits h_t into planes; the three 32 x 32-B tiles leave as three 16-byte
+// write-through (sc1) store instructions of wave 0, which drains and adds 1 to the chain's counter; consumers poll (bounded spin),
+// barrier, then sc1 LDS-DMA loads; every step's image has its own address (see lstm_persist.hip for the protocol's argument).
+#include <stdlib.h>
+#include "common.h"
+#include "experiment.h"
+#include "kernels.h"
+
+namespace s2vt {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) unsigned int gu32;
+
+constexpr int X_SR = 32;                          // batch rows per sub-step (= per chain)
+constexpr int X_UN = 16;                          // hidden units per workgroup (64 gate columns)
+constexpr int X_NT = 256;                         // 4 waves = 4 k quarters
+constexpr int X_PLANE = X_SR * 128;               // one plane of a k64 chunk: 32 rows x 128 B
+constexpr int X_CHUNK = 3 * X_PLANE;              // 12 KB
+constexpr int X_RING = 3 * X_CHUNK;               // per-wave ring: 3 slots
+constexpr int X_RLD = 72;                         // row stride of a partial-sum tile (floats): conflict-free f32x2 epilogue reads
+constexpr int X_HSM = 4 * X_RING;                 // bf16 h_t planes [3][32][16]
+constexpr int X_MAXNS = 4;
+constexpr int X_CST = X_HSM + 3 * X_SR * X_UN * 2;        // fp32 c_t of the workgroup's cells, per chain [32][16]
+constexpr int X_LDS = X_CST + X_MAXNS * X_SR * X_UN * 4;  // 158720 B
+constexpr int X_MAX_WG = 256;                     // design point: one workgroup per CU; capped by coresident_capacity() at launch
+constexpr unsigned long long X_SPIN_TICKS = 100000000ull;      // 1 s of the 100-MHz wall clock
+
+__device__ __forceinline__ void glds16x_sc1(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 16 /* sc1 */);
+}
+__device__ __forceinline__ bool spin_until_x(const unsigned int* cnt, unsigned int target) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        const unsigned int v = __hip_atomic_load((gu32*)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v >= target) return true;
+        if (__builtin_amdgcn_s_memrealtime() - t0 > X_SPIN_TICKS) return false;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+#define X_DSR(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF))
+#define X_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+__device__ __forceinline__ void seq_fwd_x3_body(const SeqFwdX3Args& p, const int bid, unsigned char* smem, int& s_flag) {
+    const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int kq = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index = k quarter (scalar: LDS-DMA targets, k offsets)
+    const int li = lane & 31, lh = lane >> 5;
+    const int H = p.H, B = p.B, Kp = p.Kp;
+    const int nC = (H + X_UN - 1) / X_UN;
+    const int cs = bid % nC, rg = bid / nC;
+    const int u0 = cs * X_UN, row0 = rg * p.RB;
+    const int k0 = kq * 256;                            // this wave's k quarter [k0, k0 + 256)
+    const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero4);
+
+    // ---- this wave's W_hh slice: wreg[(plane * 2 + cw) * 16 + j] = B operand of (plane, 32-column half cw, k16 step j);
+    //      gate column n = g*8 + uu of half cw <-> W_hh row g*H + (u0 + 8 cw + uu)
+    bf16x8 wreg[96];
+    {
+        const int g = li >> 3;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int cw = 0; cw < 2; ++cw) {
+                const int unit = u0 + cw * 8 + (li & 7);
+                const unsigned short* wrow = p.wp + pl * p.wplane + ((int64_t)g * H + unit) * p.ldw + k0 + lh * 8;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const unsigned short* q = (unit < H && k0 + 16 * j < Kp) ? wrow + 16 * j : zero;
+                    wreg[(pl * 2 + cw) * 16 + j] = *reinterpret_cast<const bf16x8*>(q);
+                }
+            }
+        // the slice is complete in registers before the step loop (otherwise the waits for these loads land inside it)
+#pragma unroll
+        for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wreg[i]));
+#pragma unroll
+        for (int i = 32; i < 96; ++i) asm volatile("" : "+a"(wreg[i]));
+    }
+
+    // ---- loader role (each wave for itself): piece (plane, i) of a chunk = rows 8i..8i+7 x 128 B; lane -> (row, swizzled piece)
+    unsigned voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3);
+        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        voff[i] = (unsigned)(r * (p.ldh * 2) + q * 16);
+    }
+    unsigned char* ring = smem + kq * X_RING;
+    // ---- A-fragment read address of lane (row li, k half lh) for k16 step s of a chunk: piece 2s + lh
+    unsigned fa[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) fa[s] = lbase + (unsigned)(kq * X_RING + li * 128 + (((2 * s + lh) ^ ((li >> 1) & 7)) * 16));
+
+    // ---- epilogue role: 2 adjacent units of one row per thread, the same (row, units) in every step
+    const int erow = tid >> 3, eul = (tid & 7) * 2;
+    const int eunit = u0 + eul;
+    const bool e_ok0 = eunit < H, e_ok1 = eunit + 1 < H;
+    const bool e_vec = e_ok1 && ((H & 1) == 0);
+    const int ecol = (eul >> 3) * 32 + (eul & 7);      // + g*8: column of gate g inside the workgroup's 64
+    float* cst = reinterpret_cast<float*>(smem + X_CST);
+    for (int s = 0; s < p.NS; ++s) {
+        const int b = row0 + s * X_SR + erow;
+        f32x2 c0 = {0.f, 0.f};
+        if (p.t0 > 0 && b < B) {
+            const float* q = p.c_all + ((int64_t)(p.t0 - 1) * B + b) * H + eunit;
+            if (e_ok0) c0[0] = q[0];
+            if (e_ok1) c0[1] = q[1];
+        }
+        *reinterpret_cast<f32x2*>(cst + (s * X_SR + erow) * X_UN + eul) = c0;
+    }
+    unsigned short* hsm = reinterpret_cast<unsigned short*>(smem + X_HSM);
+    const int64_t H4 = 4 * (int64_t)H;
+    const unsigned char* zsrc = reinterpret_cast<const unsigned char*>(g_zero4);
+    const int64_t hplane_b = p.hplane * 2;             // bytes between two planes of the h image
+
+    for (int t = p.t0; t < p.t1; ++t) {
+#pragma unroll 1
+        for (int s = 0; s < p.NS; ++s) {
+            const int rbase = row0 + s * X_SR;
+            unsigned int* cnt = p.sync + (rg * X_MAXNS + s) * 32;
+            const int xrec = (bid == p.stamp_block) ? (t - p.t0) * p.NS + s : -1;
+            XSTAMP(p.stamps, xrec, 0);
+            if (t > p.t0) {          // h_{t-1} of this chain published by every column slice of the row group?
+                if (tid == 0) {
+                    const bool ok = spin_until_x(cnt, (unsigned int)(nC * t));
+                    s_flag = ok ? 1 : 0;
+                    if (!ok) atomicExch(p.err, 1);
+                }
+                X_BARRIER();
+                if (s_flag == 0) return;
+            }
+            XSTAMP(p.stamps, xrec, 1);
+
+            // epilogue operands requested now, consumed after the contraction
+            const int eb = rbase + erow;
+            const bool rok = eb < B;
+            f32x2 gxv[4];
+            {
+                const float* gsrc = (t < p.n_gx) ? p.gx_stash + ((int64_t)t * B + eb) * H4 : p.bias;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float* q = gsrc + (int64_t)g * H + eunit;
+                    if (e_vec) {
+                        gxv[g] = *reinterpret_cast<const f32x2*>(rok ? q : g_zero4);
+                    } else {
+                        gxv[g][0] = *((rok && e_ok0) ? q : g_zero4);
+                        gxv[g][1] = *((rok && e_ok1) ? q + 1 : g_zero4);
+                    }
+                }
+            }
+
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+            if (t > 0) {
+                const unsigned char* abase = reinterpret_cast<const unsigned char*>(p.hp + ((int64_t)(t - 1) * B + rbase) * p.ldh);
+                // chunk C of this wave = k64 block 4 kq + C of all three planes: 12 requests; a block past Kp reads zeros, so
+                // that every wave issues the same number of requests (counted waits)
+                // request N (plane N / 4, row octet N % 4) of chunk C
+#define X_REQ(C, N)                                                                                             \
+                glds16x_sc1((4 * kq + (C)) * 64 < Kp ? abase + (4 * kq + (C)) * 128 + ((N) / 4) * hplane_b + voff[(N) % 4] : zsrc, \
+                            ring + ((C) % 3) * X_CHUNK + ((N) / 4) * X_PLANE + ((N) % 4) * 1024);
+#define X_ISSUE(C)                                                                                              \
+                X_REQ(C, 0) X_REQ(C, 1) X_REQ(C, 2) X_REQ(C, 3) X_REQ(C, 4) X_REQ(C, 5)                         \
+                X_REQ(C, 6) X_REQ(C, 7) X_REQ(C, 8) X_REQ(C, 9) X_REQ(C, 10) X_REQ(C, 11)
+                // A fragment of plane PL for k16 step I (chunk I / 4 in slot (I / 4) % 3)
+#define X_RD1(PL, I) X_DSR(af[PL], fa[(I) & 3], (((I) >> 2) % 3) * X_CHUNK + (PL) * X_PLANE);
+#define X_WAIT1(PL, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(af[PL]));
+#define X_MF(A, W, ACC) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, W, ACC, 0, 0, 0);
+                // k16 step I: the six plane products for both column halves, small terms first.  ONE fragment set: a plane's
+                // fragment of step I + 1 is requested as soon as its last product of step I is issued (h2 after 2 MFMAs, h1
+                // after 6, h0 after 12); the 6 MFMAs in front of the first use of h0 cover its LDS latency.  Reads return in
+                // order, so a fragment has landed when at most the two younger reads are outstanding.
+#define X_MM2(I)  X_WAIT1(2, 2) X_MF(af[2], wreg[0 * 16 + (I)], acc0) X_MF(af[2], wreg[1 * 16 + (I)], acc1)
+#define X_MM1(I)  X_MM1N(I, 2)
+#define X_MM1N(I, N) X_WAIT1(1, N) X_MF(af[1], wreg[2 * 16 + (I)], acc0) X_MF(af[1], wreg[3 * 16 + (I)], acc1)                \
+                                X_MF(af[1], wreg[0 * 16 + (I)], acc0) X_MF(af[1], wreg[1 * 16 + (I)], acc1)
+#define X_MM0(I)  X_WAIT1(0, 2) X_MF(af[0], wreg[4 * 16 + (I)], acc0) X_MF(af[0], wreg[5 * 16 + (I)], acc1)                \
+                                X_MF(af[0], wreg[2 * 16 + (I)], acc0) X_MF(af[0], wreg[3 * 16 + (I)], acc1)                \
+                                X_MF(af[0], wreg[0 * 16 + (I)], acc0) X_MF(af[0], wreg[1 * 16 + (I)], acc1)
+#define X_STEP(I) X_MM2(I) X_RD1(2, (I) + 1) X_MM1(I) X_RD1(1, (I) + 1) X_MM0(I) X_RD1(0, (I) + 1)
+                // the same with three LDS-DMA requests of chunk C slipped between the MFMA groups: a request costs ~100 issue
+                // cycles (36 in a burst in front of the loop were 1.6 us of a 8.5-us sub-step); behind an MFMA group they are free
+#define X_STEP_REQ(I, C)                                                                                        \
+                X_MM2(I) X_RD1(2, (I) + 1) X_REQ(C, 3 * ((I) & 3))                                              \
+                X_MM1(I) X_RD1(1, (I) + 1) X_REQ(C, 3 * ((I) & 3) + 1)                                          \
+                X_MM0(I) X_RD1(0, (I) + 1) X_REQ(C, 3 * ((I) & 3) + 2)
+#define X_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");
+                bf16x8 af[3];
+                X_ISSUE(0) X_ISSUE(1)
+                XSTAMP(p.stamps, xrec, 2);
+                X_VM(12)
+                X_RD1(2, 0) X_RD1(1, 0) X_RD1(0, 0)
+                XSTAMP(p.stamps, xrec, 3);
+                // chunk 0 (slot 0); chunk 2 -> slot 2 on the way
+                X_STEP_REQ(0, 2) X_STEP_REQ(1, 2) X_STEP_REQ(2, 2)
+                X_VM(9)                  // chunk 1 landed (9 requests of chunk 2 are younger) before step 4's fragments are read
+                X_STEP_REQ(3, 2)
+                // chunk 1; slot 0 is read out (step 3's last fragment was awaited in front of its MFMAs): chunk 3 takes it
+                X_STEP_REQ(4, 3) X_STEP_REQ(5, 3) X_STEP_REQ(6, 3)
+                X_VM(9)                  // chunk 2 landed
+                X_STEP_REQ(7, 3)
+                X_STEP(8) X_STEP(9) X_STEP(10)
+                X_VM(0)                  // chunk 3 landed
+                X_STEP(11)
+                X_STEP(12) X_STEP(13) X_STEP(14)
+                X_MM2(15) X_MM1N(15, 1)      // (no younger reads behind the last step's)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(af[0]));
+                X_MF(af[0], wreg[4 * 16 + 15], acc0) X_MF(af[0], wreg[5 * 16 + 15], acc1)
+                X_MF(af[0], wreg[2 * 16 + 15], acc0) X_MF(af[0], wreg[3 * 16 + 15], acc1)
+                X_MF(af[0], wreg[0 * 16 + 15], acc0) X_MF(af[0], wreg[1 * 16 + 15], acc1)
+#undef X_VM
+#undef X_STEP_REQ
+#undef X_STEP
+#undef X_MM0
+#undef X_MM1
+#undef X_MM1N
+#undef X_MM2
+#undef X_WAIT1
+#undef X_RD1
+#undef X_STEP
+#undef X_MM
+#undef X_MF
+#undef X_WAIT
+#undef X_RD
+#undef X_ISSUE
+#undef X_REQ
+            }
+            XSTAMP(p.stamps, xrec, 4);
+            {   // partial tile of this wave's k quarter -> its own (idle) ring
+                float* rp = reinterpret_cast<float*>(ring);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    rp[row * X_RLD + li] = acc0[r];
+                    rp[row * X_RLD + 32 + li] = acc1[r];
+                }
+            }
+            X_BARRIER();
+            XSTAMP(p.stamps, xrec, 5);
+
+            f32x2 gate[4], cv, hv;
+            {
+                f32x2 pre[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x2 v = gxv[g];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        v += *reinterpret_cast<const f32x2*>(reinterpret_cast<const float*>(smem + w * X_RING) + erow * X_RLD + ecol + g * 8);
+                    pre[g] = v;
+                }
+                f32x2* cp = reinterpret_cast<f32x2*>(cst + (s * X_SR + erow) * X_UN + eul);
+                const f32x2 cprev = *cp;
+                unsigned short pb[2][3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    gate[0][j] = sigmoidf_(pre[0][j]);
+                    gate[1][j] = sigmoidf_(pre[1][j]);
+                    gate[2][j] = tanhf_(pre[2][j]);
+                    gate[3][j] = sigmoidf_(pre[3][j]);
+                    const bool ok = rok && (j ? e_ok1 : e_ok0);
+                    cv[j] = ok ? gate[1][j] * cprev[j] + gate[0][j] * gate[2][j] : 0.f;
+                    hv[j] = ok ? gate[3][j] * tanhf_(cv[j]) : 0.f;
+                    split3_bits(hv[j], pb[j]);
+                }
+                *cp = cv;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    *reinterpret_cast<unsigned int*>(hsm + pl * (X_SR * X_UN) + erow * X_UN + eul) =
+                        (unsigned int)pb[0][pl] | ((unsigned int)pb[1][pl] << 16);
+            }
+            XSTAMP(p.stamps, xrec, 6);
+            X_BARRIER();
+            if (kq == 0) {   // the h_t planes: three tiles of 32 rows x 32 B = three 16-byte write-through store instructions,
+                             // issued first: they are what the other workgroups wait for
+                const int rl = lane >> 1, part = lane & 1;
+                unsigned short* dst = p.hp + ((int64_t)t * B + rbase + rl) * p.ldh + u0 + part * 8;
+                if (rbase + rl < B) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(hsm + pl * (X_SR * X_UN) + rl * X_UN + part * 8);
+                        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst + pl * p.hplane), "v"(v) : "memory");
+                    }
+                    if (cs == nC - 1) {     // the last column slice keeps the pad columns [16 nC, Kp) of the image at zero
+                        const u32x4 z = {0u, 0u, 0u, 0u};
+                        unsigned short* zd = dst;
+                        asm volatile("" : "+v"(zd));          // (opaque: derived from the payload address, nothing to keep live)
+                        for (int c = u0 + X_UN; c < Kp; c += X_UN) {
+                            zd += X_UN;
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl)
+                                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(zd + pl * p.hplane), "v"(z) : "memory");
+                        }
+                    }
+                }
+            }
+            XSTAMP(p.stamps, xrec, 7);
+            if (kq == 0) {   // the ONE wave that stored the hand-off payload drains (those three stores only: its other stores
+                             // of the step come after the signal) and signals for the workgroup
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                XSTAMP(p.stamps, xrec, 8);
+                if (lane == 0) __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            XSTAMP(p.stamps, xrec, 9);
+            if (rok) {
+                const int64_t rowi = (int64_t)t * B + eb;
+                float* cdst = p.c_all + rowi * H + eunit;
+                float* hdst = p.h_all + rowi * H + eunit;
+                float* st = p.gx_stash + rowi * H4 + eunit;
+                if (e_vec) {
+                    *reinterpret_cast<f32x2*>(cdst) = cv;
+                    *reinterpret_cast<f32x2*>(hdst) = hv;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x2*>(st + (int64_t)g * H) = gate[g];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (j ? e_ok1 : e_ok0) {
+                            cdst[j] = cv[j];
+                            hdst[j] = hv[j];
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) st[(int64_t)g * H + j] = gate[g][j];
+                        }
+                }
+            }
+            X_BARRIER();       // hsm / cst / partial sums are free again
+        }
+    }
+}
+
+// xg == 0: grid = [na workgroups of layer pa | workgroups of layer pb] (nb may be 0).
+// xg = G > 0 (XCD-aware; both layers of one shape): the hardware deals workgroup b to XCD b % 8 (speed only - nothing depends on
+// it for correctness); a GROUP is the nC column slices of one (layer, row group) - the workgroups that exchange one chain's h_t
+// tiles - and group g is dealt to the XCDs {g, g + G, ..}: a consumer's sc1 loads then find the tile in the L2 its producers
+// wrote through, and a row's lines enter 8 / G L2s instead of all eight.  The grid is 8 * ceil(nC / (8 / G)) blocks; the few
+// whose slice index falls past nC exit at once (nobody waits for them: the counters count the nC real slices).
+__global__ __launch_bounds__(X_NT, 1) void lstm_seq_fwd_x3_persist_kernel(SeqFwdX3Args pa, SeqFwdX3Args pb, int na, int xg) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[X_LDS];
+    __shared__ int s_flag;
+    const int bid = (int)blockIdx.x;
+    bool lb;
+    int vb;
+    if (xg > 0) {
+        const int nC = (pa.H + X_UN - 1) / X_UN;
+        const int x = bid & 7, q = bid >> 3, per = 8 / xg;
+        const int g = x % xg, cs = q * per + x / xg;
+        if (cs >= nC) return;
+        const int rgs = na / nC;                     // row groups of layer A
+        lb = g >= rgs;
+        vb = (lb ? g - rgs : g) * nC + cs;
+    } else {
+        lb = bid >= na;
+        vb = lb ? bid - na : bid;
+    }
+    // ONE copy of the body: the layer's arguments are selected field by field (scalar selects on kernel arguments)
+    seq_fwd_x3_body(lb ? pb : pa, vb, smem, s_flag);
+}
+
+size_t lstm_persist_sync_bytes();
+
+static int fwd_x3_capacity() {
+    const int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_fwd_x3_persist_kernel), X_NT);
+    return cap < X_MAX_WG ? cap : X_MAX_WG;
+}
+// number of 32-row chains per workgroup (0: unsupported, or two layers of the shape do not fit the device's resident capacity)
+int lstm_seq_fwd_x3_persist_supported(int B, int H) {
+    if (!(B > 0 && B % X_SR == 0 && H >= 8 && H <= 1024)) return 0;
+    const int cap = fwd_x3_capacity();
+    const int nC = cdiv(H, X_UN);
+    int R = B / X_SR, ns = 1;
+    while (R * nC > cap / 2 && ns < X_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }
+    return (R * nC <= cap / 2 && R <= 64) ? ns : 0;
+}
+
+static int prep_x(SeqFwdX3Args& a) {
+    const int ns = lstm_seq_fwd_x3_persist_supported(a.B, a.H);
+    S2VT_REQUIRE(ns > 0, "lstm_seq_fwd_x3_persist: unsupported shape (B %% 32, H <= 1024) or it does not fit the device's resident capacity");
+    S2VT_REQUIRE(a.t1 > a.t0 && a.t0 >= 0 && a.wp && a.hp && a.h_all && a.gx_stash && a.c_all && a.sync && a.err && (a.bias || a.n_gx >= a.t1),
+                 "lstm_seq_fwd_x3_persist: bad arguments");
+    S2VT_REQUIRE(a.Kp == (a.H + 63) / 64 * 64 && a.ldw >= a.Kp && a.ldh >= a.Kp && a.ldw % 8 == 0 && a.ldh % 8 == 0 &&
+                     a.wplane % 8 == 0 && a.hplane % 8 == 0 && (reinterpret_cast<uintptr_t>(a.wp) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(a.hp) & 15) == 0,
+                 "lstm_seq_fwd_x3_persist: plane images must be 16-byte aligned with rows of Kp = H rounded up to 64");
+    a.NS = ns;
+    a.RB = ns * X_SR;
+    return 0;
+}
+
+int lstm_seq_fwd_x3_persist2(hipStream_t stream, SeqFwdX3Args a, const SeqFwdX3Args* b) {
+    int rc;
+    if ((rc = prep_x(a))) return rc;
+    SeqFwdX3Args bb = b ? *b : a;
+    if (b) {
+        if ((rc = prep_x(bb))) return rc;
+        S2VT_REQUIRE(bb.sync != a.sync, "lstm_seq_fwd_x3_persist: paired layers need their own counters");
+    }
+    const int na = (a.B / a.RB) * cdiv(a.H, X_UN), nb = b ? (bb.B / bb.RB) * cdiv(bb.H, X_UN) : 0;
+    S2VT_REQUIRE(na + nb <= fwd_x3_capacity(), "lstm_seq_fwd_x3_persist: %d workgroups would not be co-resident (device capacity %d)",
+                 na + nb, fwd_x3_capacity());
+    // the hand-off counters count finished timesteps of the whole sequence: zeroed with its first block only
+    if (a.t0 == 0) S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
+    if (b && bb.t0 == 0) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
+    // XCD-aware dealing (see the kernel) when the groups divide the 8 XCDs and the padded grid still fits the device
+    static const bool xcd_on = !(getenv("S2VT_PERSIST_XCD") && atoi(getenv("S2VT_PERSIST_XCD")) == 0);
+    const int nC = cdiv(a.H, X_UN);
+    const int G = (na + nb) / nC;
+    int xg = 0, grid = na + nb;
+    if (xcd_on && (!b || (bb.B == a.B && bb.H == a.H)) && G > 0 && G <= 8 && 8 % G == 0) {
+        const int padded = 8 * cdiv(nC, 8 / G);
+        if (padded <= fwd_x3_capacity()) { xg = G; grid = padded; }
+    }
+    hipLaunchKernelGGL(lstm_seq_fwd_x3_persist_kernel, dim3(grid), dim3(X_NT), 0, stream, a, bb, na, xg);
+    S2VT_LAUNCH_CHECK("lstm_seq_fwd_x3_persist_kernel");
+    return 0;
+}
+
+// fp32 [R][C] (row stride ld) -> three bf16 planes [3][R][Cp] (x = p0 + p1 + p2), columns [C, Cp) zero: W_hh for the kernel above
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ src, int64_t ld, int R, int C, int Cp,
+                                                          unsigned short* __restrict__ dst, int64_t plane) {
+    const int64_t n = (int64_t)R * (Cp / 2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / (Cp / 2)), c = (int)(i % (Cp / 2)) * 2;
+        unsigned short a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+        if (c < C) split3_bits(src[(int64_t)r * ld + c], a);
+        if (c + 1 < C) split3_bits(src[(int64_t)r * ld + c + 1], b);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<unsigned int*>(dst + pl * plane + (int64_t)r * Cp + c) = (unsigned int)a[pl] | ((unsigned int)b[pl] << 16);
+    }
+}
+int split3_rows(hipStream_t stream, const float* src, int64_t ld, int R, int C, int Cp, unsigned short* dst, int64_t plane) {
+    S2VT_REQUIRE(src && dst && R > 0 && C > 0 && Cp >= C && Cp % 2 == 0 && plane >= (int64_t)R * Cp, "split3_rows: bad arguments");
+    const int64_t n = (int64_t)R * (Cp / 2);
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(split3_rows_kernel, dim3(grid), dim3(256), 0, stream, src, ld, R, C, Cp, dst, plane);
+    S2VT_LAUNCH_CHECK("split3_rows_kernel");
+    return 0;
+}
+
+}  // namespace s2vt

@@ -287,15 +287,21 @@ def _persist_ws(dev):
     return torch.zeros(n, dtype=torch.uint8, device=dev), n
 
 
-def lstm_seq_fwd_persist(T, B, gx, n_gx, bias, w_hh, block=0, second=None):
+def lstm_seq_fwd_persist(T, B, gx, n_gx, bias, w_hh, block=0, second=None, x3=False):
     """fp32 layer forward with the persistent kernel: returns (h_all, c_all, gates).  `second` = (gx, bias, w_hh) of another
-    layer of the same shape that shares every launch: then a pair of result tuples is returned."""
+    layer of the same shape that shares every launch: then a pair of result tuples is returned.  x3: the split-precision kernel
+    (three bf16 planes per operand, lstm_persist_x3.hip) instead of the exact-fp32 MFMA one."""
     lib = capi.load()
     w_hh = _f32c(w_hh, "w_hh")
     H = w_hh.shape[1]
     dev = w_hh.device
+    fn = lib.s2vt_lstm_seq_fwd_x3_persist if x3 else lib.s2vt_lstm_seq_fwd_persist
     with torch.cuda.device(dev):
-        ws, n = _persist_ws(dev)
+        if x3:      # (0xFF bytes: bf16 NaN patterns - the kernel must never read a plane element it has not written)
+            n = lib.s2vt_lstm_seq_x3_workspace_bytes(T, B, H)
+            ws = torch.full((n,), 0xFF, dtype=torch.uint8, device=dev)
+        else:
+            ws, n = _persist_ws(dev)
         sets = []
         for g, b, w in [(gx, bias, w_hh)] + ([second] if second is not None else []):
             stash = torch.empty(T * B, 4 * H, dtype=torch.float32, device=dev)
@@ -304,9 +310,9 @@ def lstm_seq_fwd_persist(T, B, gx, n_gx, bias, w_hh, block=0, second=None):
             sets.append((stash, b, _f32c(w, "w_hh"), torch.empty(T * B, H, dtype=torch.float32, device=dev),
                          torch.empty(T * B, H, dtype=torch.float32, device=dev)))
         a, b2 = sets[0], (sets[1] if len(sets) > 1 else (None,) * 5)
-        capi.check(lib.s2vt_lstm_seq_fwd_persist(T, B, H, _ptr(a[0]), _ptr(b2[0]), int(n_gx), _ptr(a[1]), _ptr(b2[1]), _ptr(a[2]),
-                                                 _ptr(b2[2]), _ptr(a[3]), _ptr(b2[3]), _ptr(a[4]), _ptr(b2[4]), int(block),
-                                                 _ptr(ws), n, _stream(dev)), "s2vt_lstm_seq_fwd_persist")
+        capi.check(fn(T, B, H, _ptr(a[0]), _ptr(b2[0]), int(n_gx), _ptr(a[1]), _ptr(b2[1]), _ptr(a[2]),
+                      _ptr(b2[2]), _ptr(a[3]), _ptr(b2[3]), _ptr(a[4]), _ptr(b2[4]), int(block),
+                      _ptr(ws), n, _stream(dev)), "s2vt_lstm_seq_fwd_x3_persist" if x3 else "s2vt_lstm_seq_fwd_persist")
         _check_persist_err(ws)
     outs = [(x[3], x[4], x[0]) for x in sets]
     return outs[0] if second is None else tuple(outs)

@@ -614,6 +614,52 @@ def test_persistent_fp32_recurrence(lib, T, B, H, n_gx, block):
     assert (h1 - h0).abs().max().item() < 2e-6
 
 
+@pytest.mark.parametrize("T,B,H,n_gx,block", [(6, 32, 128, 4, 0), (7, 64, 1000, 4, 3), (5, 128, 1000, 3, 0), (9, 96, 520, 9, 4),
+                                              (4, 256, 1000, 2, 0), (5, 32, 8, 5, 2), (12, 64, 1000, 6, 5), (5, 64, 1024, 2, 0),
+                                              (4, 32, 70, 1, 2)])
+def test_persistent_split_precision_recurrence(lib, T, B, H, n_gx, block):
+    """lstm_seq_fwd_x3_persist_kernel: h_{t-1} . W_hh^T as six bf16 plane products (fp32-equivalent), W_hh planes resident in
+    384 registers per lane, hand-off of h_t as three bf16 planes.  Same bounds as the exact-fp32 persistent kernel: against fp64
+    cell math, the launch-per-timestep kernels, and itself bit for bit.  The workspace is handed over full of bf16 NaN patterns:
+    a plane element read before it was written (k padding, the pad columns of the last column slice) would poison the result."""
+    from s2vt_video_caption_amd import ops
+    gx, bias, w = _r(n_gx * B, 4 * H, seed=81), _r(4 * H, seed=82, scale=0.3), _r(4 * H, H, seed=83, scale=H ** -0.5)
+    args = (T, B, gx.to(DEV), n_gx, bias.to(DEV), w.to(DEV))
+    h1, c1, g1 = ops.lstm_seq_fwd_persist(*args, block=block, x3=True)
+    h2, c2, g2 = ops.lstm_seq_fwd_persist(*args, block=block, x3=True)
+    assert torch.equal(h1, h2) and torch.equal(c1, c2) and torch.equal(g1, g2)
+    rh, rc, rg = _cell_seq_fp64(gx, n_gx, bias, w, T, B, H)
+    assert (h1.cpu().double() - rh).abs().max().item() < 2e-6
+    assert (c1.cpu().double() - rc).abs().max().item() < 4e-6
+    assert (g1.cpu().double() - rg).abs().max().item() < 2e-6
+    h0, c0, g0 = ops.lstm_seq_fwd(*args, want_stash=True)
+    assert (h1 - h0).abs().max().item() < 2e-6
+
+
+def test_persistent_split_precision_two_layers_one_launch_under_load(lib):
+    """Two layers per launch at the config-2 shape (252 workgroups, one per compute unit) while another stream loads the chip:
+    each layer equals its solo run bit for bit (a stale hand-off is timing dependent)."""
+    from s2vt_video_caption_amd import ops
+    T, B, H, n_gx = 24, 64, 1000, 12
+    ins = [(_r(n_gx * B, 4 * H, seed=111 + k), _r(4 * H, seed=113 + k, scale=0.3), _r(4 * H, H, seed=115 + k, scale=H ** -0.5))
+           for k in range(2)]
+    dev = [tuple(x.to(DEV) for x in i) for i in ins]
+    solo = [ops.lstm_seq_fwd_persist(T, B, dev[k][0], n_gx, dev[k][1], dev[k][2], block=9, x3=True) for k in range(2)]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.randn(32 * 1024 * 1024, device=DEV)
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            big = big * 1.0001 + 1.0
+    pair = ops.lstm_seq_fwd_persist(T, B, dev[0][0], n_gx, dev[0][1], dev[0][2], block=9, second=dev[1], x3=True)
+    torch.cuda.synchronize()
+    for k in range(2):
+        for a, b in zip(pair[k], solo[k]):
+            assert torch.equal(a, b)
+        rh, rc, rg = _cell_seq_fp64(*[ins[k][0], n_gx, ins[k][1], ins[k][2]], T, B, H)
+        assert (pair[k][0].cpu().double() - rh).abs().max().item() < 2e-6
+
+
 @pytest.mark.parametrize("T,B,H,dh_first,block", [(6, 32, 128, 2, 0), (7, 64, 1000, 0, 3), (5, 128, 1000, 1, 0), (9, 96, 520, 3, 4),
                                                   (4, 256, 1000, 0, 0), (5, 32, 4, 0, 2)])
 def test_persistent_fp32_bptt(lib, T, B, H, dh_first, block):
