@@ -341,7 +341,8 @@ def main():
         persist_bf16 = plan[0] == 1
         FWD_KERNELS = {0: "lstm_step_fwd_kernel", 1: "lstm_seq_fwd_bf16_persist_kernel", 2: "lstm_seq_fwd_f32_persist_kernel",
                        3: "lstm_seq_fwd_x3_persist_kernel"}
-        BWD_KERNELS = {0: "lstm_step_bwd_kernel", 1: "lstm_seq_bwd_bf16_persist_kernel", 2: "lstm_seq_bwd_f32_persist_kernel"}
+        BWD_KERNELS = {0: "lstm_step_bwd_kernel", 1: "lstm_seq_bwd_bf16_persist_kernel", 2: "lstm_seq_bwd_f32_persist_kernel",
+                       3: "lstm_seq_bwd_x3_persist_kernel"}
 
         def rooflines(pr, how, persist, B_=B, esz_=esz, bf_=bf, x3_=x3, pmc_=None, pmc_src_=None):
             # persist: (forward kind, BPTT kind) as s2vt_recurrence_plan reports them, or False for launches per timestep

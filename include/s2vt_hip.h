@@ -287,6 +287,16 @@ int s2vt_lstm_seq_fwd_x3_persist(int32_t T, int32_t B, int32_t H, float* gx_stas
                               const float* bias0, const float* bias1, const float* w_hh0, const float* w_hh1, float* h_all0,
                               float* h_all1, float* c_all0, float* c_all1, int32_t block, void* workspace,
                               size_t workspace_bytes, void* stream);
+/* BPTT in split precision (lstm_persist_x3.hip), the counterpart of s2vt_lstm_seq_fwd_x3_persist: the contraction
+ * dG_{t+1} . W_hh is split over the gate columns - every workgroup multiplies the dG tile it has just computed with its 64 rows
+ * of W_hh (planes resident in registers) for all H outputs, scatters the fp32 partial sums per consumer and gathers the ones
+ * addressed to it (fixed summation order).  Same arithmetic contract as s2vt_lstm_seq_bwd (fp32-equivalent); stash_dg: activated
+ * gates in, dG out (in place).  Layer 1 pointers may all be null.  block: timesteps per launch (0 = all T).
+ * Whole-path use: env S2VT_PERSIST_X3_BWD=1 routes the BPTT of s2vt_train_backward (gemm mode 3) through it. */
+size_t s2vt_lstm_seq_bwd_x3_workspace_bytes(int32_t T, int32_t B, int32_t H, int32_t block);
+int s2vt_lstm_seq_bwd_x3_persist(int32_t T, int32_t B, int32_t H, const float* w_hh0, const float* w_hh1, const float* dh_out0,
+                                 const float* dh_out1, int32_t dh_first, const float* c_all0, const float* c_all1, float* stash_dg0,
+                                 float* stash_dg1, int32_t block, void* workspace, size_t workspace_bytes, void* stream);
 int s2vt_lstm_seq_bwd_persist(int32_t T, int32_t B, int32_t H, const float* w_hh0, const float* w_hh1, const float* dh_out0,
                               const float* dh_out1, int32_t dh_first, const float* c_all0, const float* c_all1, float* stash_dg0,
                               float* stash_dg1, float* w_hh_t0, float* w_hh_t1, float* dc0, float* dc1, int32_t block,

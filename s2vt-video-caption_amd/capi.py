@@ -93,6 +93,9 @@ SIGNATURES = {
     "s2vt_lstm_seq_x3_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "s2vt_lstm_seq_fwd_x3_persist": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 8 +
                                   [c_int32, c_void_p, c_size_t, c_void_p]),
+    "s2vt_lstm_seq_bwd_x3_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
+    "s2vt_lstm_seq_bwd_x3_persist": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32] +
+                                     [c_void_p] * 4 + [c_int32, c_void_p, c_size_t, c_void_p]),
     "s2vt_lstm_seq_bwd_persist": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32] +
                                   [c_void_p] * 8 + [c_int32, c_void_p, c_size_t, c_void_p]),
     "s2vt_set_recurrence_mode": (c_int32, [c_int32]),

@@ -240,6 +240,9 @@ struct TrainWS {
     unsigned int *psync_a, *psync_b;     // hand-off counters of the persistent recurrence kernels (one block per lane)
     unsigned short *xw1, *xw2, *xh1, *xh2;   // split-precision persistent forward (lstm_persist_x3.hip): W_hh planes [3][4H][Kp],
     int64_t xkp;                             // h_t planes [3][T*B][Kp] per layer; Kp = H rounded up to 64 (0: H > 1024, no images)
+    unsigned short *xwt1, *xwt2;             // split-precision persistent BPTT: W_hh^T planes [3][Kp][4 Hp] per layer and the
+    float *xpart1, *xpart2;                  // partial-sum rings [xnslots][B/32][nC][nC][32][16] (xnslots = 0: not provided)
+    int xnslots; int64_t xpslot, xhp;
     size_t bytes;
 };
 
@@ -247,6 +250,7 @@ static bool dims_ok(const s2vt_dims* d) {
     return d && d->B > 0 && d->L > 1 && d->F > 0 && d->H > 0 && d->E > 0 && d->V > 0;
 }
 
+static int pipe_block();
 static TrainWS carve_train(const s2vt_dims& d, void* base) {
     const size_t B = d.B, L = d.L, H = d.H, E = d.E, V = d.V, T = 2 * L - 1;
     Carver c{reinterpret_cast<char*>(base), 0, 0};
@@ -270,6 +274,17 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     w.xw2 = c.take<unsigned short>(3 * 4 * H * w.xkp);
     w.xh1 = c.take<unsigned short>(3 * T * B * w.xkp);
     w.xh2 = c.take<unsigned short>(3 * T * B * w.xkp);
+    {   // ring slots: one more than the longest block of the backward's pipeline (a slot is written once per launch)
+        const bool can = w.xkp > 0 && B % 32 == 0 && pipe_block() > 0;
+        const size_t maxblk = (size_t)pipe_block() < T ? (size_t)pipe_block() : T;
+        w.xnslots = can ? (int)maxblk + 1 : 0;
+        w.xhp = (int64_t)((H + 15) / 16 * 16);
+        w.xpslot = can ? (int64_t)lstm_seq_bwd_x3_part_slot_floats((int)B, (int)H) : 0;
+        w.xwt1 = c.take<unsigned short>(can ? 3 * (size_t)w.xkp * 4 * w.xhp : 0);
+        w.xwt2 = c.take<unsigned short>(can ? 3 * (size_t)w.xkp * 4 * w.xhp : 0);
+        w.xpart1 = c.take<float>((size_t)w.xnslots * w.xpslot);
+        w.xpart2 = c.take<float>((size_t)w.xnslots * w.xpslot);
+    }
     // backward-only scratch (two of everything that the two concurrently running layers touch)
     w.wt1 = c.take<float>(H * 4 * H);
     w.wt2 = c.take<float>(H * 4 * H);
@@ -639,6 +654,28 @@ static bool persist_x3_fwd_on() {
     if (on < 0) { const char* e = getenv("S2VT_PERSIST_X3_FWD"); on = e ? (atoi(e) != 0) : 1; }
     return on && persist_on();
 }
+// split-precision persistent BPTT (reduce-scatter over the gate columns, lstm_persist_x3.hip): S2VT_PERSIST_X3_BWD = 0 | 1
+static bool persist_x3_bwd_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("S2VT_PERSIST_X3_BWD"); on = e ? (atoi(e) != 0) : 0; }
+    return on && persist_on();
+}
+static SeqBwdX3Args persist_bwd_x3_args(int T, int t0, int t1, int B, int H, int64_t Kp, int64_t Hp, const unsigned short* wtp,
+                                        const float* dh_out, int dh_first, const float* c_all, float* stash_dg, float* dc,
+                                        float* part, int64_t part_slot, int nslots, unsigned int* sync, int* err) {
+    SeqBwdX3Args a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.H = H; a.Kp = (int)Kp; a.Hp = (int)Hp; a.T = T; a.t0 = t0; a.t1 = t1;
+    a.wtp = wtp; a.wplane = Kp * 4 * Hp; a.ldw = 4 * Hp;
+    a.dh_out = dh_out; a.dh_first = dh_first;
+    a.stash_dg = stash_dg; a.c_all = c_all; a.dc = dc;
+    a.part = part; a.part_slot = part_slot; a.nslots = nslots;
+    a.sync = sync; a.err = err;
+#ifdef S2VT_EXPERIMENT_STAMPS
+    a.stamps = g_xstamps; a.stamp_block = g_xstamp_block;
+#endif
+    return a;
+}
 static SeqFwdX3Args persist_fwd_x3_args(int t0, int t1, int B, int H, int T, int64_t Kp, float* gx_stash, int n_gx, const float* bias,
                                         const unsigned short* wp, unsigned short* hp, float* h_all, float* c_all,
                                         unsigned int* sync, int* err) {
@@ -715,7 +752,7 @@ static SeqBwdF32Args persist_bwd_f32_args(int T, int t0, int t1, int B, int H, c
 // What a forward was run with, keyed by its workspace: s2vt_train_backward must find the same arithmetic mode and
 // recurrence schedule (they decide how the workspace is carved and which images the forward left in it), otherwise it
 // refuses instead of reading a differently carved workspace.  Host-side only.
-struct FwdRecord { s2vt_dims d; int gemm_mode, planes, persist; unsigned long long seq; bool dlog_ready; };
+struct FwdRecord { s2vt_dims d; int gemm_mode, planes, persist, blk; unsigned long long seq; bool dlog_ready; };
 static std::map<const void*, FwdRecord> g_fwd_records;
 static std::mutex g_fwd_mutex;          // autograd runs the backward on its own thread
 static unsigned long long g_fwd_seq = 0;
@@ -727,7 +764,7 @@ static void record_forward(const void* ws, const s2vt_dims& d, bool planes) {
             if (it->second.seq < oldest->second.seq) oldest = it;
         g_fwd_records.erase(oldest);
     }
-    g_fwd_records[ws] = FwdRecord{d, gemm_mode(), planes ? ((gemm_mode() == 1) ? 1 : 3) : 0, persist_mode(), ++g_fwd_seq, false};
+    g_fwd_records[ws] = FwdRecord{d, gemm_mode(), planes ? ((gemm_mode() == 1) ? 1 : 3) : 0, persist_mode(), pipe_block(), ++g_fwd_seq, false};
 }
 static int check_forward_record(const void* ws, const s2vt_dims& d, bool planes, bool* dlog_ready = nullptr) {
     FwdRecord r;
@@ -741,10 +778,10 @@ static int check_forward_record(const void* ws, const s2vt_dims& d, bool planes,
     if (dlog_ready) *dlog_ready = r.dlog_ready;
     S2VT_REQUIRE(memcmp(&r.d, &d, sizeof(d)) == 0, "s2vt_train_backward: dims differ from the forward that filled this workspace");
     const int planes_now = planes ? ((gemm_mode() == 1) ? 1 : 3) : 0;
-    S2VT_REQUIRE(r.gemm_mode == gemm_mode() && r.planes == planes_now && r.persist == persist_mode(),
-                 "s2vt_train_backward: the forward ran with gemm mode %d / recurrence mode %d, now %d / %d: the workspace "
-                 "layout differs (do not change s2vt_set_gemm_mode / s2vt_set_recurrence_mode between a forward and its backward)",
-                 r.gemm_mode, r.persist, gemm_mode(), persist_mode());
+    S2VT_REQUIRE(r.gemm_mode == gemm_mode() && r.planes == planes_now && r.persist == persist_mode() && r.blk == pipe_block(),
+                 "s2vt_train_backward: the forward ran with gemm mode %d / recurrence mode %d / pipeline block %d, now %d / %d / %d: the "
+                 "workspace layout differs (do not change s2vt_set_gemm_mode / s2vt_set_recurrence_mode / s2vt_set_pipeline_block "
+                 "between a forward and its backward)", r.gemm_mode, r.persist, r.blk, gemm_mode(), persist_mode(), pipe_block());
     return 0;
 }
 
@@ -943,20 +980,37 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = grads_ready(0, sx))) return rc;
     if ((rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     const bool pbf_bwd = bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad;
-    const std::vector<int> bd = pipe_bounds(T, L, pbf_bwd ? balanced_block(L, blk) : blk);
-    if (!bf && blk > 0 && persist_f32_dir_on(1) && lstm_seq_bwd_f32_persist_supported(B, H)) {
-        // fp32 persistent schedule, ONE stream: stage k = word_rnn BPTT of block k next to vid_rnn BPTT of block k+1
+    const bool px3_bwd = !bf && XP == 3 && blk > 0 && w.xnslots > 0 && persist_x3_bwd_on() && lstm_seq_bwd_x3_persist_supported(B, H) &&
+                         w.xnslots > (balanced_block(L, blk) < T ? balanced_block(L, blk) : T);
+    const std::vector<int> bd = pipe_bounds(T, L, (pbf_bwd || px3_bwd) ? balanced_block(L, blk) : blk);
+    if (px3_bwd) {   // W_hh^T of both layers as planes (each on the lane that transposed it)
+        if ((rc = split3_wt(st, w.wt2, H, (int)w.xkp, (int)w.xhp, w.xwt2, w.xkp * 4 * w.xhp))) return rc;
+        if ((rc = split3_wt(sx, w.wt1, H, (int)w.xkp, (int)w.xhp, w.xwt1, w.xkp * 4 * w.xhp))) return rc;
+    }
+    if (px3_bwd || (!bf && blk > 0 && persist_f32_dir_on(1) && lstm_seq_bwd_f32_persist_supported(B, H))) {
+        // fp32-equivalent persistent schedule (split precision: lstm_persist_x3.hip; exact-fp32 MFMA: lstm_persist_f32.hip), ONE
+        // stream: stage k = word_rnn BPTT of block k next to vid_rnn BPTT of block k+1
         if ((rc = handoff(sx, st, ev++))) return rc;               // W_hh1^T and the out_linear gradients of lane B
         const int nb = (int)bd.size() - 1;
         for (int k = nb - 1; k >= -1; --k) {
             const bool hw = k >= 0, hv = k + 1 <= nb - 1;
-            SeqBwdF32Args aw, av;
-            if (hw) aw = persist_bwd_f32_args(T, bd[k], bd[k + 1], B, H, w.wt2, w.dh2dec, L, w.c2, w.s2, w.dc2, w.psync_a, w.err + 1);
-            if (hv) av = persist_bwd_f32_args(T, bd[k + 1], bd[k + 2], B, H, w.wt1, w.dh1, 0, w.c1, w.s1, w.dc1, w.psync_b, w.err + 1);
             {
                 ProfScope ps(st, K_STEP_BWD, (hw ? bd[k + 1] - bd[k] : 0) + (hv ? bd[k + 2] - bd[k + 1] : 0));
-                if (hw && hv) rc = lstm_seq_bwd_f32_persist2(st, aw, &av);
-                else rc = lstm_seq_bwd_f32_persist2(st, hw ? aw : av, nullptr);
+                if (px3_bwd) {
+                    SeqBwdX3Args aw, av;
+                    if (hw) aw = persist_bwd_x3_args(T, bd[k], bd[k + 1], B, H, w.xkp, w.xhp, w.xwt2, w.dh2dec, L, w.c2, w.s2, w.dc2,
+                                                     w.xpart2, w.xpslot, w.xnslots, w.psync_a, w.err + 1);
+                    if (hv) av = persist_bwd_x3_args(T, bd[k + 1], bd[k + 2], B, H, w.xkp, w.xhp, w.xwt1, w.dh1, 0, w.c1, w.s1, w.dc1,
+                                                     w.xpart1, w.xpslot, w.xnslots, w.psync_b, w.err + 1);
+                    if (hw && hv) rc = lstm_seq_bwd_x3_persist2(st, aw, &av);
+                    else rc = lstm_seq_bwd_x3_persist2(st, hw ? aw : av, nullptr);
+                } else {
+                    SeqBwdF32Args aw, av;
+                    if (hw) aw = persist_bwd_f32_args(T, bd[k], bd[k + 1], B, H, w.wt2, w.dh2dec, L, w.c2, w.s2, w.dc2, w.psync_a, w.err + 1);
+                    if (hv) av = persist_bwd_f32_args(T, bd[k + 1], bd[k + 2], B, H, w.wt1, w.dh1, 0, w.c1, w.s1, w.dc1, w.psync_b, w.err + 1);
+                    if (hw && hv) rc = lstm_seq_bwd_f32_persist2(st, aw, &av);
+                    else rc = lstm_seq_bwd_f32_persist2(st, hw ? aw : av, nullptr);
+                }
                 if (rc) return rc;
             }
             if (hw) {
@@ -1991,7 +2045,8 @@ int s2vt_recurrence_plan(int32_t B, int32_t H, int32_t* fwd, int32_t* bwd) {
     }
     if (H <= 1024 && persist_x3_fwd_on() && lstm_seq_fwd_x3_persist_supported(B, H)) *fwd = 3;
     else if (persist_f32_dir_on(0) && lstm_seq_fwd_f32_persist_supported(B, H)) *fwd = 2;
-    if (persist_f32_dir_on(1) && lstm_seq_bwd_f32_persist_supported(B, H)) *bwd = 2;
+    if (H <= 1024 && persist_x3_bwd_on() && lstm_seq_bwd_x3_persist_supported(B, H)) *bwd = 3;
+    else if (persist_f32_dir_on(1) && lstm_seq_bwd_f32_persist_supported(B, H)) *bwd = 2;
     return 0;
 }
 
@@ -2070,6 +2125,61 @@ int s2vt_lstm_seq_fwd_x3_persist(int32_t T, int32_t B, int32_t H, float* gx_stas
         SeqFwdX3Args a1;
         if (two) a1 = persist_fwd_x3_args(t0, t1, B, H, T, Kp, gx_stash1, n_gx, bias1, wp[1], hp[1], h_all1, c_all1, sb, err);
         if ((rc = lstm_seq_fwd_x3_persist2(st, a0, two ? &a1 : nullptr))) return rc;
+    }
+    return 0;
+}
+// split-precision persistent BPTT as its own entry point.
+// workspace: [err int x64][sync A][sync B] then per layer [W_hh^T fp32][W_hh^T planes][dc][partial-sum ring]
+static size_t bwd_x3_ws_layer_bytes(int T, int B, int H, int nslots) {
+    const size_t Kp = (size_t)(H + 63) / 64 * 64, Hp = (size_t)(H + 15) / 16 * 16;
+    return align_up((size_t)H * 4 * H * 4, 256) + align_up(3 * Kp * 4 * Hp * 2, 256) + align_up((size_t)B * H * 4, 256) +
+           align_up((size_t)nslots * lstm_seq_bwd_x3_part_slot_floats(B, H) * 4, 256);
+}
+size_t s2vt_lstm_seq_bwd_x3_workspace_bytes(int32_t T, int32_t B, int32_t H, int32_t block) {
+    if (T <= 0 || B <= 0 || H <= 0 || H > 1024 || B % 32) return 0;
+    const int blk = (block > 0 && block < T) ? block : T;
+    return 256 + 2 * lstm_persist_sync_bytes() + 2 * bwd_x3_ws_layer_bytes(T, B, H, blk + 1);
+}
+int s2vt_lstm_seq_bwd_x3_persist(int32_t T, int32_t B, int32_t H, const float* w_hh0, const float* w_hh1, const float* dh_out0,
+                                 const float* dh_out1, int32_t dh_first, const float* c_all0, const float* c_all1, float* stash_dg0,
+                                 float* stash_dg1, int32_t block, void* workspace, size_t workspace_bytes, void* stream) {
+    S2VT_REQUIRE(T > 0 && B > 0 && H > 0 && w_hh0 && c_all0 && stash_dg0 && workspace && dh_first >= 0,
+                 "s2vt_lstm_seq_bwd_x3_persist: bad arguments");
+    S2VT_REQUIRE(H <= 1024 && lstm_seq_bwd_x3_persist_supported(B, H), "s2vt_lstm_seq_bwd_x3_persist: shape not supported");
+    S2VT_REQUIRE(workspace_bytes >= s2vt_lstm_seq_bwd_x3_workspace_bytes(T, B, H, block), "s2vt_lstm_seq_bwd_x3_persist: workspace too small");
+    const bool two = stash_dg1 != nullptr;
+    S2VT_REQUIRE(!two || (w_hh1 && c_all1), "s2vt_lstm_seq_bwd_x3_persist: second layer incomplete");
+    const int blk = (block > 0 && block < T) ? block : T;
+    const int64_t Kp = (H + 63) / 64 * 64, Hp = (H + 15) / 16 * 16;
+    const int64_t pslot = (int64_t)lstm_seq_bwd_x3_part_slot_floats(B, H);
+    char* base = reinterpret_cast<char*>(workspace);
+    int* err = reinterpret_cast<int*>(base);
+    unsigned int* sy[2] = {reinterpret_cast<unsigned int*>(base + 256), reinterpret_cast<unsigned int*>(base + 256 + lstm_persist_sync_bytes())};
+    char* q = base + 256 + 2 * lstm_persist_sync_bytes();
+    float* wt[2]; unsigned short* wtp[2]; float* dc[2]; float* part[2];
+    for (int l = 0; l < 2; ++l) {
+        wt[l] = reinterpret_cast<float*>(q); q += align_up((size_t)H * 4 * H * 4, 256);
+        wtp[l] = reinterpret_cast<unsigned short*>(q); q += align_up(3 * (size_t)Kp * 4 * Hp * 2, 256);
+        dc[l] = reinterpret_cast<float*>(q); q += align_up((size_t)B * H * 4, 256);
+        part[l] = reinterpret_cast<float*>(q); q += align_up((size_t)(blk + 1) * pslot * 4, 256);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = fill_zero(st, err, 256))) return rc;
+    const float* whh[2] = {w_hh0, w_hh1};
+    for (int l = 0; l < (two ? 2 : 1); ++l) {
+        if ((rc = transpose_f32(st, whh[l], 4 * H, H, wt[l]))) return rc;
+        if ((rc = split3_wt(st, wt[l], H, (int)Kp, (int)Hp, wtp[l], Kp * 4 * Hp))) return rc;
+    }
+    for (int t1 = T; t1 > 0; t1 -= blk) {
+        const int t0 = (t1 - blk > 0) ? t1 - blk : 0;
+        ProfScope ps(st, K_STEP_BWD, (two ? 2 : 1) * (t1 - t0));
+        const SeqBwdX3Args a0 = persist_bwd_x3_args(T, t0, t1, B, H, Kp, Hp, wtp[0], dh_out0, dh_first, c_all0, stash_dg0, dc[0],
+                                                    part[0], pslot, blk + 1, sy[0], err);
+        SeqBwdX3Args a1;
+        if (two) a1 = persist_bwd_x3_args(T, t0, t1, B, H, Kp, Hp, wtp[1], dh_out1, dh_first, c_all1, stash_dg1, dc[1],
+                                          part[1], pslot, blk + 1, sy[1], err);
+        if ((rc = lstm_seq_bwd_x3_persist2(st, a0, two ? &a1 : nullptr))) return rc;
     }
     return 0;
 }

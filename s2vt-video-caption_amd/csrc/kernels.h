@@ -181,6 +181,23 @@ struct SeqFwdX3Args {
 int lstm_seq_fwd_x3_persist_supported(int B, int H);
 int lstm_seq_fwd_x3_persist2(hipStream_t stream, SeqFwdX3Args a, const SeqFwdX3Args* b);
 int split3_rows(hipStream_t stream, const float* src, int64_t ld, int R, int C, int Cp, unsigned short* dst, int64_t plane);
+struct SeqBwdX3Args {
+    int B, H, Kp, Hp;                               // Kp = H rounded up to 64 (output columns j), Hp = H rounded up to 16
+    int T, t0, t1;                                  // BPTT over steps t1-1 .. t0 of a T-step layer
+    const unsigned short* wtp; int64_t wplane, ldw; // W_hh^T as planes [3][Kp][4 Hp] (split3_wt)
+    const float* dh_out; int dh_first;              // gradient from above for steps >= dh_first, [(T-dh_first)*B][H] (nullable)
+    float* stash_dg;                                // [T*B][4H]: activated gates in, fp32 dG out (in place)
+    const float* c_all;                             // [T*B][H]
+    float* dc;                                      // [B][H] dL/dc carried between launches (ignored when t1 == T)
+    float* part; int64_t part_slot; int nslots;     // partial-sum ring [nslots][chains][nC][nC][32][16] fp32; nslots > t1 - t0
+    unsigned int* sync; int* err;
+    int RB, NS;                                     // set by the launcher
+    unsigned long long* stamps; int stamp_block;    // timing experiments only (experiment.h); null in the product
+};
+int lstm_seq_bwd_x3_persist_supported(int B, int H);
+size_t lstm_seq_bwd_x3_part_slot_floats(int B, int H);
+int lstm_seq_bwd_x3_persist2(hipStream_t stream, SeqBwdX3Args a, const SeqBwdX3Args* b);
+int split3_wt(hipStream_t stream, const float* wt, int H, int Kp, int Hp, unsigned short* dst, int64_t plane);
 struct SeqBwdF32Args {
     int B, H;                                       // H % 4 == 0, H <= 1024
     int T, t0, t1;

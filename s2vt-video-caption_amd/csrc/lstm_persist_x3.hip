@@ -460,4 +460,385 @@ int split3_rows(hipStream_t stream, const float* src, int64_t ld, int R, int C, 
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------- BPTT
+// Split-precision persistent BPTT (utils/autograd of S2VTModel.py:67,77: dh_t = dh_out_t + dG_{t+1} . W_hh, gate derivatives).
+//
+// The forward's decomposition does not carry over: dG_{t+1} is [B, 4H], so a workgroup that owns 16 units of dh would have to
+// take in 32 rows x 4H x 3 planes = 768 KB per sub-step (12 us at the ~65 GB/s a compute unit ingests), and W_hh^T for 32 units
+// as planes does not fit a register file.  Here the contraction is split over K instead (a reduce-scatter): workgroup
+// (chain, cs) owns the 64 gate columns k of ITS 16 units - the dG values it has just computed itself, already in LDS - and the
+// matching 64 rows of W_hh for ALL H output columns (64 k x 1024 j x 3 planes = the same 384 registers per lane as the forward).
+// Per sub-step it computes the partial products P[b, j] = sum_{k in its 64} dG_t[b, k] W_hh[k, j] for all j (192 MFMAs per
+// wave, the six plane products of gemm_x3.hip; transposed tiles: lane = batch row, registers = 4 consecutive j, so a finished
+// tile leaves as 16-byte stores) and scatters them as fp32 blocks [32 rows][16 units], one per CONSUMER column slice; after the
+// hand-off (all waves drain their stores, barrier, one counter add) every workgroup gathers the nC blocks addressed to it - one
+// contiguous nC x 2 KB region - by LDS-DMA and sums them in producer order (fixed order: deterministic).  Per sub-step a
+// workgroup moves 128 KB out and 126 KB in instead of 768 KB in; nothing but its own dG tile is ever converted to planes.
+// Every partial block has its own address within a launch (a ring of nslots > block length steps), so no compute unit can
+// hold a stale copy of a line it is about to read; across launches the kernel boundary orders the accesses.
+constexpr int Y_GBUF = 64 * 2048;                 // gather buffer: up to 64 producer blocks of [32][16] fp32
+constexpr int Y_TILE = Y_GBUF;                    // own dG_t tile as planes [3][32 rows][64 k] bf16 (swizzled like a forward chunk)
+constexpr int Y_DCST = Y_TILE + 3 * X_PLANE;      // dL/dc carry of the workgroup's cells, per chain [32][16]
+constexpr int Y_LDS = Y_DCST + X_MAXNS * X_SR * X_UN * 4;     // 151552 B
+
+__device__ __forceinline__ void seq_bwd_x3_body(const SeqBwdX3Args& p, const int bid, unsigned char* smem, int& s_flag) {
+    const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int kw = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave index = quarter of the output columns j
+    const int li = lane & 31, lh = lane >> 5;
+    const int H = p.H, B = p.B;
+    const int nC = (H + X_UN - 1) / X_UN;
+    const int cs = bid % nC, rg = bid / nC;
+    const int u0 = cs * X_UN, row0 = rg * p.RB;
+    const unsigned short* zero = reinterpret_cast<const unsigned short*>(g_zero4);
+
+    // ---- this wave's W_hh slice as A operands of v_mfma_f32_16x16x32_bf16 (lane (jl, kg): 8 consecutive k of output column
+    //      j = 256 kw + 16 jt + jl): wreg[(plane * 2 + ks) * 16 + jt]; k step ks covers the workgroup's k = 32 ks + 8 kg + e, i.e.
+    //      gate 2 ks + (kg >> 1), unit u0 + 8 (kg & 1) + e <-> W_hh^T column (2 ks + (kg >> 1)) Hp + u0 + 8 (kg & 1) + e
+    const int l16 = lane & 15, kg = lane >> 4;
+    bf16x8 wreg[96];
+    {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int jt = 0; jt < 16; ++jt) {
+                    const int j = 256 * kw + 16 * jt + l16;
+                    const unsigned short* q = (j < p.Kp) ? p.wtp + pl * p.wplane + (int64_t)j * p.ldw + (2 * ks + (kg >> 1)) * p.Hp + u0 + (kg & 1) * 8 : zero;
+                    wreg[(pl * 2 + ks) * 16 + jt] = *reinterpret_cast<const bf16x8*>(q);
+                }
+#pragma unroll
+        for (int i = 0; i < 32; ++i) asm volatile("" : "+v"(wreg[i]));
+#pragma unroll
+        for (int i = 32; i < 96; ++i) asm volatile("" : "+a"(wreg[i]));
+    }
+    // ---- B-fragment read address of lane (batch row 16 bt + l16, k group kg) for k step ks: piece 4 ks + kg of the dG tile
+    unsigned fa[2][2];
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int b = 16 * bt + l16;
+            fa[bt][ks] = lbase + (unsigned)(Y_TILE + b * 128 + (((4 * ks + kg) ^ ((b >> 1) & 7)) * 16));
+        }
+
+    // ---- cell role: 2 adjacent units of one row per thread
+    const int erow = tid >> 3, eul = (tid & 7) * 2;
+    const int eunit = u0 + eul;
+    const bool e_ok0 = eunit < H, e_ok1 = eunit + 1 < H;
+    const bool e_vec = e_ok1 && ((H & 1) == 0);
+    float* dcst = reinterpret_cast<float*>(smem + Y_DCST);
+    const bool last_block = (p.t1 == p.T);
+    for (int s = 0; s < p.NS; ++s) {
+        const int b = row0 + s * X_SR + erow;
+        f32x2 d0 = {0.f, 0.f};
+        if (!last_block && b < B) {
+            const float* q = p.dc + (int64_t)b * H + eunit;
+            if (e_ok0) d0[0] = q[0];
+            if (e_ok1) d0[1] = q[1];
+        }
+        *reinterpret_cast<f32x2*>(dcst + (s * X_SR + erow) * X_UN + eul) = d0;
+    }
+    const int64_t H4 = 4 * (int64_t)H;
+    const float* gbuf = reinterpret_cast<const float*>(smem);
+    unsigned char* tile = smem + Y_TILE;
+    // tile write position of this thread's two cells for gate g: row erow, piece 2g + (eul >> 3), element eul & 7
+    unsigned tw[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) tw[g] = (unsigned)(erow * 128 + (((2 * g + (eul >> 3)) ^ ((erow >> 1) & 7)) * 16) + (eul & 7) * 2);
+
+    for (int t = p.t1 - 1; t >= p.t0; --t) {
+#pragma unroll 1
+        for (int s = 0; s < p.NS; ++s) {
+            const int rbase = row0 + s * X_SR;
+            const int chain = rbase / X_SR;
+            unsigned int* cnt = p.sync + (rg * X_MAXNS + s) * 32;
+            const int xrec = (bid == p.stamp_block) ? (p.t1 - 1 - t) * p.NS + s : -1;
+            XSTAMP(p.stamps, xrec, 0);
+
+            // cell operands requested first, consumed after the gather
+            const int eb = rbase + erow;
+            const bool rok = eb < B;
+            const int64_t rowi = (int64_t)t * B + eb;
+            f32x2 stv[4], cv, cpv, dhov;
+            {
+                const float* st = p.stash_dg + rowi * H4 + eunit;
+                const float* cq = p.c_all + rowi * H + eunit;
+                const bool hasdh = p.dh_out && t >= p.dh_first;
+                const float* dq = hasdh ? p.dh_out + ((int64_t)(t - p.dh_first) * B + eb) * H + eunit : g_zero4;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float* q = st + (int64_t)g * H;
+                    if (e_vec) stv[g] = *reinterpret_cast<const f32x2*>(rok ? q : g_zero4);
+                    else { stv[g][0] = *((rok && e_ok0) ? q : g_zero4); stv[g][1] = *((rok && e_ok1) ? q + 1 : g_zero4); }
+                }
+                if (e_vec) {
+                    cv = *reinterpret_cast<const f32x2*>(rok ? cq : g_zero4);
+                    cpv = *reinterpret_cast<const f32x2*>((rok && t > 0) ? cq - (int64_t)B * H : g_zero4);
+                    dhov = *reinterpret_cast<const f32x2*>((rok && hasdh) ? dq : g_zero4);
+                } else {
+                    cv[0] = *((rok && e_ok0) ? cq : g_zero4); cv[1] = *((rok && e_ok1) ? cq + 1 : g_zero4);
+                    cpv[0] = *((rok && e_ok0 && t > 0) ? cq - (int64_t)B * H : g_zero4);
+                    cpv[1] = *((rok && e_ok1 && t > 0) ? cq - (int64_t)B * H + 1 : g_zero4);
+                    dhov[0] = *((rok && e_ok0 && hasdh) ? dq : g_zero4); dhov[1] = *((rok && e_ok1 && hasdh) ? dq + 1 : g_zero4);
+                }
+            }
+
+            f32x2 dh = {0.f, 0.f};
+            if (t < p.T - 1) {
+                // the nC partial blocks of dG_{t+1} . W_hh addressed to this column slice: published by every slice of the chain?
+                if (tid == 0) {
+                    const bool ok = spin_until_x(cnt, (unsigned int)(nC * (p.T - 1 - t)));
+                    s_flag = ok ? 1 : 0;
+                    if (!ok) atomicExch(p.err, 1);
+                }
+                X_BARRIER();
+                if (s_flag == 0) return;
+                XSTAMP(p.stamps, xrec, 1);
+                const unsigned char* src = reinterpret_cast<const unsigned char*>(
+                    p.part + (int64_t)(t % p.nslots) * p.part_slot + ((int64_t)(chain * nC + cs) * nC) * (X_SR * X_UN)) + lane * 16;
+                for (int r = kw; r < 2 * nC; r += 4) glds16x_sc1(src + r * 1024, smem + r * 1024);
+                XSTAMP(p.stamps, xrec, 2);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                X_BARRIER();
+                XSTAMP(p.stamps, xrec, 3);
+                const float* gp = gbuf + erow * X_UN + eul;
+                int c = 0;                  // summed in producer order; eight LDS reads in flight at a time
+                for (; c + 8 <= nC; c += 8) {
+                    f32x2 v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x2*>(gp + (c + i) * (X_SR * X_UN));
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) dh += v[i];
+                }
+                for (; c < nC; ++c) dh += *reinterpret_cast<const f32x2*>(gp + c * (X_SR * X_UN));
+            } else {
+                XSTAMP(p.stamps, xrec, 1);
+                XSTAMP(p.stamps, xrec, 2);
+                XSTAMP(p.stamps, xrec, 3);
+            }
+            XSTAMP(p.stamps, xrec, 4);
+
+            f32x2 dg[4];
+            {
+                f32x2* dp = reinterpret_cast<f32x2*>(dcst + (s * X_SR + erow) * X_UN + eul);
+                const f32x2 dcin = *dp;
+                f32x2 dcn;
+                unsigned short pb[4][2][3];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool ok = rok && (j ? e_ok1 : e_ok0);
+                    const float d = dh[j] + dhov[j];
+                    const float ig = stv[0][j], fg = stv[1][j], gg = stv[2][j], og = stv[3][j];
+                    const float tc = tanhf_(cv[j]);
+                    const float dc = d * og * (1.0f - tc * tc) + dcin[j];
+                    const float d_o = d * tc;
+                    dg[0][j] = ok ? dc * gg * ig * (1.0f - ig) : 0.f;
+                    dg[1][j] = ok ? dc * cpv[j] * fg * (1.0f - fg) : 0.f;
+                    dg[2][j] = ok ? dc * ig * (1.0f - gg * gg) : 0.f;
+                    dg[3][j] = ok ? d_o * og * (1.0f - og) : 0.f;
+                    dcn[j] = ok ? dc * fg : 0.f;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) split3_bits(dg[g][j], pb[g][j]);
+                }
+                *dp = dcn;
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        *reinterpret_cast<unsigned int*>(tile + pl * X_PLANE + tw[g]) = (unsigned int)pb[g][0][pl] | ((unsigned int)pb[g][1][pl] << 16);
+                if (rok) {
+                    float* st = p.stash_dg + rowi * H4 + eunit;
+                    if (e_vec) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x2*>(st + (int64_t)g * H) = dg[g];
+                        if (t == p.t0) *reinterpret_cast<f32x2*>(p.dc + (int64_t)eb * H + eunit) = dcn;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            if (j ? e_ok1 : e_ok0) {
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) st[(int64_t)g * H + j] = dg[g][j];
+                                if (t == p.t0) p.dc[(int64_t)eb * H + eunit + j] = dcn[j];
+                            }
+                    }
+                }
+            }
+            XSTAMP(p.stamps, xrec, 5);
+            X_BARRIER();           // the dG_t tile is complete (and everyone is done with the gather buffer)
+
+            if (t > 0) {           // partial products of dG_t for step t - 1 (nobody consumes those of step 0)
+                float* pslot = p.part + (int64_t)((t - 1) % p.nslots) * p.part_slot + ((int64_t)chain * nC * nC + cs) * (X_SR * X_UN)
+                               + l16 * X_UN + 4 * kg;
+                const int64_t cstride = (int64_t)nC * (X_SR * X_UN);           // floats between the blocks of two consumers
+                // the whole dG_t tile as B operands, once: gfr[plane][bt][ks] (12 fragments; every output column tile uses all)
+                bf16x8 gfr[3][2][2];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) X_DSR(gfr[pl][bt][ks], fa[bt][ks], pl * X_PLANE);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(gfr[pl][bt][ks]));
+#define Y_MF(W, G, ACC) ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, G, ACC, 0, 0, 0);
+                // two output column tiles (jt, jt + 1) x two batch tiles at a time: 48 MFMAs on four accumulators (the same one
+                // every fourth instruction), the six plane products small terms first; a finished 16 x 16 tile holds
+                // P^T[j = 4 kg + e][b = l16] in register e: ONE 16-byte store per lane = 16 rows x 64 B = 1 KB contiguous of the
+                // consumer's block [32 rows][16 units]
+#pragma unroll
+                for (int jp = 0; jp < 8; ++jp) {
+                    f32x4 acc[2][2];
+#pragma unroll
+                    for (int x = 0; x < 2; ++x)
+#pragma unroll
+                        for (int bt = 0; bt < 2; ++bt) acc[x][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define Y_PROD(WP, GP)                                                                                          \
+                    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
+                        _Pragma("unroll") for (int x = 0; x < 2; ++x)                                           \
+                            _Pragma("unroll") for (int bt = 0; bt < 2; ++bt)                                    \
+                                Y_MF(wreg[((WP) * 2 + ks) * 16 + 2 * jp + x], gfr[GP][bt][ks], acc[x][bt])
+                    Y_PROD(2, 0) Y_PROD(0, 2) Y_PROD(1, 1) Y_PROD(1, 0) Y_PROD(0, 1) Y_PROD(0, 0)
+#undef Y_PROD
+#pragma unroll
+                    for (int x = 0; x < 2; ++x) {
+                        const int cons = 16 * kw + 2 * jp + x;
+                        if (cons < nC) {
+#pragma unroll
+                            for (int bt = 0; bt < 2; ++bt) {
+                                float* dst = pslot + cons * cstride + bt * (16 * X_UN);
+                                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "a"(acc[x][bt]) : "memory");
+                            }
+                        }
+                    }
+                }
+#undef Y_MF
+                XSTAMP(p.stamps, xrec, 6);
+                // hand-off: EVERY wave stored a part of the payload: each drains its own stores, then the barrier, then one add
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                XSTAMP(p.stamps, xrec, 7);
+                X_BARRIER();
+                if (tid == 0) __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                XSTAMP(p.stamps, xrec, 8);
+            } else {
+                X_BARRIER();
+            }
+        }
+    }
+}
+
+// block roles as in the forward kernel (xg: XCD-aware dealing)
+__global__ __launch_bounds__(X_NT, 1) void lstm_seq_bwd_x3_persist_kernel(SeqBwdX3Args pa, SeqBwdX3Args pb, int na, int xg) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[Y_LDS];
+    __shared__ int s_flag;
+    const int bid = (int)blockIdx.x;
+    bool lb;
+    int vb;
+    if (xg > 0) {
+        const int nC = (pa.H + X_UN - 1) / X_UN;
+        const int x = bid & 7, q = bid >> 3, per = 8 / xg;
+        const int g = x % xg, cs = q * per + x / xg;
+        if (cs >= nC) return;
+        const int rgs = na / nC;
+        lb = g >= rgs;
+        vb = (lb ? g - rgs : g) * nC + cs;
+    } else {
+        lb = bid >= na;
+        vb = lb ? bid - na : bid;
+    }
+    seq_bwd_x3_body(lb ? pb : pa, vb, smem, s_flag);
+}
+
+static int bwd_x3_capacity() {
+    const int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_bwd_x3_persist_kernel), X_NT);
+    return cap < X_MAX_WG ? cap : X_MAX_WG;
+}
+int lstm_seq_bwd_x3_persist_supported(int B, int H) {
+    if (!(B > 0 && B % X_SR == 0 && H >= 8 && H <= 1024)) return 0;
+    const int cap = bwd_x3_capacity();
+    const int nC = cdiv(H, X_UN);
+    int R = B / X_SR, ns = 1;
+    while (R * nC > cap / 2 && ns < X_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }
+    return (R * nC <= cap / 2 && R <= 64) ? ns : 0;
+}
+// floats of one ring slot of the partial-sum buffer: [chains][nC consumers][nC producers][32][16]
+size_t lstm_seq_bwd_x3_part_slot_floats(int B, int H) {
+    const size_t nC = (size_t)cdiv(H, X_UN);
+    return (size_t)(B / X_SR) * nC * nC * X_SR * X_UN;
+}
+
+static int prep_y(SeqBwdX3Args& a) {
+    const int ns = lstm_seq_bwd_x3_persist_supported(a.B, a.H);
+    S2VT_REQUIRE(ns > 0, "lstm_seq_bwd_x3_persist: unsupported shape (B %% 32, H <= 1024) or it does not fit the device's resident capacity");
+    S2VT_REQUIRE(a.t1 > a.t0 && a.t0 >= 0 && a.t1 <= a.T && a.wtp && a.stash_dg && a.c_all && a.dc && a.part && a.sync && a.err &&
+                     a.dh_first >= 0, "lstm_seq_bwd_x3_persist: bad arguments");
+    S2VT_REQUIRE(a.Kp == (a.H + 63) / 64 * 64 && a.Hp == cdiv(a.H, X_UN) * X_UN && a.ldw >= 4 * (int64_t)a.Hp && a.ldw % 8 == 0 &&
+                     a.wplane % 8 == 0 && (reinterpret_cast<uintptr_t>(a.wtp) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.part) & 15) == 0,
+                 "lstm_seq_bwd_x3_persist: W_hh^T planes must be [3][Kp][4 Hp], 16-byte aligned");
+    S2VT_REQUIRE(a.nslots > a.t1 - a.t0 && (size_t)a.part_slot >= lstm_seq_bwd_x3_part_slot_floats(a.B, a.H) && a.part_slot % 4 == 0,
+                 "lstm_seq_bwd_x3_persist: the partial-sum ring needs more slots than the launch has timesteps");
+    a.NS = ns;
+    a.RB = ns * X_SR;
+    return 0;
+}
+
+int lstm_seq_bwd_x3_persist2(hipStream_t stream, SeqBwdX3Args a, const SeqBwdX3Args* b) {
+    int rc;
+    if ((rc = prep_y(a))) return rc;
+    SeqBwdX3Args bb = b ? *b : a;
+    if (b) {
+        if ((rc = prep_y(bb))) return rc;
+        S2VT_REQUIRE(bb.sync != a.sync && bb.part != a.part, "lstm_seq_bwd_x3_persist: paired layers need their own counters and partial sums");
+    }
+    const int nC = cdiv(a.H, X_UN);
+    const int na = (a.B / a.RB) * nC, nb = b ? (bb.B / bb.RB) * cdiv(bb.H, X_UN) : 0;
+    S2VT_REQUIRE(na + nb <= bwd_x3_capacity(), "lstm_seq_bwd_x3_persist: %d workgroups would not be co-resident (device capacity %d)",
+                 na + nb, bwd_x3_capacity());
+    // the hand-off counters count finished timesteps of the whole sequence: zeroed with its first block (t1 == T) only
+    if (a.t1 == a.T) S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
+    if (b && bb.t1 == bb.T) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
+    static const bool xcd_on = !(getenv("S2VT_PERSIST_XCD") && atoi(getenv("S2VT_PERSIST_XCD")) == 0);
+    const int G = (na + nb) / nC;
+    int xg = 0, grid = na + nb;
+    if (xcd_on && (!b || (bb.B == a.B && bb.H == a.H)) && G > 0 && G <= 8 && 8 % G == 0) {
+        const int padded = 8 * cdiv(nC, 8 / G);
+        if (padded <= bwd_x3_capacity()) { xg = G; grid = padded; }
+    }
+    hipLaunchKernelGGL(lstm_seq_bwd_x3_persist_kernel, dim3(grid), dim3(X_NT), 0, stream, a, bb, na, xg);
+    S2VT_LAUNCH_CHECK("lstm_seq_bwd_x3_persist_kernel");
+    return 0;
+}
+
+// W_hh^T fp32 [H][4H] (row j: the 4H gate columns k = g H + u) -> three bf16 planes [3][Kp][4 Hp] with the gate blocks re-based
+// to k' = g Hp + u (Hp = H rounded up to 16: every workgroup's 16-unit block is 16-byte aligned), pad rows / columns zero
+__global__ __launch_bounds__(256) void split3_wt_kernel(const float* __restrict__ wt, int H, int Kp, int Hp,
+                                                        unsigned short* __restrict__ dst, int64_t plane) {
+    const int64_t n = (int64_t)Kp * (2 * Hp);             // pairs of k'
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i / (2 * Hp)), kp = (int)(i % (2 * Hp)) * 2;
+        const int g = kp / Hp, u = kp % Hp;
+        unsigned short a[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+        if (j < H && u < H) split3_bits(wt[(int64_t)j * 4 * H + (int64_t)g * H + u], a);
+        if (j < H && u + 1 < H) split3_bits(wt[(int64_t)j * 4 * H + (int64_t)g * H + u + 1], b);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<unsigned int*>(dst + pl * plane + (int64_t)j * 4 * Hp + kp) = (unsigned int)a[pl] | ((unsigned int)b[pl] << 16);
+    }
+}
+int split3_wt(hipStream_t stream, const float* wt, int H, int Kp, int Hp, unsigned short* dst, int64_t plane) {
+    S2VT_REQUIRE(wt && dst && H > 0 && Kp >= H && Hp >= H && Hp % 2 == 0 && plane >= (int64_t)Kp * 4 * Hp, "split3_wt: bad arguments");
+    const int64_t n = (int64_t)Kp * (2 * Hp);
+    const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(split3_wt_kernel, dim3(grid), dim3(256), 0, stream, wt, H, Kp, Hp, dst, plane);
+    S2VT_LAUNCH_CHECK("split3_wt_kernel");
+    return 0;
+}
+
 }  // namespace s2vt

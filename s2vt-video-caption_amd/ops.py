@@ -318,12 +318,25 @@ def lstm_seq_fwd_persist(T, B, gx, n_gx, bias, w_hh, block=0, second=None, x3=Fa
     return outs[0] if second is None else tuple(outs)
 
 
-def lstm_seq_bwd_persist(T, B, w_hh, dh_out, dh_first, c_all, gates, block=0, second=None):
-    """fp32 BPTT with the persistent kernel: returns dG (`gates` untouched).  `second` = (w_hh, dh_out, c_all, gates)."""
+def lstm_seq_bwd_persist(T, B, w_hh, dh_out, dh_first, c_all, gates, block=0, second=None, x3=False):
+    """fp32 BPTT with the persistent kernel: returns dG (`gates` untouched).  `second` = (w_hh, dh_out, c_all, gates).
+    x3: the split-precision reduce-scatter kernel (lstm_persist_x3.hip) instead of the exact-fp32 MFMA one."""
     lib = capi.load()
     w_hh = _f32c(w_hh, "w_hh")
     H = w_hh.shape[1]
     dev = w_hh.device
+    if x3:
+        with torch.cuda.device(dev):
+            n = lib.s2vt_lstm_seq_bwd_x3_workspace_bytes(T, B, H, int(block))
+            ws = torch.full((n,), 0xFF, dtype=torch.uint8, device=dev)     # (NaN patterns: nothing may be read before it is written)
+            sets = [(_f32c(w, "w_hh"), dh, _f32c(c, "c_all"), _f32c(g, "gates").clone())
+                    for w, dh, c, g in [(w_hh, dh_out, c_all, gates)] + ([second] if second is not None else [])]
+            a, b2 = sets[0], (sets[1] if len(sets) > 1 else (None,) * 4)
+            capi.check(lib.s2vt_lstm_seq_bwd_x3_persist(T, B, H, _ptr(a[0]), _ptr(b2[0]), _ptr(a[1]), _ptr(b2[1]), int(dh_first),
+                                                        _ptr(a[2]), _ptr(b2[2]), _ptr(a[3]), _ptr(b2[3]), int(block), _ptr(ws), n,
+                                                        _stream(dev)), "s2vt_lstm_seq_bwd_x3_persist")
+            _check_persist_err(ws)
+        return sets[0][3] if second is None else (sets[0][3], sets[1][3])
     with torch.cuda.device(dev):
         ws, n = _persist_ws(dev)
         sets = []

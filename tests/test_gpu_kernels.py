@@ -697,6 +697,75 @@ def test_persistent_fp32_bptt(lib, T, B, H, dh_first, block):
     assert (got - per_step).abs().max().item() < 4e-6 * scale + 1e-9
 
 
+def _bptt_fp64(w, gates, c_all, dh, dh_first, T, B, H):
+    wd, cd, gd, dhd = w.double(), c_all.double(), gates.double(), dh.double()
+    ref = torch.zeros(T * B, 4 * H, dtype=torch.float64)
+    dc = torch.zeros(B, H, dtype=torch.float64)
+    nxt = None
+    for t in range(T - 1, -1, -1):
+        d = torch.zeros(B, H, dtype=torch.float64)
+        if nxt is not None:
+            d += nxt @ wd
+        if t >= dh_first:
+            d += dhd[(t - dh_first) * B:(t - dh_first + 1) * B]
+        i, f, g, o = gd[t * B:(t + 1) * B].chunk(4, dim=1)
+        c = cd[t * B:(t + 1) * B]
+        cp = cd[(t - 1) * B:t * B] if t else torch.zeros_like(c)
+        tc = torch.tanh(c)
+        dct = d * o * (1 - tc * tc) + dc
+        nxt = torch.cat([dct * g * i * (1 - i), dct * cp * f * (1 - f), dct * i * (1 - g * g), d * tc * o * (1 - o)], dim=1)
+        ref[t * B:(t + 1) * B] = nxt
+        dc = dct * f
+    return ref
+
+
+@pytest.mark.parametrize("T,B,H,dh_first,block", [(6, 32, 128, 2, 0), (7, 64, 1000, 0, 3), (5, 128, 1000, 1, 0), (9, 96, 520, 3, 4),
+                                                  (4, 256, 1000, 0, 0), (5, 32, 8, 0, 2), (12, 64, 1000, 5, 5), (5, 64, 1024, 2, 0),
+                                                  (4, 32, 70, 1, 2)])
+def test_persistent_split_precision_bptt(lib, T, B, H, dh_first, block):
+    """lstm_seq_bwd_x3_persist_kernel: the contraction dG_{t+1} . W_hh split over the gate columns (every workgroup multiplies its
+    own dG tile with its 64 rows of W_hh, planes resident in registers, and the fp32 partial sums are scattered / gathered per
+    consumer in a fixed order).  Same bounds as the exact-fp32 persistent kernel: fp64 BPTT, the launch-per-timestep kernels,
+    itself bit for bit; the workspace arrives full of NaN patterns."""
+    from s2vt_video_caption_amd import ops
+    w, gates, c_all = _bptt_inputs(T, B, H, 90)
+    dh = _r((T - dh_first) * B, H, seed=99, scale=0.1)
+    args = (T, B, w.to(DEV), dh.to(DEV), dh_first, c_all.to(DEV), gates.to(DEV))
+    got = ops.lstm_seq_bwd_persist(*args, block=block, x3=True)
+    again = ops.lstm_seq_bwd_persist(*args, block=block, x3=True)
+    assert torch.equal(got, again)
+    ref = _bptt_fp64(w, gates, c_all, dh, dh_first, T, B, H)
+    scale = ref.abs().max().item()
+    assert (got.cpu().double() - ref).abs().max().item() < 4e-6 * scale + 1e-9
+    per_step = ops.lstm_seq_bwd(T, B, w.to(DEV), dh.to(DEV), dh_first, c_all.to(DEV), gates.to(DEV).clone())
+    assert (got - per_step).abs().max().item() < 4e-6 * scale + 1e-9
+
+
+def test_persistent_split_precision_bptt_two_layers_one_launch_under_load(lib):
+    """Two layers per launch at the config-2 shape while another stream loads the chip: each layer equals its solo run bit for
+    bit (a stale or early hand-off of the partial sums is timing dependent)."""
+    from s2vt_video_caption_amd import ops
+    T, B, H, dh_first = 20, 64, 1000, 6
+    ins = [_bptt_inputs(T, B, H, 170 + 10 * k) for k in range(2)]
+    dhs = [_r((T - dh_first) * B, H, seed=179 + k, scale=0.1) for k in range(2)]
+    dev = [tuple(x.to(DEV) for x in i) for i in ins]
+    ddh = [d.to(DEV) for d in dhs]
+    solo = [ops.lstm_seq_bwd_persist(T, B, dev[k][0], ddh[k], dh_first, dev[k][2], dev[k][1], block=7, x3=True) for k in range(2)]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    big = torch.randn(32 * 1024 * 1024, device=DEV)
+    with torch.cuda.stream(side):
+        for _ in range(20):
+            big = big * 1.0001 + 1.0
+    pair = ops.lstm_seq_bwd_persist(T, B, dev[0][0], ddh[0], dh_first, dev[0][2], dev[0][1], block=7,
+                                    second=(dev[1][0], ddh[1], dev[1][2], dev[1][1]), x3=True)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert torch.equal(pair[k], solo[k])
+        ref = _bptt_fp64(ins[k][0], ins[k][1], ins[k][2], dhs[k], dh_first, T, B, H)
+        assert (pair[k].cpu().double() - ref).abs().max().item() < 4e-6 * ref.abs().max().item() + 1e-9
+
+
 def test_persistent_fp32_two_layers_one_launch_under_load(lib):
     """Both fp32 persistent kernels with two layers per launch at the config-2 shape while another stream loads the chip:
     each layer equals its solo run bit for bit (a stale hand-off is timing dependent)."""
