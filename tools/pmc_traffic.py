@@ -18,6 +18,7 @@ for tag in ("fetch", "write", "l2"):
             for key in ("gemm_x3_kernel", "gemm_f32_kernel", "gemm_b1_kernel", "lstm_step_fwd_kernel", "lstm_step_bwd_kernel",
                         "lstm_step_fwd_bf16_kernel", "lstm_step_bwd_bf16_kernel", "lstm_seq_fwd_bf16_persist_kernel",
                         "lstm_seq_bwd_bf16_persist_kernel", "lstm_seq_fwd_f32_persist_kernel", "lstm_seq_bwd_f32_persist_kernel",
+                        "lstm_seq_fwd_x3_persist_kernel", "lstm_seq_bwd_x3_persist_kernel", "split3_rows_kernel",
                         "split_dual_kernel", "logits_argmax_x3_kernel", "logits_argmax_kernel", "ce_row_kernel", "ce_bwd_kernel"):
                 if key in n and fam is None:
                     fam = key
