@@ -395,6 +395,8 @@ if __name__ == "__main__":
         gen_long()
     if "mid64long" in which:
         gen_long("mid64long", "mid64", seed=41)
+    if "c2long" in which:   # BASELINE configs[1] (the headline) at its own size: 10 fp32 reference Adam steps (lr 1e-3) on one B=64
+        gen_long("c2long", "c2", seed=7, n_steps=10)       # batch; the fp32-equivalent GPU trajectory must stay within 1e-4 of it
     if "c3long" in which:   # BASELINE configs[2] at its own size: 10 fp32 reference Adam steps (lr 1e-3) on one B=256 batch;
         gen_long("c3long", "c3", seed=5, n_steps=10)       # the bf16 GPU trajectory is compared with it step by step
     if "c5full" in which:

@@ -37,6 +37,7 @@ struct GemmX3Args {
     int accumulate;
     int ksplit;
     float* slabs;
+    int m_base, m_tiles;                      // this launch covers m_tiles row tiles from row m_base (m_tiles == 0: all of M)
 };
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int ntn = (p.N + XT - 1) / XT, ntm = (p.M + TMR - 1) / TMR;
+    const int ntn = (p.N + XT - 1) / XT, ntm = p.m_tiles ? p.m_tiles : (p.M + TMR - 1) / TMR;
     const int nwg = ntm * ntn, cpx = (nwg + 7) >> 3;
     const int t = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
     if ((int)(blockIdx.x >> 3) >= cpx || t >= nwg) return;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
     const int gsz = GM * ntn, grp = t / gsz, first_m = grp * GM;
     const int gm = (ntm - first_m < GM) ? (ntm - first_m) : GM;
     const int tm = first_m + (t % gsz) % gm, tn = (t % gsz) / gm;
-    const int m0 = tm * TMR, n0 = tn * XT;
+    const int m0 = p.m_base + tm * TMR, n0 = tn * XT;
     const int kbeg = blockIdx.y * p.ksplit;
     const int kend = (kbeg + p.ksplit < p.K) ? kbeg + p.ksplit : p.K;
     const int nk = (kend - kbeg) >> 4;                 // k16 stages
@@ -207,6 +208,7 @@ int gemm_x3(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
     p.A = A; p.lda = lda;
     p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.cmap = cmap; p.bias = bias; p.accumulate = accumulate ? 1 : 0;
+    p.m_base = 0; p.m_tiles = 0;
     // One workgroup per CU.  Tile height (256 or 128 rows) and split-K factor are chosen by a time model: rounds of 256
     // workgroups x per-tile time + the fixed-order slab combine.  Per k unit of a tile ~0.14 us at 256x256 (2.2 us per
     // k16 stage) and ~0.092 us at 128x256 (measured: tools/bench_x3_split.py with S2VT_X3_TM); ~6 us per tile of prologue/epilogue; combine = (n + 1) passes over M x N
@@ -229,6 +231,32 @@ int gemm_x3(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
                 const double t = rounds * (ks * ck + 6.0) + (nn > 1 ? (nn + 1.0) * M * (double)N * 4.0 / 3.5e6 + 8.0 : 0.0);
                 if (t < best * 0.97) { best = t; nsplit = nn; tmr = rows; }
             }
+        }
+    }
+    // Tile quantisation without split-K: 320 tiles of 256 rows are two rounds of the chip with the second a quarter full.  Two
+    // launches instead - `a` row tiles of 256 rows that fill whole rounds, the remaining rows as 128-row tiles - when the same
+    // time model says so (gx1 / gxe of config 2: 20 x 16 tiles -> 16 x 16 of 256 rows + 8 x 16 of 128: 299 -> 249 us).
+    static int mixed_on = -1;    // S2VT_X3_MIXED=0: off
+    if (mixed_on < 0) { const char* e = getenv("S2VT_X3_MIXED"); mixed_on = e ? (atoi(e) != 0) : 1; }
+    if (mixed_on && !force_tm && nsplit == 1 && tmr == 256) {
+        const int ntn = cdiv(N, XT), ntm = cdiv(M, 256);
+        const double c256 = K * 0.14 + 6.0, c128 = K * 0.092 + 6.0;
+        const double t_single = (double)cdiv(ntm * ntn, 256) * c256;
+        int best_a = 0;
+        double best_t = t_single * 0.93;                 // (a second launch has to pay for itself)
+        for (int a = 1; a < ntm; ++a) {
+            const int rest = cdiv(M - a * 256, 128);
+            const double t = (double)cdiv(a * ntn, 256) * c256 + (double)cdiv(rest * ntn, 256) * c128 + 2.0;
+            if (t < best_t) { best_t = t; best_a = a; }
+        }
+        if (best_a > 0) {
+            p.ksplit = K; p.slabs = nullptr;
+            p.m_base = 0; p.m_tiles = best_a;
+            hipLaunchKernelGGL(gemm_x3_kernel<4>, dim3(cdiv(best_a * ntn, 8) * 8, 1), dim3(512), 0, stream, p);
+            p.m_base = best_a * 256; p.m_tiles = cdiv(M - best_a * 256, 128);
+            hipLaunchKernelGGL(gemm_x3_kernel<2>, dim3(cdiv(p.m_tiles * ntn, 8) * 8, 1), dim3(512), 0, stream, p);
+            S2VT_LAUNCH_CHECK("gemm_x3_kernel");
+            return 0;
         }
     }
     const int tiles = cdiv(M, tmr) * cdiv(N, XT);

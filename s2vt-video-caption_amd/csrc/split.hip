@@ -26,6 +26,12 @@ __device__ __forceinline__ void split3(float x, unsigned short (&o)[3]) {
     }
 }
 
+// LDS staging tile of the transposing kernels: 64 x 64 fp32, row stride 68 floats (rows 16-byte aligned: a 16-byte global
+// load lands as one ds_write_b128, an 8-element run leaves as two ds_read_b128) with element (r, c) at column c ^ TSW(r):
+// the column reads of the plain-layout transposed path (lanes = 8 consecutive c x 8 row octets) then hit 64 distinct banks
+// (8 * 68 = 32 mod 64 alone would fold the octets onto two bank groups); runs of 8 columns stay contiguous.
+#define TSW(r) ((((r) >> 3) & 7) << 3)
+
 // Plane layouts.  1 plane (bf16 mode, gemm_bf16.hip / lstm_bf16.hip): plain k-major rows, element (r, k) at r*ldo + k.
 // 3 planes (split precision, gemm_x3.hip): BLOCKED - per 64-row block and 16-wide k chunk one 6-KB record of six
 // 1-KB pieces (plane, k half), each piece = 64 rows x 8 consecutive k:
@@ -79,12 +85,25 @@ template <int NP>
 __global__ __launch_bounds__(256) void split_transpose_kernel(const float* in, int64_t ld, RowMap imap, int rows, int cols,
                                                               unsigned short* out, int64_t ldo, int kpad,
                                                               int cols_pad) {
-    __shared__ float tile[64][65];
+    __shared__ __attribute__((aligned(16))) float tile[64][68];       // (row stride 68: see split_dual_kernel)
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    for (int i = ty; i < 64; i += 4) {
-        const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < rows && c < cols) ? in[(int64_t)map_row(imap, r) * ld + c] : 0.f;
+    const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {          // 16 bytes per lane and load
+        const int i = it * 256 + (int)threadIdx.x;
+        const int rl = i >> 4, cl = (i & 15) * 4;
+        const int r = r0 + rl, c = c0 + cl;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows && c < cols) {
+            const float* src = in + (int64_t)map_row(imap, r) * ld + c;
+            if (vec_ok && c + 3 < cols) {
+                x = *reinterpret_cast<const f32x4*>(src);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = (c + j < cols) ? src[j] : 0.f;
+            }
+        }
+        *reinterpret_cast<f32x4*>(&tile[rl][cl ^ TSW(rl)]) = x;
     }
     __syncthreads();
     // each thread: one output row (c) segment of 8 consecutive r
@@ -96,7 +115,7 @@ __global__ __launch_bounds__(256) void split_transpose_kernel(const float* in, i
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             unsigned short t[3];
-            split3<NP>(tile[rq + j][cl], t);
+            split3<NP>(tile[rq + j][cl ^ TSW(rq + j)], t);
 #pragma unroll
             for (int pl = 0; pl < NP; ++pl) o[pl][j] = t[pl];
         }
@@ -124,12 +143,14 @@ __global__ __launch_bounds__(256) void split_dual_kernel(const float* in, int64_
                                                          unsigned short* out_r, int64_t ldo_r, int kpad_r,
                                                          unsigned short* out_t, int64_t ldo_t, int kpad_t,
                                                          float* colpart, CeGradArgs ce) {
-    __shared__ float tile[64][65];
+    // 64 x 64 fp32 tile, row stride 68 floats: rows stay 16-byte aligned (16-byte global loads land as one ds_write_b128, the
+    // row-plane path reads two ds_read_b128 per 8-element run: conflict-free per 16-lane group) and the transposed path's
+    // scalar column reads see consecutive banks
+    __shared__ __attribute__((aligned(16))) float tile[64][68];
     __shared__ float row_lse[64];          // CE only: per tile row, fetched once (the index arithmetic of a target is two
     __shared__ int row_tgt[64];            // integer divisions: per ELEMENT they cost more than the split itself)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     float ce_scale = 0.f;
     if (CE) {
         if (threadIdx.x < 64) {
@@ -147,17 +168,35 @@ __global__ __launch_bounds__(256) void split_dual_kernel(const float* in, int64_
         ce_scale = ce.gout[0] / (float)rows;
         __syncthreads();
     }
-    for (int i = ty; i < 64; i += 4) {
-        const int r = r0 + i, c = c0 + tx;
-        float x = (r < rows && c < cols) ? in[(int64_t)map_row(imap, r) * ld + c] : 0.f;
-        if (CE && r < rows && c < cols) x = (expf(x - row_lse[i]) - (c == row_tgt[i] ? 1.f : 0.f)) * ce_scale;
-        tile[i][tx] = x;
+    // 16 bytes per lane and load (a wave covers 4 rows x 256 B): 4-byte loads cannot keep HBM busy
+    const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int i = it * 256 + (int)threadIdx.x;
+        const int rl = i >> 4, cl = (i & 15) * 4;
+        const int r = r0 + rl, c = c0 + cl;
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows && c < cols) {
+            const float* src = in + (int64_t)map_row(imap, r) * ld + c;
+            if (vec_ok && c + 3 < cols) {
+                x = *reinterpret_cast<const f32x4*>(src);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = (c + j < cols) ? src[j] : 0.f;
+            }
+            if (CE) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    x[j] = (c + j < cols) ? (expf(x[j] - row_lse[rl]) - (c + j == row_tgt[rl] ? 1.f : 0.f)) * ce_scale : 0.f;
+            }
+        }
+        *reinterpret_cast<f32x4*>(&tile[rl][cl ^ TSW(rl)]) = x;
     }
     __syncthreads();
     if (colpart && threadIdx.x < 64 && c0 + (int)threadIdx.x < cols) {
         float sum = 0.f;
 #pragma unroll 8
-        for (int i = 0; i < 64; ++i) sum += tile[i][threadIdx.x];
+        for (int i = 0; i < 64; ++i) sum += tile[i][(int)threadIdx.x ^ TSW(i)];
         colpart[(int64_t)blockIdx.y * cols + c0 + threadIdx.x] = sum;
     }
     for (int s = threadIdx.x; s < 64 * 8; s += 256) {
@@ -167,10 +206,12 @@ __global__ __launch_bounds__(256) void split_dual_kernel(const float* in, int64_
             const int r = r0 + a, c = c0 + bq;
             if (r < rows && c < kpad_r) {
                 unsigned short o[3][8];
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(&tile[a][bq ^ TSW(a)]), hi = *reinterpret_cast<const f32x4*>(&tile[a][(bq ^ TSW(a)) + 4]);
+                const float run[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     unsigned short t[3];
-                    split3<NP>(tile[a][bq + j], t);
+                    split3<NP>(run[j], t);
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) o[pl][j] = t[pl];
                 }
@@ -188,7 +229,7 @@ __global__ __launch_bounds__(256) void split_dual_kernel(const float* in, int64_
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     unsigned short t[3];
-                    split3<NP>(tile[bq + j][a], t);
+                    split3<NP>(tile[bq + j][a ^ TSW(bq + j)], t);
 #pragma unroll
                     for (int pl = 0; pl < NP; ++pl) o[pl][j] = t[pl];
                 }

@@ -101,6 +101,28 @@ def test_plain_bf16_gemm_rows(lib, M, N, K):
     assert torch.equal(goti, ai @ bi.t())
 
 
+def test_split_precision_gemm_mixed_tile_heights(lib):
+    """gx1 of config 2 (5120 x 4000 x 1000): 320 tiles of 256 rows would be two rounds of the chip with the second a quarter
+    full, so the launcher runs 16 row tiles of 256 rows and the last 1024 rows as 128-row tiles (two launches, gemm_x3.hip):
+    every output row against fp64 (a row range served twice or not at all would show), integers exact, bias and accumulate."""
+    from s2vt_video_caption_amd import ops
+    M, N, K = 5120, 4000, 1000
+    g = torch.Generator().manual_seed(9)
+    ai = torch.randint(-3, 4, (M, K), generator=g).float()
+    bi = torch.randint(-3, 4, (N, K), generator=g).float()
+    got = ops.gemm_planes(ops.split_planes(ai.to(DEV)), ops.split_planes(bi.to(DEV)), M, N)
+    assert torch.equal(got, ai.to(DEV) @ bi.to(DEV).t())          # (integer products: any fp32 matmul is exact on them)
+    a, b, bias = _r(M, K, seed=1), _r(N, K, seed=2), _r(N, seed=3)
+    ref = (a.double() @ b.double().t()) + bias.double()
+    tol = 4e-6 * ref.abs().max().item() + 1e-6
+    pa, pb = ops.split_planes(a.to(DEV)), ops.split_planes(b.to(DEV))
+    got = ops.gemm_planes(pa, pb, M, N, bias=bias.to(DEV))
+    assert (got.cpu().double() - ref).abs().max().item() < tol
+    out = torch.ones(M, N, device=DEV)
+    ops.gemm_planes(pa, pb, M, N, out=out, accumulate=True)
+    assert (out.cpu().double() - (ref - bias.double() + 1.0)).abs().max().item() < tol
+
+
 def test_split_precision_gemm_is_exact_on_integers(lib):
     """Small integers are exact in the hi plane (mid/lo planes zero) and every partial sum is representable: the
     result must be exact - catches any wrong piece / fragment / k mapping of the blocked layout."""

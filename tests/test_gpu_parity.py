@@ -177,7 +177,7 @@ def _c2_body(g, d, sd, feats, caps, mask, greedy=True):
 
 @pytest.mark.parametrize("name,cfg,gemm_mode,bound", [("c1long", "c1", 3, 1e-4), ("mid64long", "mid64", 3, 1e-4),
                                                       ("mid64long", "mid64", 0, 1e-4), ("mid64long", "mid64", 1, 5e-2),
-                                                      ("c3long", "c3", 1, 2e-2)])
+                                                      ("c3long", "c3", 1, 2e-2), ("c2long", "c2", 3, 1e-4)])
 def test_long_loss_trajectory_against_reference(lib, golden, name, cfg, gemm_mode, bound):
     """FORTY Adam steps on one fixed batch at ten times train.py's learning rate (the reference's loss falls from 4.6 to
     0.007 at c1 dims, from 7.0 to 2.1 at B=64): every step runs on weights that carry the rounding history of all earlier
@@ -187,7 +187,10 @@ def test_long_loss_trajectory_against_reference(lib, golden, name, cfg, gemm_mod
     trajectory.  Final parameter norms within 1e-4 (fp32) / 2e-2 (bf16) relative.
     c3long: BASELINE configs[2] AT ITS OWN SIZE (B=256, H=E=1000, V=12000): TEN fp32 Adam steps of the reference (lr 1e-3,
     one batch; train.py:116-127) against the bf16 configuration - persistent recurrence, bf16 batched GEMMs - step by step:
-    |loss - reference| < 2e-2 at every step while the reference's loss moves by far more than that, final norms within 2 %."""
+    |loss - reference| < 2e-2 at every step while the reference's loss moves by far more than that, final norms within 2 %.
+    c2long: BASELINE configs[1] - the headline workload - AT ITS OWN SIZE (B=64, H=E=1000, V=12000): ten fp32 Adam steps of the
+    reference against the timed configuration (split-precision GEMMs, split-precision persistent forward recurrence, two-lane
+    BPTT): north_star's 1e-4 on the loss at every step, final parameter norms within 1e-4."""
     import utils
     g = golden(name)
     d = synth.CONFIGS[cfg]
