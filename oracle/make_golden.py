@@ -204,6 +204,78 @@ def gen_long(name="c1long", cfg="c1", seed=31, n_steps=40, lr=1e-3):
     print(f"[{name}] wrote {os.path.join(GOLD, name + '.npz')}")
 
 
+ATT_CONFIGS = {"att_tiny": dict(B=5, L=8, F=48, H=32, E=24, V=60, seed=3, full=True),
+               "att_mid": dict(B=16, L=20, F=256, H=128, E=96, V=300, seed=4, full=False)}
+
+
+def gen_att(name):
+    """The reference's SECOND network, Att_Baseline (attention_baseline.py:9-105; what its committed train.py instantiates):
+    one train forward + MaskCriterion loss + backward and one greedy decode of the reference itself on seeded inputs.  Stored:
+    the seeded default initialisation (arrays for the tiny case, the seed for the larger one - the drop-in creates its
+    parameter containers in the reference's order, checked here), logits, loss, every parameter's gradient (full / norm +
+    head), greedy ids and the top-2 margin of every decision."""
+    import importlib.util
+    sys.path.insert(0, REF)
+    spec = importlib.util.spec_from_file_location("_ref_attention_baseline", os.path.join(REF, "attention_baseline.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    _, Crit = _reference()
+    d = ATT_CONFIGS[name]
+    torch.manual_seed(d["seed"])
+    m = ref.Att_Baseline(d["V"], d["F"], d["L"], dim_hid=d["H"], dim_embed=d["E"])
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    feats, caps, mask = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=900 + d["seed"])
+    m.train()
+    logits = m(feats, targets=caps[:, :-1], mode="train")
+    loss = Crit()(logits, caps, mask)
+    loss.backward()
+    grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in m.named_parameters()}
+    m.eval()
+    with torch.no_grad():
+        ids = m(feats, mode="test")
+        # replay of the greedy loop on the reference's own sub-modules for the margins (attention_baseline.py:85-104)
+        x = m.feat_linear(feats)
+        enc, _ = m.encoder(x)
+        ctxv = enc.sum(dim=1, keepdim=True)             # softmax over a size-one dimension: all weights 1
+        tok = torch.full((d["B"],), m.sos_ix, dtype=torch.long)
+        state, rid, marg = None, [], []
+        for _ in range(d["L"]):
+            out, state = m.decoder(torch.cat([m.embedding(tok).unsqueeze(1), ctxv], dim=2), state)
+            pr = m.out_linear(out)[:, 0]
+            top = pr.topk(2, dim=1).values
+            marg.append(top[:, 0] - top[:, 1])
+            tok = pr.argmax(dim=1)
+            rid.append(tok)
+        assert torch.equal(torch.stack(rid, 1), ids), "replay of the reference's greedy loop differs from the reference"
+    # the drop-in's seeded default initialisation must equal the reference's (same containers in the same order)
+    spec2 = importlib.util.spec_from_file_location("_mine_attention_baseline", os.path.join(ROOT, "attention_baseline.py"))
+    mine = importlib.util.module_from_spec(spec2)        # the repo's drop-in, loaded by path (REF is in front on sys.path)
+    spec2.loader.exec_module(mine)
+    torch.manual_seed(d["seed"])
+    mm = mine.Att_Baseline(d["V"], d["F"], d["L"], dim_hid=d["H"], dim_embed=d["E"])
+    for k, v in mm.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    out = dict(seed=d["seed"], dims=np.array([d[k] for k in "BLFHEV"], dtype=np.int64), loss=np.array(float(loss)),
+               keys=np.array(list(sd.keys())), shapes=np.array([str(tuple(v.shape)) for v in sd.values()]),
+               ids=ids.numpy(), margins=torch.stack(marg, 1).numpy())
+    if d["full"]:
+        out["logits"] = logits.detach().numpy()
+        for k, v in sd.items():
+            out["param/" + k] = v.numpy()
+    else:
+        out["logits_rows"] = logits.detach()[:, ::3, :64].contiguous().numpy()
+        out["logits_abs_sum"] = np.array(logits.detach().double().abs().sum().item())
+    for k, g in grads.items():
+        assert g is not None, k                           # the attention layers get zeros, not None
+        out["gradnorm/" + k] = np.array(g.double().norm().item())
+        out["gradhead/" + k] = g.reshape(-1)[:32].numpy()
+        if d["full"]:
+            out["grad/" + k] = g.numpy()
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[{name}] loss {float(loss):.6f}, weakest greedy top-2 margin {float(torch.stack(marg,1).min()):.3e}, "
+          f"att grad norms {[float(grads[k].norm()) for k in grads if k.startswith('att_')]}; wrote {name}.npz")
+
+
 def gen_beam_only(name, cfg, seed, beam_b, beam_width, out_scale=1.0):
     """BASELINE config 5 dims (H=E=1000, V=12000), a few samples: reference beam-search ids (beam 5, depth 30) and
     greedy ids; the reference needs ~16 s per caption on CPU, so only `beam_b` samples are generated."""
@@ -395,6 +467,9 @@ if __name__ == "__main__":
         gen_long()
     if "mid64long" in which:
         gen_long("mid64long", "mid64", seed=41)
+    for att in ("att_tiny", "att_mid"):
+        if att in which:
+            gen_att(att)
     if "c2long" in which:   # BASELINE configs[1] (the headline) at its own size: 10 fp32 reference Adam steps (lr 1e-3) on one B=64
         gen_long("c2long", "c2", seed=7, n_steps=10)       # batch; the fp32-equivalent GPU trajectory must stay within 1e-4 of it
     if "c3long" in which:   # BASELINE configs[2] at its own size: 10 fp32 reference Adam steps (lr 1e-3) on one B=256 batch;

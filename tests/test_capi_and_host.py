@@ -218,3 +218,26 @@ def test_load_glove_weights_fills_known_words_and_keeps_the_embedding_trainable(
     assert torch.equal(m2.embedding.weight[5].detach(), w[5].detach())
     with pytest.raises(AssertionError):
         m2.load_glove_weights("unused", 3, ix2word)
+
+
+def test_att_baseline_dropin_layout_matches_reference_fixture():
+    """attention_baseline.Att_Baseline: parameter names, order and shapes are the reference's (recorded
+    in tests/golden/att_tiny.npz by oracle/make_golden.py from the reference class), and the seeded default initialisation
+    reproduces the reference's numbers - its state_dicts and pickles load unchanged.  No compute here (CPU)."""
+    import os
+    import numpy as np
+    import torch
+    import attention_baseline
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "att_tiny.npz"))
+    B, L, F, H, E, V = (int(x) for x in g["dims"])
+    torch.manual_seed(int(g["seed"]))
+    m = attention_baseline.Att_Baseline(V, F, L, dim_hid=H, dim_embed=E)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    assert [str(tuple(v.shape)) for v in sd.values()] == [str(s) for s in g["shapes"]]
+    for k, v in sd.items():
+        assert np.array_equal(v.numpy(), g["param/" + k]), k
+    import pytest
+    from s2vt_video_caption_amd import capi
+    with pytest.raises(capi.S2VTHipError):        # no CPU fallback: the product path fails loudly off the GPU
+        m(torch.zeros(B, L, F), targets=torch.zeros(B, L - 1, dtype=torch.long), mode="train")

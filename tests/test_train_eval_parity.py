@@ -135,3 +135,40 @@ def test_train_harness_and_generate_match_oracle(tmp_path):
         assert got_b == want_b
     else:       # a tie in the reference's own ranking: compare everything the tie cannot touch
         assert set(got_b) == set(want_b)
+
+
+@pytest.mark.gpu
+def test_train_and_generate_with_the_attention_baseline(tmp_path):
+    """train.py --model att_baseline (the network the reference's committed train.py:86 builds) through the same harness: the
+    loss falls, the checkpoints are full-module pickles of attention_baseline.Att_Baseline, and eval.generate decodes from
+    one of them exactly what a direct mode='test' call gives (the model's arithmetic is pinned to the reference in
+    tests/test_gpu_att_baseline.py; the epoch loop above)."""
+    sys.path.insert(0, ROOT)
+    import eval as s2vt_eval
+    import train
+    data = make_toy(str(tmp_path))
+    ck = tmp_path / "ck"
+    opt = train.parse(["--caption-file", str(tmp_path / "captions.json"), "--feats-path", str(tmp_path / "feats"),
+                       "--train-length", str(L), "--dim-hidden", str(H), "--dim-embed", str(E), "--feat-dim", str(F),
+                       "--batch-size", str(BS), "--epochs", "6", "--lr", str(LR), "--save-freq", "3", "--save-path", str(ck),
+                       "--no-shuffle", "--seed", str(SEED), "--model", "att_baseline"])
+    got = train.run(opt)
+    tl = got["train_loss"]
+    assert len(tl) == 6 and all(np.isfinite(tl)) and tl[-1] < tl[0] - 0.1, tl
+    st = got["start_time"]
+    final = ck / (st + "final.pth")
+    m = torch.load(final, weights_only=False)
+    import attention_baseline
+    assert isinstance(m, attention_baseline.Att_Baseline)
+    import dataloader
+    test_ds = dataloader.VideoDataset(str(tmp_path / "captions.json"), str(tmp_path / "feats"), max_len=L, mode="test")
+    feats = torch.stack([test_ds[i][0] for i in range(len(test_ds))]).to("cuda:0")
+    ids = m.to("cuda:0").eval()(feats, mode="test").cpu()
+    ix2word = data["ix2word"]
+
+    def words(row):
+        w = [ix2word[str(int(i))] for i in row]
+        return " ".join(w[:w.index("<eos>")] if "<eos>" in w else w)
+    want = {test_ds[i][2]: words(ids[i].tolist()) for i in range(len(test_ds))}
+    got_g = s2vt_eval.generate(str(final), str(tmp_path / "captions.json"), str(tmp_path / "feats"), batch_size=3, mode="test")
+    assert got_g == want

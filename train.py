@@ -44,6 +44,9 @@ def parse(argv=None):
     # reproducibility switches (not in the reference, whose runs are unseeded): used by the harness parity test
     ap.add_argument("--no-shuffle", action="store_true", help="iterate the training set in file order")
     ap.add_argument("--seed", type=int, default=None, help="seed numpy's global RNG (caption sampling, dataloader.py:41)")
+    ap.add_argument("--model", choices=("s2vt", "att_baseline"), default="s2vt",
+                    help="s2vt: S2VTModel.S2VT (the hot path); att_baseline: attention_baseline.Att_Baseline, the network the "
+                         "reference's committed train.py:86 instantiates")
     ap.add_argument("--init-state", default=None, help="state_dict file to start from instead of the seeded default init")
     return ap.parse_args(argv)
 
@@ -91,9 +94,15 @@ def run(opt):
     word2ix = trainset.word2ix
 
     torch.manual_seed(0)        # identical replicas
-    model = S2VT(len(word2ix), opt.feat_dim, length=opt.train_length, dim_hid=opt.dim_hidden, dim_embed=opt.dim_embed,
-                 feat_dropout=opt.feat_dropout, rnn_dropout=opt.rnn_dropout, out_dropout=opt.out_dropout,
-                 sos_ix=word2ix['<sos>'], eos_ix=word2ix['<eos>'])
+    if opt.model == "att_baseline":
+        from attention_baseline import Att_Baseline
+        model = Att_Baseline(len(word2ix), opt.feat_dim, length=opt.train_length, dim_hid=opt.dim_hidden, dim_embed=opt.dim_embed,
+                             feat_dropout=opt.feat_dropout, out_dropout=opt.out_dropout,
+                             sos_ix=word2ix['<sos>'], eos_ix=word2ix['<eos>'])                      # train.py:86-87 upstream
+    else:
+        model = S2VT(len(word2ix), opt.feat_dim, length=opt.train_length, dim_hid=opt.dim_hidden, dim_embed=opt.dim_embed,
+                     feat_dropout=opt.feat_dropout, rnn_dropout=opt.rnn_dropout, out_dropout=opt.out_dropout,
+                     sos_ix=word2ix['<sos>'], eos_ix=word2ix['<eos>'])
     if opt.init_state:
         model.load_state_dict(torch.load(opt.init_state))
     model.to(dev)
@@ -102,7 +111,11 @@ def run(opt):
     early_stopping = EarlyStopping(patience=opt.early_stopping_patience, verbose=rank == 0,
                                    path=os.path.join(opt.save_path, start_time + 'stop.pth'))        # :98-100
     criterion = MaskCriterion()
-    reducer = dp.FlatGradAllReducer(model.parameters()).attach(model) if world > 1 else None
+    reducer = None
+    if world > 1:       # S2VT: gradients written straight into the flat buffer, all-reduce overlapped with the backward;
+        reducer = dp.FlatGradAllReducer(model.parameters())            # Att_Baseline: plain bucketed all-reduce after it
+        if opt.model == "s2vt":
+            reducer.attach(model)
     hist = {"train_loss": [], "valid_loss": [], "lr": [], "stopped_at": None, "checkpoints": []}
 
     def save(name):
