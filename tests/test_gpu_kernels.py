@@ -638,7 +638,7 @@ def test_persistent_fp32_recurrence(lib, T, B, H, n_gx, block):
 
 @pytest.mark.parametrize("T,B,H,n_gx,block", [(6, 32, 128, 4, 0), (7, 64, 1000, 4, 3), (5, 128, 1000, 3, 0), (9, 96, 520, 9, 4),
                                               (4, 256, 1000, 2, 0), (5, 32, 8, 5, 2), (12, 64, 1000, 6, 5), (5, 64, 1024, 2, 0),
-                                              (4, 32, 70, 1, 2)])
+                                              (4, 32, 70, 1, 2), (5, 64, 37, 3, 2), (3, 32, 999, 1, 0)])
 def test_persistent_split_precision_recurrence(lib, T, B, H, n_gx, block):
     """lstm_seq_fwd_x3_persist_kernel: h_{t-1} . W_hh^T as six bf16 plane products (fp32-equivalent), W_hh planes resident in
     384 registers per lane, hand-off of h_t as three bf16 planes.  Same bounds as the exact-fp32 persistent kernel: against fp64
@@ -743,7 +743,7 @@ def _bptt_fp64(w, gates, c_all, dh, dh_first, T, B, H):
 
 @pytest.mark.parametrize("T,B,H,dh_first,block", [(6, 32, 128, 2, 0), (7, 64, 1000, 0, 3), (5, 128, 1000, 1, 0), (9, 96, 520, 3, 4),
                                                   (4, 256, 1000, 0, 0), (5, 32, 8, 0, 2), (12, 64, 1000, 5, 5), (5, 64, 1024, 2, 0),
-                                                  (4, 32, 70, 1, 2)])
+                                                  (4, 32, 70, 1, 2), (5, 64, 37, 3, 2), (3, 32, 999, 1, 0)])
 def test_persistent_split_precision_bptt(lib, T, B, H, dh_first, block):
     """lstm_seq_bwd_x3_persist_kernel: the contraction dG_{t+1} . W_hh split over the gate columns (every workgroup multiplies its
     own dG tile with its 64 rows of W_hh, planes resident in registers, and the fp32 partial sums are scattered / gathered per
