@@ -251,6 +251,7 @@ static bool dims_ok(const s2vt_dims* d) {
 }
 
 static int pipe_block();
+static bool persist_x3_bwd_on();
 static TrainWS carve_train(const s2vt_dims& d, void* base) {
     const size_t B = d.B, L = d.L, H = d.H, E = d.E, V = d.V, T = 2 * L - 1;
     Carver c{reinterpret_cast<char*>(base), 0, 0};
@@ -275,7 +276,7 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     w.xh1 = c.take<unsigned short>(3 * T * B * w.xkp);
     w.xh2 = c.take<unsigned short>(3 * T * B * w.xkp);
     {   // ring slots: one more than the longest block of the backward's pipeline (a slot is written once per launch)
-        const bool can = w.xkp > 0 && B % 32 == 0 && pipe_block() > 0;
+        const bool can = w.xkp > 0 && B % 32 == 0 && pipe_block() > 0 && persist_x3_bwd_on();    // (opt-in kernel: no rings otherwise)
         const size_t maxblk = (size_t)pipe_block() < T ? (size_t)pipe_block() : T;
         w.xnslots = can ? (int)maxblk + 1 : 0;
         w.xhp = (int64_t)((H + 15) / 16 * 16);

@@ -747,3 +747,46 @@ def test_decode_cache_follows_the_weights(lib, golden):
     finally:
         functional.DECODE_CACHE = keep
         functional.clear_decode_cache()
+
+
+_BPTT_CHILD = r"""
+import json, sys
+sys.path.insert(0, %r)
+import torch, S2VTModel, utils
+from s2vt_video_caption_amd import capi, synth
+d = synth.CONFIGS["c2"]
+sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=21)
+feats, caps, mask = (t.to("cuda:0") for t in synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=22))
+m = S2VTModel.S2VT(d["V"], d["F"], d["L"], dim_hid=d["H"], dim_embed=d["E"])
+m.load_state_dict(sd); m.to("cuda:0").train()
+loss = utils.MaskCriterion()(m(feats, targets=caps[:, :-1], mode="train"), caps, mask)
+loss.backward()
+torch.cuda.synchronize(); capi.check_async_error()
+print(json.dumps({"plan": capi.recurrence_plan(d["B"], d["H"]), "loss": float(loss.detach()),
+                  "norms": {k: float(p.grad.double().norm()) for k, p in m.named_parameters()},
+                  "heads": {k: p.grad.reshape(-1)[:8].cpu().tolist() for k, p in m.named_parameters()}}))
+"""
+
+
+def test_opt_in_persistent_bptt_is_the_default_backward_within_fp32_rounding(lib):
+    """S2VT_PERSIST_X3_BWD=1 (the split-precision reduce-scatter BPTT, an opt-in: faster as a kernel, slower end to end) through
+    the whole config-2 train step in a child process (the switch is read once per process): same loss bits (the forward is
+    unchanged), every gradient within fp32 rounding of the default launch-per-timestep backward's."""
+    import json
+    import subprocess
+    import sys as _sys
+    import os
+    code = _BPTT_CHILD % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        env = dict(os.environ, S2VT_PERSIST_X3_BWD=flag)
+        r = subprocess.run([_sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        outs.append(json.loads(r.stdout.decode().strip().splitlines()[-1]))
+    base, opt = outs
+    assert base["plan"] == [3, 0] and opt["plan"] == [3, 3]
+    assert base["loss"] == opt["loss"]
+    for k, n in base["norms"].items():
+        assert abs(opt["norms"][k] - n) <= 2e-5 * n + 1e-9, k
+        h0, h1 = np.array(base["heads"][k]), np.array(opt["heads"][k])
+        assert np.abs(h0 - h1).max() <= 1e-6 + 2e-4 * np.abs(h0).max(), k
