@@ -292,7 +292,9 @@ int s2vt_lstm_seq_fwd_x3_persist(int32_t T, int32_t B, int32_t H, float* gx_stas
  * of W_hh (planes resident in registers) for all H outputs, scatters the fp32 partial sums per consumer and gathers the ones
  * addressed to it (fixed summation order).  Same arithmetic contract as s2vt_lstm_seq_bwd (fp32-equivalent); stash_dg: activated
  * gates in, dG out (in place).  Layer 1 pointers may all be null.  block: timesteps per launch (0 = all T).
- * Whole-path use: env S2VT_PERSIST_X3_BWD=1 routes the BPTT of s2vt_train_backward (gemm mode 3) through it. */
+ * Whole-path use: env S2VT_PERSIST_X3_BWD=1 routes the BPTT of s2vt_train_backward (gemm mode 3) through it (one stream, both
+ * layers per launch); =2 runs each layer's blocks as their own persistent launches on the two lanes of the default schedule
+ * (an experiment: same step time). */
 size_t s2vt_lstm_seq_bwd_x3_workspace_bytes(int32_t T, int32_t B, int32_t H, int32_t block);
 int s2vt_lstm_seq_bwd_x3_persist(int32_t T, int32_t B, int32_t H, const float* w_hh0, const float* w_hh1, const float* dh_out0,
                                  const float* dh_out1, int32_t dh_first, const float* c_all0, const float* c_all1, float* stash_dg0,

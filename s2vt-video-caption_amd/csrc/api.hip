@@ -656,11 +656,14 @@ static bool persist_x3_fwd_on() {
     return on && persist_on();
 }
 // split-precision persistent BPTT (reduce-scatter over the gate columns, lstm_persist_x3.hip): S2VT_PERSIST_X3_BWD = 0 | 1
-static bool persist_x3_bwd_on() {
+// (= 2: experiment - one-LAYER persistent launches on the two lanes of the launch-per-timestep schedule: each holds half of the
+// compute units, so both fit beside each other and the lanes' GEMMs keep their overlap)
+static int persist_x3_bwd_mode() {
     static int on = -1;
-    if (on < 0) { const char* e = getenv("S2VT_PERSIST_X3_BWD"); on = e ? (atoi(e) != 0) : 0; }
-    return on && persist_on();
+    if (on < 0) { const char* e = getenv("S2VT_PERSIST_X3_BWD"); on = e ? atoi(e) : 0; if (on < 0 || on > 2) on = 0; }
+    return persist_on() ? on : 0;
 }
+static bool persist_x3_bwd_on() { return persist_x3_bwd_mode() != 0; }
 static SeqBwdX3Args persist_bwd_x3_args(int T, int t0, int t1, int B, int H, int64_t Kp, int64_t Hp, const unsigned short* wtp,
                                         const float* dh_out, int dh_first, const float* c_all, float* stash_dg, float* dc,
                                         float* part, int64_t part_slot, int nslots, unsigned int* sync, int* err) {
@@ -981,10 +984,11 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = grads_ready(0, sx))) return rc;
     if ((rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     const bool pbf_bwd = bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad;
-    const bool px3_bwd = !bf && XP == 3 && blk > 0 && w.xnslots > 0 && persist_x3_bwd_on() && lstm_seq_bwd_x3_persist_supported(B, H) &&
-                         w.xnslots > (balanced_block(L, blk) < T ? balanced_block(L, blk) : T);
+    const bool px3_any = !bf && XP == 3 && blk > 0 && w.xnslots > 0 && persist_x3_bwd_on() && lstm_seq_bwd_x3_persist_supported(B, H) &&
+                         w.xnslots > (blk < T ? blk : T);
+    const bool px3_bwd = px3_any && persist_x3_bwd_mode() == 1, px3_lanes = px3_any && persist_x3_bwd_mode() == 2;
     const std::vector<int> bd = pipe_bounds(T, L, (pbf_bwd || px3_bwd) ? balanced_block(L, blk) : blk);
-    if (px3_bwd) {   // W_hh^T of both layers as planes (each on the lane that transposed it)
+    if (px3_any) {   // W_hh^T of both layers as planes (each on the lane that transposed it)
         if ((rc = split3_wt(st, w.wt2, H, (int)w.xkp, (int)w.xhp, w.xwt2, w.xkp * 4 * w.xhp))) return rc;
         if ((rc = split3_wt(sx, w.wt1, H, (int)w.xkp, (int)w.xhp, w.xwt1, w.xkp * 4 * w.xhp))) return rc;
     }
@@ -1070,11 +1074,22 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
         // chip, and it overlaps the weight-gradient GEMMs below instead of the BPTT.
         if ((rc = grads_ready(0, st))) return rc;
         if ((rc = handoff(st, sx, ev++))) return rc;               // lane B's parameter-gradient GEMMs need dG1
-    } else
+    } else {
+    // one-layer persistent block of the split-precision BPTT on stream s (px3_lanes)
+    auto x3_block = [&](hipStream_t s, int t0, int t1, bool word) -> int {
+        ProfScope ps(s, K_STEP_BWD, t1 - t0);
+        const SeqBwdX3Args a = word ? persist_bwd_x3_args(T, t0, t1, B, H, w.xkp, w.xhp, w.xwt2, w.dh2dec, L, w.c2, w.s2, w.dc2, w.xpart2,
+                                                          w.xpslot, w.xnslots, w.psync_a, w.err + 1)
+                                    : persist_bwd_x3_args(T, t0, t1, B, H, w.xkp, w.xhp, w.xwt1, w.dh1, 0, w.c1, w.s1, w.dc1, w.xpart1,
+                                                          w.xpslot, w.xnslots, w.psync_b, w.err + 1);
+        return lstm_seq_bwd_x3_persist2(s, a, nullptr);
+    };
     for (size_t k = bd.size() - 1; k >= 1; --k) {
         const int t0 = bd[k - 1], t1 = bd[k];
         if (bf) {
             if ((rc = seq_bwd_bf16(st, T, t0, t1, B, H, q.whh2T, w.dh2dec, L, w.c2, w.s2, q.dg2, w.dc2))) return rc;
+        } else if (px3_lanes) {
+            if ((rc = x3_block(st, t0, t1, true))) return rc;
         } else {
             if ((rc = seq_bwd(st, T, t0, t1, B, H, w.wt2, w.dh2dec, L, w.c2, w.s2, w.dc2))) return rc;
         }
@@ -1088,12 +1103,16 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
         if ((rc = handoff(st, sx, ev++))) return rc;
         if (bf) {
             if ((rc = seq_bwd_bf16(sx, T, t0, t1, B, H, q.whh1T, w.dh1, 0, w.c1, w.s1, q.dg1, w.dc1))) return rc;
+        } else if (px3_lanes) {
+            if ((rc = x3_block(sx, t0, t1, false))) return rc;
         } else {
             if ((rc = seq_bwd(sx, T, t0, t1, B, H, w.wt1, w.dh1, 0, w.c1, w.s1, w.dc1))) return rc;
         }
         if ((rc = pdual(lb, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, (t0 < L && !bf) ? &q.dg1 : nullptr, t0 * B, &q.dg1T,
                         t0 * B, w.colsum_b + (int64_t)(t0 * B / 64) * 4 * H)))
             return rc;
+    }
+    if (px3_lanes && (rc = grads_ready(0, st))) return rc;         // (as behind the one-stream persistent schedules above)
     }
     // lane A: word_rnn parameter gradients + embedding gradient
     if ((rc = pgemm(la, 4 * H, H, (T - 1) * B, q.dg2T, 0, B, q.h2T, 0, 0, g->word_w_hh, H, ID, nullptr, false))) return rc;
@@ -2046,7 +2065,7 @@ int s2vt_recurrence_plan(int32_t B, int32_t H, int32_t* fwd, int32_t* bwd) {
     }
     if (H <= 1024 && persist_x3_fwd_on() && lstm_seq_fwd_x3_persist_supported(B, H)) *fwd = 3;
     else if (persist_f32_dir_on(0) && lstm_seq_fwd_f32_persist_supported(B, H)) *fwd = 2;
-    if (H <= 1024 && persist_x3_bwd_on() && lstm_seq_bwd_x3_persist_supported(B, H)) *bwd = 3;
+    if (H <= 1024 && persist_x3_bwd_on() && lstm_seq_bwd_x3_persist_supported(B, H)) *bwd = 3;        // (one-stream or lanes mode)
     else if (persist_f32_dir_on(1) && lstm_seq_bwd_f32_persist_supported(B, H)) *bwd = 2;
     return 0;
 }
