@@ -129,15 +129,19 @@ def test_c2_full_size_against_reference_golden(lib, golden, gemm_mode):
         lib.s2vt_set_gemm_mode(prev)
 
 
-def test_c2_train_with_fp32_persistent_recurrence(lib, golden):
-    """The same config-2 train step with s2vt_set_recurrence_mode(2): both layers' fp32 recurrences (forward and BPTT) run
-    in the persistent kernels of lstm_persist_f32.hip, one launch per block of timesteps for both layers."""
+@pytest.mark.parametrize("mode,plan", [(2, (3, 2)), (0, (0, 0))])
+def test_c2_train_in_the_other_recurrence_modes(lib, golden, mode, plan):
+    """The same config-2 train step in the non-default recurrence modes (the default, mode 1 = split-precision persistent
+    forward + launch-per-timestep BPTT, is test_c2_full_size_against_reference_golden): mode 2 adds the exact-fp32 persistent
+    BPTT of lstm_persist_f32.hip; mode 0 runs every recurrence as launches per timestep on two streams (round 2's default, still
+    the path of hidden sizes above 1024 and of a shared card)."""
+    from s2vt_video_caption_amd import capi
     g = golden("c2")
     d, sd, feats, caps, mask = _setup(g, "c2")
-    prev = lib.s2vt_set_recurrence_mode(2)
+    prev = lib.s2vt_set_recurrence_mode(mode)
     try:
+        assert capi.recurrence_plan(d["B"], d["H"]) == plan
         _c2_body(g, d, sd, feats, caps, mask)
-        from s2vt_video_caption_amd import capi
         capi.check_async_error()
     finally:
         lib.s2vt_set_recurrence_mode(prev)
