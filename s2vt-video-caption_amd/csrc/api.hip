@@ -1392,6 +1392,13 @@ struct DecodeWS {
     PB feats, px1, ph1;                    // packed planes of per-call activations (split-precision mode only)
     PB ph2;                                // the decode step's h_t planes
     PB embp, wep;                          // planes of the embedding table and of W_e (scratch of the per-token table's GEMM)
+    // persistent split-precision recurrence of the ENCODE phase (lstm_persist_x3.hip): per-step cell states, word_rnn's encode
+    // outputs, the h_t plane images of both layers, hand-off counters, error flags (xkp == 0: not provided)
+    int64_t xkp;
+    float *c1_all, *c2_all, *h2_all;
+    unsigned short *xh1, *xh2;
+    unsigned int *psync_a, *psync_b;
+    int* err;
     size_t bytes;
 };
 static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
@@ -1424,17 +1431,27 @@ static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
         w.ph1 = mk(T * B, H);   w.ph2 = mk(B, H);
         w.embp = mk(d.V, d.E);  w.wep = mk(4 * H, d.E);
     }
+    w.xkp = (planes_ok(d) && H <= 1024) ? (int64_t)pad64((int)H) : 0;
+    w.c1_all = c.take<float>(w.xkp ? T * B * H : 0);
+    w.c2_all = c.take<float>(w.xkp ? L * B * H : 0);
+    w.h2_all = c.take<float>(w.xkp ? L * B * H : 0);
+    w.xh1 = c.take<unsigned short>(w.xkp ? 3 * T * B * (size_t)w.xkp : 0);
+    w.xh2 = c.take<unsigned short>(w.xkp ? 3 * L * B * (size_t)w.xkp : 0);
+    w.psync_a = c.take<unsigned int>(lstm_persist_sync_bytes() / sizeof(unsigned int));
+    w.psync_b = c.take<unsigned int>(lstm_persist_sync_bytes() / sizeof(unsigned int));
+    w.err = c.take<int>(4);
     w.bytes = align_up(c.off, 256);
     return w;
 }
 // What a decode derives from the WEIGHTS alone (plane images of W_f, W_ih1, W_v, W_o and the per-token gate-input table):
 // carved from the tail of the call's workspace, or from a caller-kept cache that outlives the call (s2vt_greedy_decode_cached)
-struct DecodeConst { PB wf, wih1, wv, wo; float* gtab; size_t bytes; };
+struct DecodeConst { PB wf, wih1, wv, wo; float* gtab; unsigned short *xw1, *xw2; size_t bytes; };   // xw: W_hh planes [3][4H][Kp]
 static DecodeConst carve_decode_const(const s2vt_dims& d, void* base) {
     const size_t F = d.F, H = d.H;
     Carver c{reinterpret_cast<char*>(base), 0, 0};
     DecodeConst k;
     k.gtab = nullptr;
+    k.xw1 = k.xw2 = nullptr;
     k.wf = k.wih1 = k.wv = k.wo = PB{nullptr, 0, 0};
     if (planes_ok(d)) {
         XP = 3;
@@ -1447,6 +1464,9 @@ static DecodeConst carve_decode_const(const s2vt_dims& d, void* base) {
         };
         k.wf = mk(H, F); k.wih1 = mk(4 * H, H); k.wv = mk(4 * H, H); k.wo = mk(d.V, H);
         k.gtab = c.take<float>((size_t)d.V * 4 * H);
+        const size_t xkp = (H <= 1024) ? (size_t)pad64((int)H) : 0;
+        k.xw1 = c.take<unsigned short>(3 * 4 * H * xkp);
+        k.xw2 = c.take<unsigned short>(3 * 4 * H * xkp);
     }
     k.bytes = align_up(c.off, 256);
     return k;
@@ -1591,6 +1611,13 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
     // V = 12000) against B x 4H x E of MFMA work and E/(E+H) of the operand traffic in EVERY decode step - pays from B ~ 64
     static const bool no_tab = getenv("S2VT_DECODE_TABLE") && atoi(getenv("S2VT_DECODE_TABLE")) == 0;
     const bool use_tab = x3 && !no_tab;
+    // encode phase (both layers, L steps) and vid_rnn's input-free decode steps as persistent split-precision launches; only the
+    // 79 token-dependent word_rnn steps stay one launch (+ argmax) per step
+    const bool use_px = x3 && blk > 0 && w.xkp > 0 && persist_x3_fwd_on() && lstm_seq_fwd_x3_persist_supported(B, H);
+    if (use_px && fill) {
+        if ((rc = split3_rows(sx, p->vid_w_hh, H, 4 * H, H, (int)w.xkp, kc.xw1, 4 * (int64_t)H * w.xkp))) return rc;
+        if ((rc = split3_rows(sx, p->word_w_hh, H, 4 * H, H, (int)w.xkp, kc.xw2, 4 * (int64_t)H * w.xkp))) return rc;
+    }
     if (x3) {
         if (ax3) {      // W_o planes: constant over the 79 decode steps; h_t planes: written by the decode steps themselves, k padding zeroed here
             if (fill && (rc = psplit(lb, kc.wo, 0, p->out_w, H, ID, V, H))) return rc;
@@ -1613,6 +1640,99 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
             return rc;
         if ((rc = lgemm(la, true, true, L * B, 4 * H, H, w.x1, H, ID, p->vid_w_ih, H, ID, w.gx1, 4 * H, ID, w.bsum1, false)))
             return rc;
+    }
+    // one word_rnn step on stream s (+ out_linear / argmax for a decode step): encode steps see a zero embedding (:84-86), decode
+    // steps Emb[prev token] (:89-103)
+    auto word_step = [&](hipStream_t s, int t, const float* hprev, const float* cprev) -> int {
+        int r;
+        {
+            ProfScope ps(s, K_STEP_FWD, 1);
+            StepFwdArgs a;
+            memset(&a, 0, sizeof(a));
+            a.B = B; a.H = H;
+            a.h_prev = hprev; a.ldh = H;
+            a.w_hh = p->word_w_hh; a.ldw = H;
+            if (t >= L) {
+                if (use_tab) {
+                    a.gx_tab = kc.gtab; a.ldtab = 4 * (int64_t)H;
+                } else {
+                    a.x2 = p->emb_w; a.ldx2 = E; a.K2 = E;
+                    a.w2 = p->word_w_ih; a.ldw2 = E + H;
+                }
+                a.tok_packed = (t > L) ? w.packed + (int64_t)(t - L - 1) * B : nullptr;
+                a.tok_const = sos_ix;
+            }
+            a.gx = w.gx2 + t * B4H; a.ldgx = 4 * (int64_t)H;
+            a.c_prev = cprev; a.ldc = H;
+            a.h_out = w.h2 + (t & 1) * BH; a.ldho = H;
+            a.c_out = w.c2; a.ldco = H;
+            if (t >= L && ax3) { a.h_planes = w.ph2.p; a.ldhp = w.ph2.ld; }
+            if ((r = lstm_step_fwd(s, a))) return r;
+        }
+        if (t >= L && ax3) {  // out_linear + argmax (:95-96, :105-106) on the bf16 matrix cores (argmax_x3.hip); the
+            ProfScope ps(s, K_ARGMAX, 1);       // step kernel above wrote h_t as planes (StepFwdArgs::h_planes)
+            ArgmaxX3Args ax;
+            ax.B = B; ax.V = V; ax.K = kc.wo.kpad;
+            ax.W = kc.wo.p; ax.ldw = kc.wo.ld;
+            ax.Hp = w.ph2.p; ax.ldh = w.ph2.ld;
+            ax.bias = p->out_b;
+            ax.packed = w.packed + (int64_t)(t - L) * B;
+            ax.dbg = 0; ax.stamps = nullptr;
+            if ((r = logits_argmax_x3(s, ax))) return r;
+        } else if (t >= L) {  // the same on the fp32-input MFMA (lstm.hip), for batches the plane path does not take
+            ProfScope ps(s, K_ARGMAX, 1);
+            LogitsArgmaxArgs la2;
+            la2.B = B; la2.H = H; la2.V = V;
+            la2.h = w.h2 + (t & 1) * BH; la2.ldh = H;
+            la2.w_out = p->out_w; la2.ldw = H; la2.b_out = p->out_b;
+            la2.packed = w.packed + (int64_t)(t - L) * B;
+            la2.stamps = nullptr;
+            if ((r = logits_argmax(s, la2))) return r;
+        }
+        return 0;
+    };
+    if (use_px) {
+        if ((rc = handoff(sx, st, ev++))) return rc;            // lane B's weight images before their first use on this stream
+        if ((rc = fill_zero(st, w.err, 4 * sizeof(int)))) return rc;
+        auto gx2_block = [&](int t0, int t1) -> int {           // vid_out half of word_rnn's gate input for steps [t0, t1) (+ biases)
+            int r;
+            if ((r = psplit(la, w.ph1, t0 * B, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H))) return r;
+            return pgemm(la, (t1 - t0) * B, 4 * H, H, w.ph1, t0 * B, 0, kc.wv, 0, 0, w.gx2 + t0 * B4H, 4 * H, ID, w.bsum2, false);
+        };
+        const std::vector<int> be = pipe_bounds(L, L, balanced_block(L, blk));     // blocks over the L encode steps
+        const int nb = (int)be.size() - 1;
+        for (int k = 0; k <= nb; ++k) {          // stage k: vid_rnn block k next to word_rnn block k-1 (as in s2vt_train_forward)
+            const bool hv = k < nb, hw = k >= 1;
+            SeqFwdX3Args av, aw;
+            if (hv) {
+                av = persist_fwd_x3_args(be[k], be[k + 1], B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
+                av.no_stash = 1;
+            }
+            if (hw) {
+                aw = persist_fwd_x3_args(be[k - 1], be[k], B, H, L, w.xkp, w.gx2, L, w.bsum2, kc.xw2, w.xh2, w.h2_all, w.c2_all, w.psync_b, w.err + 1);
+                aw.no_stash = 1;
+            }
+            {
+                ProfScope ps(st, K_STEP_FWD, (hv ? be[k + 1] - be[k] : 0) + (hw ? be[k] - be[k - 1] : 0));
+                if (hv && hw) rc = lstm_seq_fwd_x3_persist2(st, av, &aw);
+                else rc = lstm_seq_fwd_x3_persist2(st, hv ? av : aw, nullptr);
+                if (rc) return rc;
+            }
+            if (hv && (rc = gx2_block(be[k], be[k + 1]))) return rc;
+        }
+        {   // vid_rnn over the L - 1 decode steps (no input: bias only): one launch that may use the whole device
+            SeqFwdX3Args av = persist_fwd_x3_args(L, T, B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
+            av.no_stash = 1;
+            ProfScope ps(st, K_STEP_FWD, T - L);
+            if ((rc = lstm_seq_fwd_x3_persist2(st, av, nullptr))) return rc;
+        }
+        if ((rc = gx2_block(L, T))) return rc;
+        for (int t = L; t < T; ++t)
+            if ((rc = word_step(st, t, t == L ? w.h2_all + (int64_t)(L - 1) * BH : w.h2 + ((t - 1) & 1) * BH,
+                                t == L ? w.c2_all + (int64_t)(L - 1) * BH : w.c2)))
+                return rc;
+        if ((rc = unpack_tokens(st, w.packed, L - 1, B, ids))) return rc;
+        return post_async_error(st, w.err);                   // (a timed-out hand-off surfaces like the train path's)
     }
     const std::vector<int> bd = pipe_bounds(T, L, blk);
     for (size_t k = 0; k + 1 < bd.size(); ++k) {
@@ -1645,52 +1765,8 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
                             w.gx2 + t0 * B4H, 4 * H, ID, w.bsum2, false)))
                 return rc;
         }
-        for (int t = t0; t < t1; ++t) {
-            {   // word_rnn: encode steps see a zero embedding (:84-86), decode steps Emb[prev token] (:89-103)
-                ProfScope ps(sx, K_STEP_FWD, 1);
-                StepFwdArgs a;
-                memset(&a, 0, sizeof(a));
-                a.B = B; a.H = H;
-                a.h_prev = t ? w.h2 + ((t - 1) & 1) * BH : nullptr; a.ldh = H;
-                a.w_hh = p->word_w_hh; a.ldw = H;
-                if (t >= L) {
-                    if (use_tab) {
-                        a.gx_tab = kc.gtab; a.ldtab = 4 * (int64_t)H;
-                    } else {
-                        a.x2 = p->emb_w; a.ldx2 = E; a.K2 = E;
-                        a.w2 = p->word_w_ih; a.ldw2 = E + H;
-                    }
-                    a.tok_packed = (t > L) ? w.packed + (int64_t)(t - L - 1) * B : nullptr;
-                    a.tok_const = sos_ix;
-                }
-                a.gx = w.gx2 + t * B4H; a.ldgx = 4 * (int64_t)H;
-                a.c_prev = t ? w.c2 : nullptr; a.ldc = H;
-                a.h_out = w.h2 + (t & 1) * BH; a.ldho = H;
-                a.c_out = w.c2; a.ldco = H;
-                if (t >= L && ax3) { a.h_planes = w.ph2.p; a.ldhp = w.ph2.ld; }
-                if ((rc = lstm_step_fwd(sx, a))) return rc;
-            }
-            if (t >= L && ax3) {  // out_linear + argmax (:95-96, :105-106) on the bf16 matrix cores (argmax_x3.hip); the
-                ProfScope ps(sx, K_ARGMAX, 1);      // step kernel above wrote h_t as planes (StepFwdArgs::h_planes)
-                ArgmaxX3Args ax;
-                ax.B = B; ax.V = V; ax.K = kc.wo.kpad;
-                ax.W = kc.wo.p; ax.ldw = kc.wo.ld;
-                ax.Hp = w.ph2.p; ax.ldh = w.ph2.ld;
-                ax.bias = p->out_b;
-                ax.packed = w.packed + (int64_t)(t - L) * B;
-                ax.dbg = 0; ax.stamps = nullptr;
-                if ((rc = logits_argmax_x3(sx, ax))) return rc;
-            } else if (t >= L) {  // the same on the fp32-input MFMA (lstm.hip), for batches the plane path does not take
-                ProfScope ps(sx, K_ARGMAX, 1);
-                LogitsArgmaxArgs la2;
-                la2.B = B; la2.H = H; la2.V = V;
-                la2.h = w.h2 + (t & 1) * BH; la2.ldh = H;
-                la2.w_out = p->out_w; la2.ldw = H; la2.b_out = p->out_b;
-                la2.packed = w.packed + (int64_t)(t - L) * B;
-                la2.stamps = nullptr;
-                if ((rc = logits_argmax(sx, la2))) return rc;
-            }
-        }
+        for (int t = t0; t < t1; ++t)
+            if ((rc = word_step(sx, t, t ? w.h2 + ((t - 1) & 1) * BH : nullptr, t ? w.c2 : nullptr))) return rc;
     }
     if ((rc = handoff(sx, st, ev++))) return rc;
     return unpack_tokens(st, w.packed, L - 1, B, ids);

@@ -174,6 +174,7 @@ struct SeqFwdX3Args {
     unsigned short* hp; int64_t hplane, ldh;        // h_t as planes [3][T*B][ldh], time-major: the hand-off payload
     float* h_all;                                   // [T*B][H] fp32 h_t (output only)
     float* gx_stash; const float* bias; float* c_all;
+    int no_stash;                                   // 1: the activated gates are not written back (inference: greedy decode)
     unsigned int* sync; int* err;
     int RB, NS;                                     // set by the launcher
     unsigned long long* stamps; int stamp_block;    // timing experiments only (experiment.h); null in the product

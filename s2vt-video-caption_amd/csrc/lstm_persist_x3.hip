@@ -138,7 +138,7 @@ __device__ __forceinline__ void seq_fwd_x3_body(const SeqFwdX3Args& p, const int
 #pragma unroll 1
         for (int s = 0; s < p.NS; ++s) {
             const int rbase = row0 + s * X_SR;
-            unsigned int* cnt = p.sync + (rg * X_MAXNS + s) * 32;
+            unsigned int* cnt = p.sync + (rbase / X_SR) * 32;          // one counter per 32-row chain, whatever NS the launch uses
             const int xrec = (bid == p.stamp_block) ? (t - p.t0) * p.NS + s : -1;
             XSTAMP(p.stamps, xrec, 0);
             if (t > p.t0) {          // h_{t-1} of this chain published by every column slice of the row group?
@@ -330,19 +330,24 @@ __device__ __forceinline__ void seq_fwd_x3_body(const SeqFwdX3Args& p, const int
                 float* cdst = p.c_all + rowi * H + eunit;
                 float* hdst = p.h_all + rowi * H + eunit;
                 float* st = p.gx_stash + rowi * H4 + eunit;
+                const bool stash = p.no_stash == 0;
                 if (e_vec) {
                     *reinterpret_cast<f32x2*>(cdst) = cv;
                     *reinterpret_cast<f32x2*>(hdst) = hv;
+                    if (stash) {
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x2*>(st + (int64_t)g * H) = gate[g];
+                        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x2*>(st + (int64_t)g * H) = gate[g];
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         if (j ? e_ok1 : e_ok0) {
                             cdst[j] = cv[j];
                             hdst[j] = hv[j];
+                            if (stash) {
 #pragma unroll
-                            for (int g = 0; g < 4; ++g) st[(int64_t)g * H + j] = gate[g][j];
+                                for (int g = 0; g < 4; ++g) st[(int64_t)g * H + j] = gate[g][j];
+                            }
                         }
                 }
             }
@@ -395,8 +400,16 @@ int lstm_seq_fwd_x3_persist_supported(int B, int H) {
     return (R * nC <= cap / 2 && R <= 64) ? ns : 0;
 }
 
-static int prep_x(SeqFwdX3Args& a) {
-    const int ns = lstm_seq_fwd_x3_persist_supported(a.B, a.H);
+// chains per workgroup of a launch with ONE layer: it may use the whole device (a pair shares it half / half)
+static int fwd_x3_single_ns(int B, int H) {
+    if (!lstm_seq_fwd_x3_persist_supported(B, H)) return 0;
+    const int cap = fwd_x3_capacity(), nC = cdiv(H, X_UN);
+    int R = B / X_SR, ns = 1;
+    while (R * nC > cap && ns < X_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }
+    return (R * nC <= cap) ? ns : 0;
+}
+static int prep_x(SeqFwdX3Args& a, bool single = false) {
+    const int ns = single ? fwd_x3_single_ns(a.B, a.H) : lstm_seq_fwd_x3_persist_supported(a.B, a.H);
     S2VT_REQUIRE(ns > 0, "lstm_seq_fwd_x3_persist: unsupported shape (B %% 32, H <= 1024) or it does not fit the device's resident capacity");
     S2VT_REQUIRE(a.t1 > a.t0 && a.t0 >= 0 && a.wp && a.hp && a.h_all && a.gx_stash && a.c_all && a.sync && a.err && (a.bias || a.n_gx >= a.t1),
                  "lstm_seq_fwd_x3_persist: bad arguments");
@@ -411,7 +424,7 @@ static int prep_x(SeqFwdX3Args& a) {
 
 int lstm_seq_fwd_x3_persist2(hipStream_t stream, SeqFwdX3Args a, const SeqFwdX3Args* b) {
     int rc;
-    if ((rc = prep_x(a))) return rc;
+    if ((rc = prep_x(a, b == nullptr))) return rc;
     SeqFwdX3Args bb = b ? *b : a;
     if (b) {
         if ((rc = prep_x(bb))) return rc;
