@@ -279,7 +279,8 @@ int s2vt_lstm_seq_fwd_persist(int32_t T, int32_t B, int32_t H, float* gx_stash0,
 /* The same forward in split precision (lstm_persist_x3.hip): both operands of h_{t-1} . W_hh^T as three bf16 planes, six plane
  * products on the bf16 matrix cores, fp32 accumulate - fp32-equivalent like gemm mode 3, at 6/16 of the exact-fp32 MFMA's
  * cycles; one workgroup per compute unit keeps its W_hh planes in 384 registers per lane.  H <= 1024, B % 32 == 0.  Same
- * arguments as s2vt_lstm_seq_fwd_persist; workspace from s2vt_lstm_seq_x3_workspace_bytes (word 0: hand-off time-out flag).
+ * arguments as s2vt_lstm_seq_fwd_persist; workspace from s2vt_lstm_seq_x3_workspace_bytes (0 = shape not supported on this
+ * device; word 0 of the workspace: hand-off time-out flag).
  * Whole-path use: env S2VT_PERSIST_X3_FWD=1 routes the forward recurrences of s2vt_train_forward (gemm mode 3) through it
  * (S2VTModel.py:67,77). */
 size_t s2vt_lstm_seq_x3_workspace_bytes(int32_t T, int32_t B, int32_t H);

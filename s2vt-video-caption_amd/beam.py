@@ -18,7 +18,7 @@ import heapq
 import numpy as np
 import torch
 
-from . import ops
+from . import capi, ops
 
 FANOUT = 20  # hard-coded topk(20) of the reference (S2VTModel.py:216)
 
@@ -48,6 +48,9 @@ class BeamSearchNode(object):
         return bool(self.eval() > other.eval())
 
 
+PERSISTENT_ENCODER = True        # A/B switch: encoder recurrences on the persistent split-precision kernels
+
+
 @torch.no_grad()
 def beam_search(model, feats, params, beam_width=3, max_depth=30):
     (w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, w_f, b_f, w_o, b_o, emb) = [p.detach() for p in params]
@@ -65,16 +68,22 @@ def beam_search(model, feats, params, beam_width=3, max_depth=30):
     # ---- encoder: vid_rnn over the L real frames only, word_rnn with a zero embedding (S2VTModel.py:57-60)
     x1 = ops.feat_proj_fwd(feats.contiguous(), w_f, b_f)                       # [L*B, H] time-major
     gx1 = _gemm_strided(x1, w_ih1, bsum1)
-    h1_all, c1_all, _ = ops.lstm_seq_fwd(L, B, gx1, L, None, w_hh1)
+    # (the persistent split-precision recurrence, lstm_persist_x3.hip, where the shape is supported; else launches per timestep)
+    px = capi.load().s2vt_lstm_seq_x3_workspace_bytes(L, B, H) > 0 and PERSISTENT_ENCODER
+
+    def layer(gx, w_hh):
+        if px:
+            return ops.lstm_seq_fwd_persist(L, B, gx, L, None, w_hh, x3=True, poison=False)
+        return ops.lstm_seq_fwd(L, B, gx, L, None, w_hh)
+    h1_all, c1_all, _ = layer(gx1, w_hh1)
     gx2 = _gemm_strided(h1_all, w_v, bsum2)
-    h2_all, c2_all, _ = ops.lstm_seq_fwd(L, B, gx2, L, None, w_hh2)
+    h2_all, c2_all, _ = layer(gx2, w_hh2)
     vid_h, vid_c = h1_all[(L - 1) * B:], c1_all[(L - 1) * B:]
     word_h, word_c = h2_all[(L - 1) * B:].clone(), c2_all[(L - 1) * B:].clone()
 
     # ---- per-sample queues (host, BeamQueues) + one library call per depth (s2vt_beam_step): vid step for the batch,
     # word step / out_linear / log_softmax / top-20 for all expandable (sample, beam slot) rows
     import ctypes
-    from . import capi
     from .functional import _ptr, _stream, _dims, _params_struct
     lib = capi.load()
     queues = (BeamQueues if FAST_QUEUES else HeapQueues)(B, beam_width, sos, eos)

@@ -2185,7 +2185,7 @@ int s2vt_lstm_seq_fwd_persist(int32_t T, int32_t B, int32_t H, float* gx_stash0,
 // split-precision persistent forward (lstm_persist_x3.hip) as its own entry point.
 // workspace: [err int x64][sync A][sync B][W planes 0][W planes 1][h planes 0][h planes 1]
 size_t s2vt_lstm_seq_x3_workspace_bytes(int32_t T, int32_t B, int32_t H) {
-    if (T <= 0 || B <= 0 || H <= 0 || H > 1024) return 0;
+    if (T <= 0 || B <= 0 || H <= 0 || H > 1024 || !lstm_seq_fwd_x3_persist_supported(B, H)) return 0;      // 0: shape not supported
     const size_t Kp = (size_t)(H + 63) / 64 * 64;
     return 256 + 2 * lstm_persist_sync_bytes() + 2 * align_up(3 * 4 * (size_t)H * Kp * 2, 256) + 2 * align_up(3 * (size_t)T * B * Kp * 2, 256);
 }

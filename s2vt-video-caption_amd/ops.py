@@ -287,7 +287,7 @@ def _persist_ws(dev):
     return torch.zeros(n, dtype=torch.uint8, device=dev), n
 
 
-def lstm_seq_fwd_persist(T, B, gx, n_gx, bias, w_hh, block=0, second=None, x3=False):
+def lstm_seq_fwd_persist(T, B, gx, n_gx, bias, w_hh, block=0, second=None, x3=False, poison=True):
     """fp32 layer forward with the persistent kernel: returns (h_all, c_all, gates).  `second` = (gx, bias, w_hh) of another
     layer of the same shape that shares every launch: then a pair of result tuples is returned.  x3: the split-precision kernel
     (three bf16 planes per operand, lstm_persist_x3.hip) instead of the exact-fp32 MFMA one."""
@@ -299,7 +299,9 @@ def lstm_seq_fwd_persist(T, B, gx, n_gx, bias, w_hh, block=0, second=None, x3=Fa
     with torch.cuda.device(dev):
         if x3:      # (0xFF bytes: bf16 NaN patterns - the kernel must never read a plane element it has not written)
             n = lib.s2vt_lstm_seq_x3_workspace_bytes(T, B, H)
-            ws = torch.full((n,), 0xFF, dtype=torch.uint8, device=dev)
+            if n == 0:
+                raise capi.S2VTHipError("lstm_seq_fwd_persist(x3=True): shape B=%d H=%d is not supported on this device" % (B, H))
+            ws = torch.full((n,), 0xFF, dtype=torch.uint8, device=dev) if poison else torch.empty(n, dtype=torch.uint8, device=dev)
         else:
             ws, n = _persist_ws(dev)
         sets = []
