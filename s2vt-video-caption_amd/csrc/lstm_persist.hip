@@ -168,7 +168,7 @@ __device__ __forceinline__ void seq_fwd_body(const SeqFwdBf16Args& p, const int 
 #pragma unroll 1
         for (int s = 0; s < p.NS; ++s) {
             const int rbase = row0 + s * P_SR;            // first batch row of this sub-step
-            unsigned int* cnt = p.sync + (rg * P_MAXNS + s) * 32;
+            unsigned int* cnt = p.sync + (rbase / P_SR) * 32;          // one counter per 32-row chain, whatever NS the launch uses
             const int xrec = (bid == p.stamp_block) ? (t - p.t0) * p.NS + s : -1;
             XSTAMP(p.stamps, xrec, 0);
 
@@ -490,7 +490,7 @@ __device__ __forceinline__ void seq_bwd_body(const SeqBwdBf16Args& p, const int 
 #pragma unroll 1
         for (int s = 0; s < p.NS; ++s) {
             const int rbase = row0 + s * P_SR;
-            unsigned int* cnt = p.sync + (rg * P_MAXNS + s) * 32;
+            unsigned int* cnt = p.sync + (rbase / P_SR) * 32;          // one counter per 32-row chain, whatever NS the launch uses
             const int done = p.t1 - 1 - t;             // steps of this launch already finished by every workgroup?
             const int done_all = p.T - 1 - t;          // ... and of the whole sequence: the counters run on from launch to launch
             const int xrec = (bid == p.stamp_block) ? done * p.NS + s : -1;
@@ -665,19 +665,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 4) ? 2 : 1) void lstm_seq_bwd_bf16_
 
 // chains per workgroup such that TWO layers of this shape (un hidden units per workgroup) fit `cap` co-resident workgroups
 // (0: they do not)
-static int chains_for(int B, int H, int cap, int un) {
-    const int nC = cdiv(H, un);
+// single: a launch with ONE layer (the first / last stage of the layer pipeline, the test entries) may take the whole device:
+// half the chains per workgroup, half the sub-steps per timestep.  The hand-off counters are per 32-row chain, so launches of
+// one layer with different NS continue each other.
+static int chains_for(int B, int H, int cap, int un, bool single = false) {
+    const int nC = cdiv(H, un), lim = single ? cap : cap / 2;
     int R = B / P_SR;                       // row groups (one 32-row chain each) ...
     int ns = 1;
-    while (R * nC > cap / 2 && ns < P_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }   // ... merged until a layer fits half
-    return (R * nC <= cap / 2 && R <= 64) ? ns : 0;                               // the device (two layers co-run)
+    while (R * nC > lim && ns < P_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }       // ... merged until a layer fits half
+    return (R * nC <= lim && R <= 64) ? ns : 0;                                   // the device (two layers co-run)
 }
 
 // Which shape of the BPTT kernel a layer of (B, H) runs with: 32 units per workgroup (one workgroup per compute unit)
 // wherever two such layers fit the device, else 16 units (two per compute unit).  S2VT_BPTT_UNITS=16|32 pins one (tests,
 // A/B timing).
 struct BwdPlan { int un, ns, cap; };
-static BwdPlan bwd_plan(int B, int H, int Kp4) {
+static BwdPlan bwd_plan(int B, int H, int Kp4, bool single = false) {
     BwdPlan none = {0, 0, 0};
     if (!(B > 0 && B % P_SR == 0 && H % 8 == 0 && Kp4 % 64 == 0 && Kp4 >= 4 * H && Kp4 <= 64 * Q_KCH)) return none;
     static int pref = -1;
@@ -685,22 +688,22 @@ static BwdPlan bwd_plan(int B, int H, int Kp4) {
     if (pref != 16) {
         int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_bwd_bf16_persist_kernel<8, 32>), 512);
         if (cap > P_MAX_WG / 2) cap = P_MAX_WG / 2;
-        const int ns = chains_for(B, H, cap, 32);
-        if (ns > 0) return BwdPlan{32, ns, cap};
+        const int ns = chains_for(B, H, cap, 32, single);
+        if (ns > 0 && chains_for(B, H, cap, 32) > 0) return BwdPlan{32, ns, cap};        // (the kernel shape is the pair's choice)
     }
     if (pref != 32) {
         int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_bwd_bf16_persist_kernel<4, 16>), 256);
         if (cap > P_MAX_WG) cap = P_MAX_WG;
-        const int ns = chains_for(B, H, cap, 16);
-        if (ns > 0) return BwdPlan{16, ns, cap};
+        const int ns = chains_for(B, H, cap, 16, single);
+        if (ns > 0 && chains_for(B, H, cap, 16) > 0) return BwdPlan{16, ns, cap};
     }
     return none;
 }
 
 int lstm_seq_bwd_bf16_persist_supported(int B, int H, int Kp4) { return bwd_plan(B, H, Kp4).ns; }
 
-static int prep_bwd(SeqBwdBf16Args& a, BwdPlan* plan) {
-    *plan = bwd_plan(a.B, a.H, a.Kp);
+static int prep_bwd(SeqBwdBf16Args& a, BwdPlan* plan, bool single = false) {
+    *plan = bwd_plan(a.B, a.H, a.Kp, single);
     S2VT_REQUIRE(plan->ns > 0, "lstm_seq_bwd_bf16_persist: unsupported shape (B %% 32, H %% 8, 4H <= 4096) or two layers of it do not "
                  "fit the workgroups this device keeps resident");
     S2VT_REQUIRE(a.T > 0 && a.t1 > a.t0 && a.t0 >= 0 && a.t1 <= a.T && a.wtb && a.dgb && a.stash_dg && a.c_all && a.dc && a.sync && a.err,
@@ -718,7 +721,7 @@ static int prep_bwd(SeqBwdBf16Args& a, BwdPlan* plan) {
 int lstm_seq_bwd_bf16_persist2(hipStream_t stream, SeqBwdBf16Args a, const SeqBwdBf16Args* b) {
     int rc;
     BwdPlan pa, pb;
-    if ((rc = prep_bwd(a, &pa))) return rc;
+    if ((rc = prep_bwd(a, &pa, b == nullptr))) return rc;
     SeqBwdBf16Args bb = b ? *b : a;
     pb = pa;
     if (b) {
@@ -749,7 +752,10 @@ int lstm_seq_fwd_bf16_persist_supported(int B, int H, int Kp) {
 
 size_t lstm_persist_sync_bytes() { return (size_t)64 * P_MAXNS * 32 * sizeof(unsigned int); }   // <= 64 row groups
 
-static int prep(SeqFwdBf16Args& a, const char* who) {
+static int prep(SeqFwdBf16Args& a, const char* who, bool single = false) {
+    // (`single` is not used here: a one-layer forward launch with half the chains per workgroup - 504 workgroups of ONE layer,
+    // two per CU - measured slower, 1.97 vs 1.74 ms per config-3 forward: the two workgroups of a CU then belong to the same
+    // timestep wave and stop hiding each other's latencies; the one-workgroup-per-CU BPTT kernel gains, 2.64 -> 2.47 ms)
     const int ns = lstm_seq_fwd_bf16_persist_supported(a.B, a.H, a.Kp);
     S2VT_REQUIRE(ns > 0, "%s: unsupported shape (B %% 32, Kp <= 1024) or two layers of it do not fit the %d workgroups this device "
                  "keeps resident", who, persist_capacity());
@@ -766,7 +772,7 @@ static int prep(SeqFwdBf16Args& a, const char* who) {
 // one layer (b == nullptr) or two layers side by side in one launch
 int lstm_seq_fwd_bf16_persist2(hipStream_t stream, SeqFwdBf16Args a, const SeqFwdBf16Args* b) {
     int rc;
-    if ((rc = prep(a, "lstm_seq_fwd_bf16_persist"))) return rc;
+    if ((rc = prep(a, "lstm_seq_fwd_bf16_persist", b == nullptr))) return rc;
     SeqFwdBf16Args bb = b ? *b : a;
     if (b) {
         if ((rc = prep(bb, "lstm_seq_fwd_bf16_persist"))) return rc;
