@@ -136,7 +136,7 @@ def launcher_selftest(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)      # (a 20-step run read 3 % faster than the 400-step soak median of its box)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="batch per GPU (BASELINE configs[1]: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -224,6 +224,7 @@ def main():
         loss = one_step()
     sync_all()
     dt = time.perf_counter() - t0
+    dt_local = dt
     if use_pg:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -232,6 +233,29 @@ def main():
     frames_per_s = world * B * L * args.steps / dt
     capi.check_async_error()      # a device-side error inside the timed steps (bad token, timed-out hand-off) voids the number
     final_loss = float(loss)
+    # per-rank step time (which rank is the straggler?) and the gradient all-reduce under the microscope: three extra steps with
+    # events around every gradient group's collective on the communication stream (dp.FlatGradAllReducer.read_timing) - how long
+    # each group took, when it started relative to the end of the backward, how much of it the step had to wait for
+    rank_ms, comm = None, None
+    if use_pg:
+        mine = torch.tensor([dt_local / args.steps * 1e3], dtype=torch.float64, device=dev)
+        allms = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allms, mine)
+        allms = [float(x.item()) for x in allms]
+        rank_ms = {"min": round(min(allms), 3), "max": round(max(allms), 3), "by_rank": [round(x, 3) for x in allms]}
+        reducer.timing = True
+        for _ in range(3):
+            one_step()
+        sync_all()
+        reducer.timing = False
+        mine_comm = reducer.read_timing()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine_comm)
+        comm = dict(gathered[0])
+        comm["exposed_after_backward_ms_by_rank"] = [g["exposed_after_backward_ms"] for g in gathered]
+        comm["group_ms_by_rank"] = [g["group_ms"] for g in gathered]
+        comm["note"] = ("events on the communication stream, mean of 3 steps after the timed region; group 0 out_linear, 1 word_rnn + "
+                        "embedding, 2 vid_rnn + feat_linear; a group's start < 0 = issued while the backward was still running")
     # Host-side cost of ENQUEUING one step: the phases of a step timed separately with the queues drained before each (a
     # free-running host is throttled by queue back-pressure, which is GPU time, not host cost: round 2 reported that
     # figure, 8.3 ms, as if it were enqueue cost).  Must stay well below ms_per_step or the run is launch-bound.
@@ -622,6 +646,8 @@ def main():
             "decode": decode,
             "beam": beam,
             "cpu_baseline": cpu,
+            "ms_per_step_by_rank": rank_ms,
+            "comm": comm,
             "rccl_ranks": dist.get_world_size() if use_pg else 1,
             "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if use_pg else None,
             "dp_b128": shard128,

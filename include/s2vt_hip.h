@@ -213,6 +213,15 @@ size_t s2vt_colsum_ws_floats(int64_t rows, int32_t cols);
 int s2vt_lstm_step_fwd(int32_t B, int32_t H, const float* gx, const float* bias, const float* w_hh,
                        const float* h_prev, const float* c_prev, float* h_out, float* c_out, float* stash,
                        void* stream);
+/* One DECODE step of word_rnn (S2VTModel.py:100-103: embedding of the previous word, concatenated in front of vid_rnn's output,
+ * one nn.LSTM step): G = gx + h_prev·W_hh^T + Emb[token(b)]·W_e^T with gx [B,4H] = the vid_out half of the gate input + both
+ * biases, emb [V,E], w_e = the first E columns of word_rnn.weight_ih (row stride ldw_e).  token(b) = tok[b] (int32), else the
+ * packed argmax word of the previous step (s2vt_decode_step_argmax: 0xFFFFFFFF - low 32 bits), else tok_const for every row.
+ * A token id outside [0, V) - nn.Embedding raises IndexError there - is read as token 0 and reported as S2VT_ERR_INDEX by
+ * s2vt_check_async_error / the next call: it never addresses memory outside the table. */
+int s2vt_lstm_step_fwd_token(int32_t B, int32_t H, int32_t E, int32_t V, const float* gx, const float* w_hh, const float* h_prev,
+                             const float* c_prev, const float* emb, const float* w_e, int64_t ldw_e, const int32_t* tok,
+                             const unsigned long long* tok_packed, int32_t tok_const, float* h_out, float* c_out, void* stream);
 /* BPTT of one step: dh = dh_out + dg_next·W_hh (w_hh_t = W_hh^T [H,4H]); dc (in/out, [B,H]) carries dL/dc;
  * dg [B,4H] out (may alias stash). dg_next NULL at the last step; dc_is_zero = 1 there. */
 int s2vt_lstm_step_bwd(int32_t B, int32_t H, const float* dg_next, const float* w_hh_t, const float* dh_out,

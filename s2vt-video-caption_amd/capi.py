@@ -74,6 +74,8 @@ SIGNATURES = {
                                      c_void_p, c_void_p]),
     "s2vt_colsum_ws_floats": (c_size_t, [c_int64, c_int32]),
     "s2vt_lstm_step_fwd": (c_int32, [c_int32, c_int32] + [c_void_p] * 9),
+    "s2vt_lstm_step_fwd_token": (c_int32, [c_int32, c_int32, c_int32, c_int32] + [c_void_p] * 6 + [c_int64, c_void_p, c_void_p,
+                                                                                            c_int32, c_void_p, c_void_p, c_void_p]),
     "s2vt_lstm_step_bwd": (c_int32, [c_int32, c_int32] + [c_void_p] * 7 + [c_int32, c_void_p, c_void_p]),
     "s2vt_lstm_seq_fwd": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_int32] + [c_void_p] * 6),
     "s2vt_lstm_seq_bwd": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 5),

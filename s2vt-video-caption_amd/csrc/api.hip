@@ -57,9 +57,9 @@ static int read_record(ErrRecord& r, bool wait) {
     const int bad_target = r.host[0], timed_out = r.host[1];
     r.host[0] = r.host[1] = 0;
     if (bad_target) {
-        set_error("index out of range: a target id of the previous s2vt_train_forward / s2vt_mean_ce_forward lies outside "
-                  "[0, vocab_size) (the reference raises IndexError in nn.Embedding, S2VTModel.py:71, and in "
-                  "nn.CrossEntropyLoss, utils.py:22)");
+        set_error("index out of range: a token id of the previous call (targets of s2vt_train_forward / s2vt_mean_ce_forward, a "
+                  "decode or beam step's input token) lies outside [0, vocab_size) (the reference raises IndexError in "
+                  "nn.Embedding, S2VTModel.py:71,90,100,211, and in nn.CrossEntropyLoss, utils.py:22)");
         return S2VT_ERR_INDEX;
     }
     if (timed_out) {
@@ -99,6 +99,18 @@ static int post_async_error(hipStream_t st, const int* dev_flags, int kind = 0) 
     return 0;
 }
 
+// The four flag words of a per-op entry point that has no workspace of its own (s2vt_mean_ce_forward, s2vt_lstm_step_fwd_token):
+// the only device memory the library owns, 16 bytes per device, allocated on first use.
+static int device_flags(int** out) {
+    static int* flags_of[64] = {};
+    int dev = 0;
+    S2VT_HIP(hipGetDevice(&dev));
+    S2VT_REQUIRE(dev >= 0 && dev < 64, "device index %d", dev);
+    if (!flags_of[dev]) S2VT_HIP(hipMalloc(reinterpret_cast<void**>(&flags_of[dev]), 4 * sizeof(int)));
+    *out = flags_of[dev];
+    return 0;
+}
+
 // ------------------------------------------------------------------ live kernel timing
 enum { K_GEMM = 0, K_STEP_FWD = 1, K_STEP_BWD = 2, K_CE = 3, K_ARGMAX = 4, K_NKINDS = 5 };
 struct ProfRec { hipEvent_t a, b; int kind; int64_t launches; };
@@ -135,7 +147,7 @@ struct ProfScope {
 // addresses); a key that never repeats simply stays eager.  Not used while live timing is on (the event brackets are not
 // capturable).  At most 8 executables are kept (least recently used goes).
 static int g_graph_mode = -1;
-static bool g_capturing = false;
+static thread_local bool g_capturing = false;      // (the enqueue callback runs on the capturing thread)
 struct GraphEntry { hipGraphExec_t exec; unsigned long long last_use; int seen; };
 static std::map<std::vector<uint64_t>, GraphEntry> g_graphs;
 static std::mutex g_graph_mutex;
@@ -149,8 +161,21 @@ static int run_graphed(hipStream_t st, const std::vector<uint64_t>& key, F&& enq
     if (graphed) *graphed = false;
     if (!graph_on()) return enqueue(st);
     std::lock_guard<std::mutex> lock(g_graph_mutex);
+    // bound the table for keys that never repeat as well (a fresh pointer every step: no capture ever happens and the
+    // eviction below would never run): the least recently used entry goes before a ninth is inserted
+    auto evict_lru = [&](const GraphEntry* keep) {
+        while (g_graphs.size() > 8) {
+            auto oldest = g_graphs.end();
+            for (auto it = g_graphs.begin(); it != g_graphs.end(); ++it)
+                if (&it->second != keep && (oldest == g_graphs.end() || it->second.last_use < oldest->second.last_use)) oldest = it;
+            if (oldest == g_graphs.end()) break;
+            if (oldest->second.exec) (void)hipGraphExecDestroy(oldest->second.exec);
+            g_graphs.erase(oldest);
+        }
+    };
     GraphEntry& e = g_graphs[key];                  // (a new key: exec = nullptr, seen = 0)
     e.last_use = ++g_graph_tick;
+    evict_lru(&e);
     if (e.exec) {
         ++g_graph_replays;
         S2VT_HIP(hipGraphLaunch(e.exec, st));
@@ -177,14 +202,6 @@ static int run_graphed(hipStream_t st, const std::vector<uint64_t>& key, F&& enq
     S2VT_HIP(ie);
     e.exec = exec;
     ++g_graph_captures;
-    while (g_graphs.size() > 8) {
-        auto oldest = g_graphs.end();
-        for (auto it = g_graphs.begin(); it != g_graphs.end(); ++it)
-            if (&it->second != &e && (oldest == g_graphs.end() || it->second.last_use < oldest->second.last_use)) oldest = it;
-        if (oldest == g_graphs.end()) break;
-        if (oldest->second.exec) (void)hipGraphExecDestroy(oldest->second.exec);
-        g_graphs.erase(oldest);
-    }
     S2VT_HIP(hipGraphLaunch(exec, st));
     return 0;
 }
@@ -240,6 +257,7 @@ struct TrainWS {
     unsigned int *psync_a, *psync_b;     // hand-off counters of the persistent recurrence kernels (one block per lane)
     unsigned short *xw1, *xw2, *xh1, *xh2;   // split-precision persistent forward (lstm_persist_x3.hip): W_hh planes [3][4H][Kp],
     int64_t xkp;                             // h_t planes [3][T*B][Kp] per layer; Kp = H rounded up to 64 (0: H > 1024, no images)
+    bool xfwd;                               // the four images above are provided (the persistent x3 forward is selectable)
     unsigned short *xwt1, *xwt2;             // split-precision persistent BPTT: W_hh^T planes [3][Kp][4 Hp] per layer and the
     float *xpart1, *xpart2;                  // partial-sum rings [xnslots][B/32][nC][nC][32][16] (xnslots = 0: not provided)
     int xnslots; int64_t xpslot, xhp;
@@ -251,6 +269,8 @@ static bool dims_ok(const s2vt_dims* d) {
 }
 
 static int pipe_block();
+static int gemm_mode();
+static bool persist_x3_fwd_on();
 static bool persist_x3_bwd_on();
 static TrainWS carve_train(const s2vt_dims& d, void* base) {
     const size_t B = d.B, L = d.L, H = d.H, E = d.E, V = d.V, T = 2 * L - 1;
@@ -271,10 +291,14 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     w.psync_a = c.take<unsigned int>(lstm_persist_sync_bytes() / sizeof(unsigned int));
     w.psync_b = c.take<unsigned int>(lstm_persist_sync_bytes() / sizeof(unsigned int));
     w.xkp = (H <= 1024) ? (int64_t)((H + 63) / 64 * 64) : 0;
-    w.xw1 = c.take<unsigned short>(3 * 4 * H * w.xkp);
-    w.xw2 = c.take<unsigned short>(3 * 4 * H * w.xkp);
-    w.xh1 = c.take<unsigned short>(3 * T * B * w.xkp);
-    w.xh2 = c.take<unsigned short>(3 * T * B * w.xkp);
+    // images of the split-precision persistent forward: only where that kernel can be selected (the shape / mode part of
+    // train_forward_x3's predicate - no device query here: s2vt_train_workspace_bytes has no side effect and works without a
+    // GPU); the bf16 configuration (gemm mode 1) and the fp32-MFMA mode never read them (0.5 GB at B = 256)
+    w.xfwd = w.xkp > 0 && gemm_mode() == 3 && B % 64 == 0 && pipe_block() > 0 && persist_x3_fwd_on();
+    w.xw1 = c.take<unsigned short>(w.xfwd ? 3 * 4 * H * w.xkp : 0);
+    w.xw2 = c.take<unsigned short>(w.xfwd ? 3 * 4 * H * w.xkp : 0);
+    w.xh1 = c.take<unsigned short>(w.xfwd ? 3 * T * B * w.xkp : 0);
+    w.xh2 = c.take<unsigned short>(w.xfwd ? 3 * T * B * w.xkp : 0);
     {   // ring slots: one more than the longest block of the backward's pipeline (a slot is written once per launch)
         const bool can = w.xkp > 0 && B % 32 == 0 && pipe_block() > 0 && persist_x3_bwd_on();    // (opt-in kernel: no rings otherwise)
         const size_t maxblk = (size_t)pipe_block() < T ? (size_t)pipe_block() : T;
@@ -823,7 +847,7 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
     }
     if ((rc = handoff(st, sx, ev++))) return rc;
     if (bf && (rc = pdual(lb, p->word_w_hh, H, ID, 4 * H, H, &q.whh2, 0, &q.whh2T, 0, nullptr))) return rc;
-    const bool px3_fwd = !bf && XP == 3 && blk > 0 && w.xkp > 0 && persist_x3_fwd_on() && lstm_seq_fwd_x3_persist_supported(B, H);
+    const bool px3_fwd = !bf && XP == 3 && blk > 0 && w.xfwd && persist_x3_fwd_on() && lstm_seq_fwd_x3_persist_supported(B, H);
     if (px3_fwd) {   // W_hh of both layers as row-major planes for the persistent split-precision recurrence
         if ((rc = split3_rows(sx, p->vid_w_hh, H, 4 * H, H, (int)w.xkp, w.xw1, 4 * (int64_t)H * w.xkp))) return rc;
         if ((rc = split3_rows(sx, p->word_w_hh, H, 4 * H, H, (int)w.xkp, w.xw2, 4 * (int64_t)H * w.xkp))) return rc;
@@ -1431,7 +1455,7 @@ static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
         w.ph1 = mk(T * B, H);   w.ph2 = mk(B, H);
         w.embp = mk(d.V, d.E);  w.wep = mk(4 * H, d.E);
     }
-    w.xkp = (planes_ok(d) && H <= 1024) ? (int64_t)pad64((int)H) : 0;
+    w.xkp = (planes_ok(d) && H <= 1024 && pipe_block() > 0 && persist_x3_fwd_on()) ? (int64_t)pad64((int)H) : 0;   // (0: the persistent encode phase is not selectable)
     w.c1_all = c.take<float>(w.xkp ? T * B * H : 0);
     w.c2_all = c.take<float>(w.xkp ? L * B * H : 0);
     w.h2_all = c.take<float>(w.xkp ? L * B * H : 0);
@@ -1475,6 +1499,7 @@ static DecodeConst carve_decode_const(const s2vt_dims& d, void* base) {
 // ---------------------------------------------------------------------------------- batched beam-search depth
 struct BeamWS {
     float *bsum1, *bsum2, *ph, *pc, *gx, *logits, *gws;
+    int* err;                // [0]: a token id outside [0, V) reached the word step (reported as S2VT_ERR_INDEX)
     size_t gws_floats, bytes;
 };
 static BeamWS carve_beam(const s2vt_dims& d, int max_rows, void* base) {
@@ -1489,6 +1514,7 @@ static BeamWS carve_beam(const s2vt_dims& d, int max_rows, void* base) {
     w.logits = c.take<float>(R * V);
     w.gws_floats = 4 * R * (V > 4 * H ? V : 4 * H);
     w.gws = c.take<float>(w.gws_floats);
+    w.err = c.take<int>(4);
     w.bytes = align_up(c.off, 256);
     return w;
 }
@@ -1536,13 +1562,16 @@ int s2vt_beam_step(const s2vt_dims* d, const s2vt_params* p, int32_t R, const in
         a.B = R; a.H = H;
         a.h_prev = w.ph; a.ldh = H; a.w_hh = p->word_w_hh; a.ldw = H;
         a.x2 = p->emb_w; a.ldx2 = E; a.K2 = E; a.w2 = p->word_w_ih; a.ldw2 = E + H; a.tok_idx = tok;
+        a.tok_limit = V; a.tok_err = w.err;            // nn.Embedding raises IndexError for such an id (S2VTModel.py:211)
         a.gx = w.gx; a.ldgx = 4 * H;
         a.c_prev = w.pc; a.ldc = H;
         a.h_out = word_h_out; a.ldho = H; a.c_out = word_c_out; a.ldco = H;
+        if ((rc = fill_zero(st, w.err, 4 * sizeof(int)))) return rc;
         if ((rc = lstm_step_fwd(st, a))) return rc;
     }
     if ((rc = lgemm(ln, true, true, R, V, H, word_h_out, H, ID, p->out_w, H, ID, w.logits, V, ID, p->out_b, false))) return rc;   // (:213)
-    return top20_logprob(st, w.logits, V, R, V, top_ix, top_lp);                                                                   // (:214-219)
+    if ((rc = top20_logprob(st, w.logits, V, R, V, top_ix, top_lp))) return rc;                                                    // (:214-219)
+    return post_async_error(st, w.err);
 }
 
 int s2vt_backward_wait_grads(int32_t group, void* stream) {
@@ -1603,6 +1632,7 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
     if ((rc = add_vectors(st, p->vid_b_ih, p->vid_b_hh, w.bsum1, 4 * H))) return rc;
     if ((rc = add_vectors(st, p->word_b_ih, p->word_b_hh, w.bsum2, 4 * H))) return rc;
     if ((rc = fill_zero(st, w.packed, sizeof(unsigned long long) * (size_t)(L - 1) * B))) return rc;
+    if ((rc = fill_zero(st, w.err, 4 * sizeof(int)))) return rc;
     if ((rc = handoff(st, sx, ev++))) return rc;
     // feature projection + vid_rnn input GEMM                                  S2VTModel.py:54, 64-67
     static const bool argmax_f32 = getenv("S2VT_ARGMAX_F32") && atoi(getenv("S2VT_ARGMAX_F32")) != 0;   // A/B switch: the fp32-MFMA kernel
@@ -1614,16 +1644,21 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
     // encode phase (both layers, L steps) and vid_rnn's input-free decode steps as persistent split-precision launches; only the
     // 79 token-dependent word_rnn steps stay one launch (+ argmax) per step
     const bool use_px = x3 && blk > 0 && w.xkp > 0 && persist_x3_fwd_on() && lstm_seq_fwd_x3_persist_supported(B, H);
-    if (use_px && fill) {
-        if ((rc = split3_rows(sx, p->vid_w_hh, H, 4 * H, H, (int)w.xkp, kc.xw1, 4 * (int64_t)H * w.xkp))) return rc;
-        if ((rc = split3_rows(sx, p->word_w_hh, H, 4 * H, H, (int)w.xkp, kc.xw2, 4 * (int64_t)H * w.xkp))) return rc;
+    // A caller-kept cache outlives this call's choices (batch size, recurrence mode, pipeline block, experiment switches): a call
+    // that fills it builds EVERY weight-derived image it holds, not only the ones this call reads - a later call on the same
+    // weights with another batch or mode then finds its images whatever it selects (cache_valid says "the weights stand",
+    // nothing about who filled it).
+    const bool fill_all = fill && cache != nullptr;
+    const int64_t ckp = (x3 && H <= 1024) ? (int64_t)pad64(H) : 0;      // row length of the W_hh plane images (carve_decode_const)
+    if (ckp > 0 && fill && (use_px || fill_all)) {
+        if ((rc = split3_rows(sx, p->vid_w_hh, H, 4 * H, H, (int)ckp, kc.xw1, 4 * (int64_t)H * ckp))) return rc;
+        if ((rc = split3_rows(sx, p->word_w_hh, H, 4 * H, H, (int)ckp, kc.xw2, 4 * (int64_t)H * ckp))) return rc;
     }
     if (x3) {
-        if (ax3) {      // W_o planes: constant over the 79 decode steps; h_t planes: written by the decode steps themselves, k padding zeroed here
-            if (fill && (rc = psplit(lb, kc.wo, 0, p->out_w, H, ID, V, H))) return rc;
-            if ((rc = fill_zero(sx, w.ph2.p, rows64((size_t)B) * (size_t)w.ph2.ld * sizeof(unsigned short)))) return rc;
-        }
-        if (use_tab && fill) {  // gtab[v] = Emb[v]·W_e^T for every token (S2VTModel.py:90-93,100-103: embedding + the embed columns of word_rnn's W_ih)
+        // W_o planes: constant over the 79 decode steps; h_t planes: written by the decode steps themselves, k padding zeroed here
+        if (fill && (ax3 || fill_all) && (rc = psplit(lb, kc.wo, 0, p->out_w, H, ID, V, H))) return rc;
+        if (ax3 && (rc = fill_zero(sx, w.ph2.p, rows64((size_t)B) * (size_t)w.ph2.ld * sizeof(unsigned short)))) return rc;
+        if (fill && (use_tab || fill_all)) {  // gtab[v] = Emb[v]·W_e^T for every token (S2VTModel.py:90-93,100-103: embedding + the embed columns of word_rnn's W_ih)
             if ((rc = psplit(lb, w.embp, 0, p->emb_w, E, ID, V, E))) return rc;
             if ((rc = psplit(lb, w.wep, 0, p->word_w_ih, E + H, ID, 4 * H, E))) return rc;
             if ((rc = pgemm(lb, V, 4 * H, E, w.embp, 0, 0, w.wep, 0, 0, kc.gtab, 4 * H, ID, nullptr, false))) return rc;
@@ -1661,6 +1696,9 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
                 }
                 a.tok_packed = (t > L) ? w.packed + (int64_t)(t - L - 1) * B : nullptr;
                 a.tok_const = sos_ix;
+                // the packed word is the previous step's argmax: a producer that left it unwritten would decode as token
+                // 0xFFFFFFFF - clamped and flagged (w.err[0], S2VT_ERR_INDEX) instead of read from beyond the table
+                a.tok_limit = V; a.tok_err = w.err;
             }
             a.gx = w.gx2 + t * B4H; a.ldgx = 4 * (int64_t)H;
             a.c_prev = cprev; a.ldc = H;
@@ -1693,7 +1731,6 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
     };
     if (use_px) {
         if ((rc = handoff(sx, st, ev++))) return rc;            // lane B's weight images before their first use on this stream
-        if ((rc = fill_zero(st, w.err, 4 * sizeof(int)))) return rc;
         auto gx2_block = [&](int t0, int t1) -> int {           // vid_out half of word_rnn's gate input for steps [t0, t1) (+ biases)
             int r;
             if ((r = psplit(la, w.ph1, t0 * B, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H))) return r;
@@ -1769,7 +1806,8 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
             if ((rc = word_step(sx, t, t ? w.h2 + ((t - 1) & 1) * BH : nullptr, t ? w.c2 : nullptr))) return rc;
     }
     if ((rc = handoff(sx, st, ev++))) return rc;
-    return unpack_tokens(st, w.packed, L - 1, B, ids);
+    if ((rc = unpack_tokens(st, w.packed, L - 1, B, ids))) return rc;
+    return post_async_error(st, w.err);
 }
 
 // ------------------------------------------------------------------ loss
@@ -1777,22 +1815,18 @@ int s2vt_mean_ce_forward(int32_t B, int32_t Lm1, int32_t V, const float* logits,
                          int64_t target_ld, float* lse, float* rowloss, float* loss_out, void* stream) {
     S2VT_REQUIRE(B > 0 && Lm1 > 0 && V > 0, "s2vt_mean_ce_forward: bad dims");
     hipStream_t st = (hipStream_t)stream;
-    // target ids outside [0, V): flagged on the device, reported like the embedding's (s2vt_check_async_error).  The four
-    // flag words are the only device memory the library owns: 16 bytes per device, allocated on first use.
-    static int* flags_of[64] = {};
-    int dev = 0;
-    S2VT_HIP(hipGetDevice(&dev));
-    S2VT_REQUIRE(dev >= 0 && dev < 64, "s2vt_mean_ce_forward: device index %d", dev);
-    if (!flags_of[dev]) S2VT_HIP(hipMalloc(reinterpret_cast<void**>(&flags_of[dev]), 4 * sizeof(int)));
-    const int rc0 = poll_async_error(false);
+    // target ids outside [0, V): flagged on the device, reported like the embedding's (s2vt_check_async_error)
+    int* flags = nullptr;
     int rc;
-    if ((rc = fill_zero(st, flags_of[dev], 4 * sizeof(int)))) return rc;
+    if ((rc = device_flags(&flags))) return rc;
+    const int rc0 = poll_async_error(false);
+    if ((rc = fill_zero(st, flags, 4 * sizeof(int)))) return rc;
     {
         ProfScope ps(st, K_CE, 1);
-        if ((rc = mean_ce_fwd(st, logits, (int64_t)B * Lm1, V, target, Lm1, target_ld, lse, rowloss, loss_out, flags_of[dev])))
+        if ((rc = mean_ce_fwd(st, logits, (int64_t)B * Lm1, V, target, Lm1, target_ld, lse, rowloss, loss_out, flags)))
             return rc;
     }
-    return rc0 ? rc0 : post_async_error(st, flags_of[dev], 2);
+    return rc0 ? rc0 : post_async_error(st, flags, 2);
 }
 int s2vt_mean_ce_backward(int32_t B, int32_t Lm1, int32_t V, const float* logits, const int64_t* target,
                           int64_t target_ld, const float* lse, const float* gout, float* dlogits, void* stream) {
@@ -1902,6 +1936,34 @@ int s2vt_lstm_step_fwd(int32_t B, int32_t H, const float* gx, const float* bias,
     a.stash = stash; a.ldst = 4 * (int64_t)H;
     ProfScope ps((hipStream_t)stream, K_STEP_FWD, 1);
     return lstm_step_fwd((hipStream_t)stream, a);
+}
+
+int s2vt_lstm_step_fwd_token(int32_t B, int32_t H, int32_t E, int32_t V, const float* gx, const float* w_hh, const float* h_prev,
+                             const float* c_prev, const float* emb, const float* w_e, int64_t ldw_e, const int32_t* tok,
+                             const unsigned long long* tok_packed, int32_t tok_const, float* h_out, float* c_out, void* stream) {
+    S2VT_REQUIRE(B > 0 && H > 0 && E > 0 && V > 0 && gx && w_hh && emb && w_e && h_out && c_out && ldw_e >= E,
+                 "s2vt_lstm_step_fwd_token: null/invalid argument");
+    hipStream_t st = (hipStream_t)stream;
+    int* flags = nullptr;
+    int rc;
+    if ((rc = device_flags(&flags))) return rc;
+    const int rc0 = poll_async_error(false);
+    if ((rc = fill_zero(st, flags, 4 * sizeof(int)))) return rc;
+    StepFwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.B = B; a.H = H;
+    a.h_prev = h_prev; a.ldh = H; a.w_hh = w_hh; a.ldw = H;
+    a.x2 = emb; a.ldx2 = E; a.K2 = E; a.w2 = w_e; a.ldw2 = ldw_e;
+    a.tok_idx = tok; a.tok_packed = tok_packed; a.tok_const = tok_const;
+    a.tok_limit = V; a.tok_err = flags;
+    a.gx = gx; a.ldgx = 4 * (int64_t)H;
+    a.c_prev = c_prev; a.ldc = H;
+    a.h_out = h_out; a.ldho = H; a.c_out = c_out; a.ldco = H;
+    {
+        ProfScope ps(st, K_STEP_FWD, 1);
+        if ((rc = lstm_step_fwd(st, a))) return rc;
+    }
+    return rc0 ? rc0 : post_async_error(st, flags, 2);
 }
 
 int s2vt_lstm_step_bwd(int32_t B, int32_t H, const float* dg_next, const float* w_hh_t, const float* dh_out,

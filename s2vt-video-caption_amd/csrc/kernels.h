@@ -66,6 +66,11 @@ struct StepFwdArgs {
     // (tok_idx / tok_packed / tok_const): gtab[tok][4H] = Emb[tok]·W_e^T computed once per decode call replaces the
     // E-wide second K segment of every decode step (x2 must then be null)
     const float* gx_tab; int64_t ldtab;
+    // guard of the token path (tok_idx / tok_packed / tok_const): an id outside [0, tok_limit) is read as token 0 and raises
+    // *tok_err (the S2VT_ERR_INDEX flag word of the caller's workspace) instead of addressing memory outside the table - a
+    // producer bug (e.g. a packed argmax word that no workgroup wrote) then surfaces as an error code, not as a GPU fault.
+    // tok_limit == 0: no token segment in use
+    int tok_limit; int* tok_err;
 };
 int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a);
 int lstm_step_fwd2(hipStream_t stream, const StepFwdArgs& a, const StepFwdArgs* b);   // two independent steps, one launch

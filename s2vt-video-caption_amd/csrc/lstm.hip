@@ -192,6 +192,18 @@ __global__ __launch_bounds__(NW_FWD * 64, NW_FWD / 2) void lstm_step_fwd_kernel(
     else lstm_step_fwd_body<MT, NT, VEC>(pb, blockIdx.x - na);
 }
 
+// token of batch row b for the embedding segment / the per-token table; ids outside [0, tok_limit) -> token 0 + error flag
+__device__ __forceinline__ int64_t step_token(const StepFwdArgs& p, int b) {
+    int64_t tok = p.tok_const;
+    if (p.tok_idx) tok = p.tok_idx[b];
+    else if (p.tok_packed) tok = (int64_t)(0xFFFFFFFFu - (uint32_t)(p.tok_packed[b] & 0xFFFFFFFFull));
+    if ((uint64_t)tok >= (uint64_t)(int64_t)p.tok_limit) {
+        if (p.tok_err) *p.tok_err = 1;
+        tok = 0;
+    }
+    return tok;
+}
+
 template <int MT, int NT, bool VEC>
 __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid) {
     constexpr int TM = 16 * MT, TN = 16 * NT, UN = TN / 4;
@@ -233,11 +245,7 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
     }
     float gtv[4] = {0.f, 0.f, 0.f, 0.f};
     if (p.gx_tab) {       // embedded-word half of the gate input from the per-token table (two dependent loads, behind the K loop)
-        int64_t tok = p.tok_const;
-        if (evalid) {
-            if (p.tok_idx) tok = p.tok_idx[eb];
-            else if (p.tok_packed) tok = (int64_t)(0xFFFFFFFFu - (uint32_t)(p.tok_packed[eb] & 0xFFFFFFFFull));
-        }
+        const int64_t tok = evalid ? step_token(p, eb) : 0;
         const float* trow = p.gx_tab + tok * p.ldtab;
 #pragma unroll
         for (int g = 0; g < 4; ++g) gtv[g] = *(evalid ? trow + (int64_t)g * p.H + eunit : g_zero4);
@@ -265,11 +273,7 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
         for (int i = 0; i < MT * LPT; ++i) {
             const int b = b0 + lrow + RPL * i;
             if (b < p.B) {
-                int64_t tok;
-                if (p.tok_idx) tok = p.tok_idx[b];
-                else if (p.tok_packed) tok = (int64_t)(0xFFFFFFFFu - (uint32_t)(p.tok_packed[b] & 0xFFFFFFFFull));
-                else tok = p.tok_const;
-                arow[i] = p.x2 + tok * p.ldx2;
+                arow[i] = p.x2 + step_token(p, b) * p.ldx2;
             } else {
                 arow[i] = nullptr;
             }
@@ -339,6 +343,7 @@ static bool step_fwd_vec(const StepFwdArgs& a) {
 int lstm_step_fwd2(hipStream_t stream, const StepFwdArgs& a, const StepFwdArgs* b) {
     S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.h_out && a.c_out, "lstm_step_fwd: bad arguments");
     S2VT_REQUIRE(a.gx || a.bias, "lstm_step_fwd: need gx or bias");
+    S2VT_REQUIRE(!(a.x2 || a.gx_tab) || a.tok_limit > 0, "lstm_step_fwd: a token segment needs tok_limit (rows of the table)");
     S2VT_REQUIRE(!b || (b->B == a.B && b->H == a.H && b->h_out && b->c_out && (b->gx || b->bias)),
                  "lstm_step_fwd: paired steps must have the same batch and hidden size");
     const bool vec = step_fwd_vec(a) && (!b || step_fwd_vec(*b));

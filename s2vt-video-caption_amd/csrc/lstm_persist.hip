@@ -35,6 +35,8 @@
 // All workgroups of a launch must be co-resident (2 per CU): the launchers ask the runtime how many workgroups of the
 // kernel the device holds at once (compute units x occupancy, coresident_capacity()) and a shape that does not fit is
 // reported as unsupported, so the drivers fall back to one launch per timestep (api.hip).
+#include <mutex>
+
 #include "common.h"
 #include "experiment.h"
 #include "kernels.h"
@@ -361,6 +363,8 @@ int coresident_capacity(const void* kernel, int block) {
     struct Entry { int dev; const void* k; int cap; };
     static Entry cache[32];
     static int n = 0;
+    static std::mutex mu;               // the forward (caller's thread) and the backward (autograd's thread) both size launches
+    std::lock_guard<std::mutex> lock(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     for (int i = 0; i < n; ++i)

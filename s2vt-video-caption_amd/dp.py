@@ -64,7 +64,9 @@ class FlatGradAllReducer:
         self.model = None
         self.groups = None
         self.comm_stream = None
-        
+        self.timing = False          # True: every all_reduce() brackets its collectives with events (read_timing())
+        self._timed = []
+
     def attach(self, model):
         """Overlap mode for the HIP S2VT replica `model` (whose 13 parameters are exactly self.params):
         * the backward WRITES its gradients straight into the flat buffer (no autograd accumulation pass, no zeroing);
@@ -102,11 +104,18 @@ class FlatGradAllReducer:
             return
         if self.model is not None and self.flat.is_cuda:
             return self._all_reduce_overlapped()
+        import time
+        t0 = time.perf_counter()
         works = [dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                  for (lo, hi) in reversed(self.buckets)]
         for w in works:
             w.wait()
         self.flat.mul_(1.0 / self.world)
+        if self.timing:          # bucketed path (CPU / gloo, or a replica that is not attached): host wall time, nothing overlaps
+            if self.flat.is_cuda:
+                torch.cuda.synchronize(self.flat.device)
+            ms = (time.perf_counter() - t0) * 1e3
+            self._timed.append({"host_ms": ms, "bytes": [self.flat.numel() * self.flat.element_size()]})
 
     def _all_reduce_overlapped(self):
         """Called right after loss.backward() returned, i.e. with the whole backward ENQUEUED but mostly not executed."""
@@ -120,15 +129,52 @@ class FlatGradAllReducer:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
             t.mul_(1.0 / self.world)
 
+        ev = None
+        if self.timing:              # diagnosis of a multi-GPU run: when did each group's all-reduce start and end, when did the
+            mk = lambda: torch.cuda.Event(enable_timing=True)     # backward end (all on the device's clock)
+            ev = {"bwd_end": mk(), "g": [(mk(), mk()) for _ in range(3)]}
+            ev["bwd_end"].record(main)
         with torch.cuda.stream(cs):
             for g in (0, 1):
                 capi.check(lib.s2vt_backward_wait_grads(g, capi.c_void_p(cs.cuda_stream)), "s2vt_backward_wait_grads")
+                if ev:
+                    ev["g"][g][0].record(cs)
                 for lo, hi in self.groups[g]:
                     reduce(lo, hi)
+                if ev:
+                    ev["g"][g][1].record(cs)
             cs.wait_stream(main)                 # the remaining gradients are final with the backward's stream
+            if ev:
+                ev["g"][2][0].record(cs)
             for lo, hi in self.groups[2]:
                 reduce(lo, hi)
+            if ev:
+                ev["g"][2][1].record(cs)
         main.wait_stream(cs)
+        if ev:
+            self._timed.append(ev)
+
+    def read_timing(self):
+        """Mean over the all_reduce() calls made with `timing` on (and forget them): per gradient group (0 out_linear, 1 word_rnn +
+        embedding, 2 vid_rnn + feat_linear) the duration of its all-reduce + 1/W scaling on the communication stream, its start
+        relative to the end of the backward (negative = issued under the backward), and `exposed_after_backward_ms` = from the
+        backward's last kernel to the last collective's end - the part of the communication the step waits for."""
+        recs, self._timed = self._timed, []
+        if not recs:
+            return None
+        if "host_ms" in recs[0]:
+            return {"path": "bucketed (not overlapped)", "calls": len(recs), "host_ms": sum(r["host_ms"] for r in recs) / len(recs),
+                    "bytes": recs[0]["bytes"], "world": self.world}
+        torch.cuda.synchronize(self.flat.device)
+        n = len(recs)
+        esz = self.flat.element_size()
+        grp = [sum(r["g"][g][0].elapsed_time(r["g"][g][1]) for r in recs) / n for g in range(3)]
+        start = [sum(r["bwd_end"].elapsed_time(r["g"][g][0]) for r in recs) / n for g in range(3)]
+        exposed = sum(max(0.0, r["bwd_end"].elapsed_time(r["g"][2][1])) for r in recs) / n
+        return {"path": "overlapped with the backward (s2vt_backward_wait_grads)", "calls": n, "world": self.world,
+                "group_ms": [round(x, 4) for x in grp], "group_start_after_backward_end_ms": [round(x, 4) for x in start],
+                "exposed_after_backward_ms": round(exposed, 4),
+                "bytes": [sum(hi - lo for lo, hi in self.groups[g]) * esz for g in range(3)]}
 
 
 def global_mean(total, count, device="cpu"):
@@ -161,6 +207,20 @@ def train_step(model, criterion, optimizer, feats, caps, mask, reducer=None, che
     if check_errors:
         from . import capi
         torch.cuda.synchronize(loss.device)
-        capi.check_async_error()
+        err = None
+        try:
+            capi.check_async_error()
+        except Exception as e:                  # noqa: BLE001 - re-raised below, on every rank
+            err = e
+        if reducer is not None and reducer.world > 1:
+            # every rank learns whether ANY rank failed before one of them raises: a rank that raised alone would leave the
+            # others blocked in the next step's all-reduce until the process-group time-out
+            flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=loss.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=reducer.group)
+            if err is None and int(flag[0]) != 0:
+                err = capi.S2VTHipError("another rank reported a device-side error in this step (bad caption id or a timed-out "
+                                        "hand-off): stopping with it")
+        if err is not None:
+            raise err
     optimizer.step()
     return loss.detach()

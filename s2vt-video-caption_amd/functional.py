@@ -108,7 +108,11 @@ class _TrainForward(torch.autograd.Function):
         if ctx.dlog_fused:
             # the criterion's backward already turned the logits into dlogits operand planes inside ctx.ws; what arrives here is
             # its stride-0 placeholder.  Anything else means a second consumer of the logits added its own gradient
-            if not (dlogits.dim() == 3 and all(st == 0 for st in dlogits.stride())):
+            # (stride 0 everywhere).  A tensor hook on the logits, anomaly mode or a future autograd that makes incoming
+            # gradients contiguous hands over a MATERIALISED copy of those zeros: still the hand-over, recognised by its
+            # content (one reduction over [B, L-1, V], only on that rare route), not by its strides
+            placeholder = dlogits.dim() == 3 and all(st == 0 for st in dlogits.stride())
+            if not placeholder and bool((dlogits != 0).any()):
                 raise capi.S2VTHipError("the logits of this forward fed the fused MaskCriterion backward AND another consumer: set "
                                         "s2vt_video_caption_amd.functional.FUSE_CE = False to materialise dlogits")
             dlogits = None
@@ -197,6 +201,8 @@ def greedy_decode(feats, params, sos_ix, owner=None):
         ids = torch.empty(d.B, d.L - 1, dtype=torch.int64, device=dev)
         ps = _params_struct(capi.Params, params)
         if owner is not None and DECODE_CACHE and d.B % 64 == 0 and lib.s2vt_set_gemm_mode(-1) != 0:
+            # (the batch size, the recurrence mode and the pipeline block are NOT in the key: a filling call writes every
+            # image the cache holds, whichever of them its own batch / modes read - s2vt_greedy_decode_cached)
             key = (tuple((p.data_ptr(), p._version) for p in raw), (d.L, d.F, d.H, d.E, d.V), lib.s2vt_set_gemm_mode(-1),
                    str(dev), torch.cuda.current_stream(dev).cuda_stream)
             entry = _DECODE_CACHES.get(owner)

@@ -115,6 +115,25 @@ def lstm_step_fwd(gx, bias, w_hh, h_prev, c_prev, want_stash=False):
     return (h, c, stash) if want_stash else (h, c)
 
 
+def lstm_step_fwd_token(gx, w_hh, h_prev, c_prev, emb, w_ih, tok=None, tok_packed=None, tok_const=0):
+    """One decode step of word_rnn (S2VTModel.py:100-103): gx [B,4H] (vid_out half of the gate input + biases), emb [V,E],
+    w_ih [4H, E+H] (its first E columns multiply the embedded word).  Token per row: `tok` int32 [B], else `tok_packed` (the
+    packed argmax words of decode_step_argmax), else `tok_const`.  Ids outside [0, V) raise IndexError at the next
+    capi.check_async_error()."""
+    lib = capi.load()
+    gx, w_hh, emb, w_ih = _f32c(gx, "gx"), _f32c(w_hh, "w_hh"), _f32c(emb, "emb"), _f32c(w_ih, "w_ih")
+    B, H = gx.shape[0], w_hh.shape[1]
+    V, E = emb.shape
+    dev = gx.device
+    with torch.cuda.device(dev):
+        h = torch.empty(B, H, dtype=torch.float32, device=dev)
+        c = torch.empty(B, H, dtype=torch.float32, device=dev)
+        capi.check(lib.s2vt_lstm_step_fwd_token(B, H, E, V, _ptr(gx), _ptr(w_hh), _ptr(h_prev), _ptr(c_prev), _ptr(emb), _ptr(w_ih),
+                                                w_ih.stride(0), _ptr(tok), _ptr(tok_packed), int(tok_const), _ptr(h), _ptr(c),
+                                                _stream(dev)), "s2vt_lstm_step_fwd_token")
+    return h, c
+
+
 def lstm_step_bwd(dg_next, w_hh_t, dh_out, stash, c, c_prev, dc, dc_is_zero):
     lib = capi.load()
     B, H4 = stash.shape

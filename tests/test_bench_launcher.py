@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -30,3 +32,22 @@ def test_world_size_mismatch_aborts():
                                                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29917"})
     assert r.returncode != 0
     assert not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+def test_one_rank_rccl_line_carries_the_comm_record():
+    """The N > 1 path of bench.py on the one GPU of the test box: a 1-rank RCCL group (S2VT_BENCH_PG=1) runs the overlapped
+    all-reduce code, and the JSON line must say how long each gradient group's collective took and how much of it was exposed
+    after the backward - the fields the first 8-GPU run will be read by."""
+    r = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--headline-only"],
+             {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29931",
+              "S2VT_BENCH_PG": "1"})
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert out["rccl_ranks"] == 1 and out["n_gpus"] == 1
+    c = out["comm"]
+    assert len(c["group_ms"]) == 3 and all(x >= 0 for x in c["group_ms"]) and len(c["bytes"]) == 3
+    assert sum(c["bytes"]) == 4 * 48125000                              # the whole flat gradient buffer (SURVEY.md §8e)
+    assert c["exposed_after_backward_ms"] >= 0 and len(c["exposed_after_backward_ms_by_rank"]) == 1
+    assert c["group_start_after_backward_end_ms"][0] < 0               # out_linear's all-reduce starts under the backward
+    assert out["ms_per_step_by_rank"]["min"] <= out["ms_per_step_by_rank"]["max"]

@@ -161,6 +161,52 @@ def test_lstm_step_fwd_matches_cell(lib, B, H):
     assert (hb.cpu() - h_ref2.expand(B, H)).abs().max().item() < 1e-6
 
 
+
+def test_decode_step_token_segment_and_poisoned_token_word(lib):
+    """The decode step's token path (S2VTModel.py:100-103: Emb[prev word] in front of vid_out) through s2vt_lstm_step_fwd_token:
+    (a) int32 tokens and packed argmax words against the fp64 cell; (b) a packed word that no producer wrote (0 -> token
+    0xFFFFFFFF) or an int32 id >= V must come back as IndexError from capi.check_async_error() - the row is computed with
+    token 0 and nothing outside the table is addressed - where the kernel used to read emb + 4e9 rows (a queue abort)."""
+    from s2vt_video_caption_amd import capi, ops
+    B, H, E, V = 37, 72, 40, 50
+    gx, w_hh, w_ih, emb = _r(B, 4 * H, seed=1), _r(4 * H, H, seed=2, scale=0.2), _r(4 * H, E + H, seed=3, scale=0.2), _r(V, E, seed=4)
+    hp, cp = _r(B, H, seed=5, scale=0.5), _r(B, H, seed=6, scale=0.5)
+    tok = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(7), dtype=torch.int32)
+
+    def ref(tk):
+        pre = gx.double() + hp.double() @ w_hh.double().t() + emb[tk.long()].double() @ w_ih[:, :E].double().t()
+        i, f, g, o = pre.chunk(4, dim=1)
+        c = torch.sigmoid(f) * cp.double() + torch.sigmoid(i) * torch.tanh(g)
+        return torch.sigmoid(o) * torch.tanh(c), c
+    args = [t.to(DEV) for t in (gx, w_hh, hp, cp, emb, w_ih)]
+    h, c = ops.lstm_step_fwd_token(*args, tok=tok.to(DEV))
+    capi.check_async_error()
+    hr, cr = ref(tok)
+    assert (h.cpu().double() - hr).abs().max().item() < 2e-6 and (c.cpu().double() - cr).abs().max().item() < 2e-6
+    packed = ((torch.arange(B, dtype=torch.int64) + 1234) << 32) | (0xFFFFFFFF - tok.long())     # (ordered logit << 32 | ~index)
+    h2, c2 = ops.lstm_step_fwd_token(*args, tok_packed=packed.to(DEV))
+    capi.check_async_error()
+    assert torch.equal(h2, h) and torch.equal(c2, c)
+    h3, _ = ops.lstm_step_fwd_token(*args, tok_const=9)
+    capi.check_async_error()
+    assert (h3.cpu().double() - ref(torch.full((B,), 9))[0]).abs().max().item() < 2e-6
+    # poisoned inputs: row 5's packed word never written; an int32 id == V; a negative id
+    for kw in (dict(tok_packed=packed.clone().index_fill_(0, torch.tensor([5]), 0).to(DEV)),
+               dict(tok=tok.clone().index_fill_(0, torch.tensor([5]), V).to(DEV)),
+               dict(tok=tok.clone().index_fill_(0, torch.tensor([5]), -1).to(DEV)),
+               dict(tok_const=V)):
+        hb, cb = ops.lstm_step_fwd_token(*args, **kw)
+        with pytest.raises(IndexError):
+            capi.check_async_error()
+        if "tok_const" not in kw:                       # every other row is untouched, the bad row ran with token 0
+            tz = tok.clone()
+            tz[5] = 0
+            assert (hb.cpu().double() - ref(tz)[0]).abs().max().item() < 2e-6
+    h4, _ = ops.lstm_step_fwd_token(*args, tok=tok.to(DEV))        # the flag does not stick
+    capi.check_async_error()
+    assert torch.equal(h4, h)
+
+
 @pytest.mark.parametrize("B,H", [(3, 32), (20, 100), (64, 500)])
 def test_lstm_step_bwd_matches_autograd(lib, B, H):
     from s2vt_video_caption_amd import ops

@@ -753,6 +753,51 @@ def test_decode_cache_follows_the_weights(lib, golden):
         functional.clear_decode_cache()
 
 
+
+def test_decode_cache_filled_under_one_mode_serves_every_other(lib, golden):
+    """The cache is keyed on the WEIGHTS; which images a call reads depends on its batch size, the recurrence mode and the
+    pipeline block (the persistent encode phase reads the W_hh plane images, the launch-per-timestep schedule does not).  A call
+    that fills the cache must therefore write every image: fill under a mode / batch that does not use the persistent kernels
+    (recurrence mode 0; pipeline block 0; B = 192 at H = 1000, which the persistent forward does not take), then decode the
+    fixture's batch under the default modes from that cache - the ids must be the reference's (round-3 advisor finding: the
+    second call read torch.empty bytes as W_hh)."""
+    from s2vt_video_caption_amd import functional
+    g = golden("c2")
+    d, sd, feats, caps, mask = _setup(g, "c2")
+    f = feats.to(DEV)
+    f192 = torch.cat([f, f, f], 0)
+    m = _model(d, sd).eval()
+    keep = functional.DECODE_CACHE
+    mode0 = lib.s2vt_set_recurrence_mode(-1)
+    blk0 = lib.s2vt_set_pipeline_block(0)                           # (returns the previous block length)
+    lib.s2vt_set_pipeline_block(blk0)
+    try:
+        functional.DECODE_CACHE = True
+        for how in ("recurrence_mode_0", "pipeline_block_0", "B192"):
+            functional.clear_decode_cache()
+            with torch.no_grad():
+                if how == "recurrence_mode_0":
+                    lib.s2vt_set_recurrence_mode(0)
+                    first = m(f, mode="test").cpu().numpy()
+                    lib.s2vt_set_recurrence_mode(mode0)
+                elif how == "pipeline_block_0":
+                    lib.s2vt_set_pipeline_block(0)
+                    first = m(f, mode="test").cpu().numpy()
+                    lib.s2vt_set_pipeline_block(blk0)
+                else:
+                    first = m(f192, mode="test").cpu().numpy()[:d["B"]]
+                np.testing.assert_array_equal(first, g["greedy_ids"], err_msg=how)
+                key_before = functional._DECODE_CACHES[m][0]
+                second = m(f, mode="test").cpu().numpy()            # default modes, images from the cache filled above
+                assert functional._DECODE_CACHES[m][0] == key_before, "the second call must have used the cache"
+                np.testing.assert_array_equal(second, g["greedy_ids"], err_msg=how + " -> default")
+    finally:
+        lib.s2vt_set_recurrence_mode(mode0)
+        lib.s2vt_set_pipeline_block(blk0)
+        functional.DECODE_CACHE = keep
+        functional.clear_decode_cache()
+
+
 _BPTT_CHILD = r"""
 import json, sys
 sys.path.insert(0, %r)
