@@ -2427,6 +2427,12 @@ int s2vt_set_gemm_mode(int32_t mode) {
     return prev;
 }
 
+int s2vt_gemm_tune(int32_t nplanes, int32_t tile_rows, int32_t nsplit) {
+    S2VT_REQUIRE(nplanes == 1, "s2vt_gemm_tune: only the bf16 kernel (nplanes = 1) takes overrides");
+    gemm_b1_tune(tile_rows, nsplit);
+    return 0;
+}
+
 int s2vt_pipeline_overlaps(void) { return g_side_overlaps; }
 
 int s2vt_set_graph_mode(int32_t on) {

@@ -2,32 +2,35 @@
 // C[M,N] (+)= A[M,K] · B[N,K]^T (+ bias), both operands k-major ROWS of bf16 (element (r, k) at r*ld + k, K % 64 == 0) -
 // the layout the bf16 timestep kernels write, so no repacking pass sits between the recurrence and its batched GEMMs.
 //
-// 256x256 tile, k chunk 64 per stage: the stage image is [512 rows][128 B], filled by global_load_lds_dwordx4 with
-// one wave-instruction per 8 rows (8 lanes x 16 B = one full 128-B line per row).  An LDS-DMA writes lane-linear, so the
-// XOR swizzle that keeps the fragment reads conflict-free is applied to the per-lane SOURCE address instead: position p
-// of row r holds the row's 16-B piece p ^ ((r >> 1) & 7); a reader wanting piece q of row r reads position
-// q ^ ((r >> 1) & 7): the 16 rows of a ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) then take the 16 different
-// (row parity, (r >> 1) & 7) slots of the 256-B bank row.  (The first version XORed with r & 7: rows 12 and 20 of a group
-// met on one slot - PMC showed half of the kernel's LDS cycles as bank conflicts.)
-// Two stages (128 KB LDS, one workgroup per CU), one barrier per stage: after the barrier that opens stage s every wave
-// is done with stage s-1, whose slot takes the requests of stage s+1 while stage s is multiplied.  8 waves as 2x4,
-// wave tile 128x64: per k16 block 6 ds_read_b128 feed 8 v_mfma_f32_32x32x16_bf16; reads are inline asm with
-// hand-counted lgkmcnt, double-buffered by k16 block.
+// Workgroup tile (64 MI) x 256, MI = 2..5 (128 / 192 / 256 / 320 rows: the host picks the height whose tile count fills whole
+// rounds of the 256 compute units - 20480 x 1000 is 320 tiles of 256 rows = 1.25 rounds, but 256 tiles of 320 rows = one),
+// k chunk 64 per stage: the stage image is [64 MI + 256 rows][128 B], filled by buffer_load_dwordx4 ... lds with one
+// wave-instruction per 8 rows (8 lanes x 16 B = one full 128-B line per row).  An LDS-DMA writes lane-linear, so the XOR
+// swizzle that keeps the fragment reads conflict-free is applied to the per-lane SOURCE offset instead: position p of row r
+// holds the row's 16-B piece p ^ ((r >> 1) & 7); a reader wanting piece q of row r reads position q ^ ((r >> 1) & 7): the 16
+// rows of a ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...) then take the 16 different (row parity, (r >> 1) & 7) slots of
+// the 256-B bank row.  Operand rows are addressed through buffer descriptors whose range ends with the tile's last valid
+// row: lanes of rows past the operand's end are dropped by the range check (no clamping arithmetic, one 32-bit offset
+// register per request, the k position in a scalar offset); what such rows leave in LDS only reaches outputs that are never
+// stored.
+// Two stages (128-144 KB LDS, one workgroup per CU), one barrier per stage: after the barrier that opens stage s every wave
+// is done with stage s-1, whose slot takes the requests of stage s+1 while stage s is multiplied.  8 waves as 2x4, wave tile
+// (32 MI) x 64: per k16 block MI + 2 ds_read_b128 feed 2 MI v_mfma_f32_32x32x16_bf16; reads are inline asm with hand-counted
+// lgkmcnt, double-buffered by k16 block.
+// PERSISTENT: a launch is at most one workgroup per compute unit; each walks its share of the tiles (XCD-aware order: the
+// workgroups of one XCD work on neighbouring tiles that share operand panels in its L2) and the stage pipeline runs ON across
+// tiles - the last stage of a tile requests the first stage of the next one, so that transfer lands under the epilogue's
+// stores and no tile but the first pays a prologue.
 #include <stdlib.h>
 
 #include <type_traits>
 
 #include "common.h"
-#include "experiment.h"
 #include "kernels.h"
 
 namespace s2vt {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int BT = 256;                    // tile rows = tile cols
-constexpr int B_IMG = BT * 128;            // one operand image of a stage: 256 rows x 128 B
-constexpr int B_STAGE = 2 * B_IMG;         // A image + B image = 64 KB
 
 struct GemmB1Args {
     int M, N, K;                              // K: multiple of 64 (zero-padded rows)
@@ -36,63 +39,71 @@ struct GemmB1Args {
     float* C; int64_t ldc; RowMap cmap;
     const float* bias;
     int accumulate;
-    int ksplit;
+    int ksplit;                               // k extent of a split-K slice (blockIdx.y), multiple of 64
     float* slabs;
-    unsigned long long* stamps; int stamp_block;    // timing experiments only
+    int ntm, ntn;                             // tile grid of this launch's tile height
 };
 
-__device__ __forceinline__ void glds16b(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t b1_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
+template <int MI>
 __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * B_STAGE];
+    constexpr int TM = 64 * MI, ROWS = TM + 256, STAGE = ROWS * 128, IMG_A = TM * 128, NREQ = MI + 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int ntn = (p.N + BT - 1) / BT, ntm = (p.M + BT - 1) / BT;
-    const int nwg = ntm * ntn, cpx = (nwg + 7) >> 3;
-    const int t = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= cpx || t >= nwg) return;
-    constexpr int GM = 4;
-    const int gsz = GM * ntn, grp = t / gsz, first_m = grp * GM;
-    const int gm = (ntm - first_m < GM) ? (ntm - first_m) : GM;
-    const int tm = first_m + (t % gsz) % gm, tn = (t % gsz) / gm;
-    const int m0 = tm * BT, n0 = tn * BT;
+    // ---- this workgroup's share of the tiles: the XCD of blockIdx % 8 owns a contiguous chunk of the (grouped) tile order,
+    // its gridDim / 8 workgroups walk that chunk side by side
+    const int items = p.ntm * p.ntn;
+    const int cpx = (items + 7) >> 3, gx = (int)gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int q_end = ((xcd + 1) * cpx < items) ? (xcd + 1) * cpx : items;
+    int q = xcd * cpx + (int)(blockIdx.x >> 3);
+    if (q >= q_end) return;
     const int kbeg = blockIdx.y * p.ksplit;
     const int kend = (kbeg + p.ksplit < p.K) ? kbeg + p.ksplit : p.K;
-    const int nk = (kend - kbeg) >> 6;                 // k64 stages
+    const int nk = (kend - kbeg) >> 6;                 // k64 stages per tile
+    auto tile_of = [&](int t, int& m0, int& n0) {
+        constexpr int GM = 4;
+        const int gsz = GM * p.ntn, grp = t / gsz, first_m = grp * GM;
+        const int gm = (p.ntm - first_m < GM) ? (p.ntm - first_m) : GM;
+        m0 = (first_m + (t % gsz) % gm) * TM;
+        n0 = ((t % gsz) / gm) * 256;
+    };
 
-    // loader role: waves 0-3 fill the A image (64 rows each), waves 4-7 the B image; request j of a wave covers rows
-    // 8j..8j+7 of its 64: lane -> (row lane/8, position lane%8) <- piece (lane%8) ^ ((row >> 1) & 7); rows past the operand's
-    // end are clamped onto its last row (their outputs are never stored)
-    const unsigned char* src[8];
+    // ---- loader role: request j of wave w covers stage rows 8w + 64j .. + 7 (j < MI: A rows of the tile, else B rows
+    // 8w + 64(j - MI) ..): lane -> (row lane / 8, position lane % 8) <- piece (lane % 8) ^ ((row >> 1) & 7), and
+    // (row >> 1) & 7 = (4w + lane / 16) & 7 for every j
+    unsigned voa[MI], vob[4];
     {
-        const bool isA = wave < 4;
-        const int nrows = isA ? p.M : p.N, r0 = (isA ? m0 : n0) + (wave & 3) * 64 + (lane >> 3);
-        const unsigned short* base = isA ? p.A : p.B;
-        const int64_t ld = isA ? p.lda : p.ldb;
+        const unsigned piece = (unsigned)((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7));
+        const unsigned r = (unsigned)(8 * wave + (lane >> 3));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            int r = r0 + 8 * j;
-            r = r < nrows ? r : nrows - 1;
-            // tile row 8j + lane/8 of this wave's 64: (row >> 1) & 7 = (4j + lane/16) & 7
-            const int piece = (lane & 7) ^ ((4 * j + (lane >> 4)) & 7);
-            src[j] = reinterpret_cast<const unsigned char*>(base + (int64_t)r * ld + kbeg) + piece * 16;
-        }
+        for (int j = 0; j < MI; ++j) voa[j] = (r + 64u * j) * (unsigned)(p.lda * 2) + piece * 16u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vob[j] = (r + 64u * j) * (unsigned)(p.ldb * 2) + piece * 16u;
     }
-    unsigned char* const ldst = smem + (wave >> 2) * B_IMG + (wave & 3) * 64 * 128;     // + stage*B_STAGE + j*1024
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    auto rsrc_a = [&](int m0) {
+        const int rows = (p.M - m0 < TM) ? p.M - m0 : TM;
+        return b1_rsrc(p.A + (int64_t)m0 * p.lda + kbeg, (unsigned)((rows - 1) * (int)(p.lda * 2) + (kend - kbeg) * 2));
+    };
+    auto rsrc_b = [&](int n0) {
+        const int rows = (p.N - n0 < 256) ? p.N - n0 : 256;
+        return b1_rsrc(p.B + (int64_t)n0 * p.ldb + kbeg, (unsigned)((rows - 1) * (int)(p.ldb * 2) + (kend - kbeg) * 2));
+    };
+    // request j of a stage: source descriptors ra / rb at byte offset koff of the k range, into ring slot `slot`
+#define B1_REQ(J, RA, RB, KOFF, SLOT)                                                                                       \
+    if constexpr ((J) < NREQ) {                                                                                             \
+        auto* dst = (__attribute__((address_space(3))) void*)(smem + (SLOT) * STAGE + wave * 1024 + (J) * 8192);            \
+        if constexpr ((J) < MI) __builtin_amdgcn_raw_ptr_buffer_load_lds(RA, dst, 16, (int)voa[(J) < MI ? (J) : 0], KOFF, 0, 0); \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(RB, dst, 16, (int)vob[(J) >= MI ? (J) - MI : 0], KOFF, 0, 0);         \
+    }
 
     // fragment addresses: row r = tile row of lane ((r >> 1) & 7 == (li >> 1) & 7), k16 block c, half lh -> piece 2c+lh at
     // position (2c+lh) ^ s = (2c) ^ y with s = (li >> 1) & 7, y = lh ^ s
@@ -100,102 +111,220 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
     unsigned fa[4], fb[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        fa[c] = lbase + (unsigned)((wm * 128 + li) * 128 + (((2 * c) ^ y) * 16));
-        fb[c] = lbase + (unsigned)(B_IMG + (wn * 64 + li) * 128 + (((2 * c) ^ y) * 16));
+        fa[c] = lbase + (unsigned)((wm * 32 * MI + li) * 128 + (((2 * c) ^ y) * 16));
+        fb[c] = lbase + (unsigned)(IMG_A + (wn * 64 + li) * 128 + (((2 * c) ^ y) * 16));
     }
+
+    f32x16 acc[MI][2];
 
 #define B1_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF));
 #define B1_READ(FA, FB, C, SO)                                                                                        \
-    B1_RD(FA[0], fa[C] + (SO), 0) B1_RD(FA[1], fa[C] + (SO), 4096) B1_RD(FA[2], fa[C] + (SO), 8192)                    \
-    B1_RD(FA[3], fa[C] + (SO), 12288) B1_RD(FB[0], fb[C] + (SO), 0) B1_RD(FB[1], fb[C] + (SO), 4096)
-#define B1_WAIT(N, FA, FB) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(FA[0]), "+v"(FA[1]), "+v"(FA[2]), "+v"(FA[3]), \
-                                        "+v"(FB[0]), "+v"(FB[1]));
+    {                                                                                                                 \
+        const unsigned a_ = fa[C] + (SO), b_ = fb[C] + (SO);                                                          \
+        B1_RD(FA[0], a_, 0) B1_RD(FA[1], a_, 4096)                                                                    \
+        if constexpr (MI > 2) { B1_RD(FA[MI > 2 ? 2 : 0], a_, 8192) }                                                 \
+        if constexpr (MI > 3) { B1_RD(FA[MI > 3 ? 3 : 0], a_, 12288) }                                                \
+        if constexpr (MI > 4) { B1_RD(FA[MI > 4 ? 4 : 0], a_, 16384) }                                                \
+        B1_RD(FB[0], b_, 0) B1_RD(FB[1], b_, 4096)                                                                    \
+    }
+    // wait until at most N fragment reads are outstanding; the empty statements tie the fragments to the wait
+#define B1_WAIT(N, FA, FB)                                                                                            \
+    {                                                                                                                 \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_) asm volatile("" : "+v"(FA[i_]));                            \
+        asm volatile("" : "+v"(FB[0]));                                                                               \
+        asm volatile("" : "+v"(FB[1]));                                                                               \
+    }
 #define B1_PROD(FA, FB)                                                                                          \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)            \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)           \
         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[mi], FB[ni], acc[mi][ni], 0, 0, 0);
 #define B1_FENCE __builtin_amdgcn_sched_barrier(0);
 
-    // MORE: stage s+1 exists and is requested during stage s
-    const int xon = (p.stamps && (int)blockIdx.x == p.stamp_block && blockIdx.y == 0) ? 1 : 0;
-    auto stage = [&](int s, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
-        const int xrec = xon ? s : -1;
-        XSTAMP(p.stamps, xrec, 0);
-        // this wave's requests of stage s are the only ones outstanding; after the barrier all pieces of stage s are in
-        // and every wave has finished reading stage s-1 (its slot takes stage s+1)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        XSTAMP(p.stamps, xrec, 1);
+    // One k64 stage of the running pipeline (g counts stages across tiles: ring slot g & 1).  more (wave-uniform): a next
+    // stage exists - of this tile (ra / rb = its descriptors, koff = its byte offset) or the first of the workgroup's next
+    // tile - and is requested into the other slot while this one is multiplied.  wait_all = false: the stage follows an
+    // epilogue of >= 64 store instructions per wave, so "at most 63 operations outstanding" already says that the requests
+    // issued BEFORE those stores have landed (the counter retires in issue order) and the wave does not sit out its stores.
+    auto stage = [&](int g, auto more_tag, bool more_rt, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int koff, bool wait_all) {
+        const bool more = decltype(more_tag)::value || more_rt;       // (compile-time true inside a tile: no branch around the requests)
+        // this wave's requests of stage g are the only loads outstanding; after the barrier all pieces of stage g are in and
+        // every wave has finished reading stage g-1 (its slot takes stage g+1)
+        if (wait_all) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");
-        XSTAMP(p.stamps, xrec, 2);
-        const unsigned so = (unsigned)((s & 1) * B_STAGE);
-        unsigned char* l2 = ldst + ((s + 1) & 1) * B_STAGE;
-        const int64_t g2 = (int64_t)(s + 1) * 128;
-#define B1_REQ(J) if (MORE) glds16b(src[J] + g2, l2 + (J) * 1024);
-        bf16x8 ax[4], bx[2], ay[4], by[2];
+        const unsigned so = (unsigned)((g & 1) * STAGE);
+        const int ns = (g + 1) & 1;
+        bf16x8 ax[MI], bx[2], ay[MI], by[2];
+        // request set k of the next stage: waves 0-3 issue it BEHIND product group k, waves 4-7 (their SIMD partners) IN FRONT of
+        // it - while one wave of a SIMD spends ~100-150 cycles per request at the issue port, its partner feeds the matrix pipe
+        // (all eight waves behind the group: every shape of the config-3 step 4-6 % slower, profiles/round4_gemm_b1_shapes.txt)
+        const bool early = more && wave >= 4, late = more && wave < 4;
+#define B1_REQS(K) { B1_REQ(K, ra, rb, koff, ns) B1_REQ((K) + 4, ra, rb, koff, ns) if constexpr ((K) == 0) { B1_REQ(8, ra, rb, koff, ns) } }
         B1_FENCE
         B1_READ(ax, bx, 0, so) B1_READ(ay, by, 1, so)
-        B1_WAIT(6, ax, bx) XSTAMP(p.stamps, xrec, 3); B1_PROD(ax, bx) B1_REQ(0) B1_REQ(1) B1_FENCE
-        XSTAMP(p.stamps, xrec, 4);
+        if (early) B1_REQS(0)
+        B1_WAIT(MI + 2, ax, bx) B1_PROD(ax, bx)
+        if (late) B1_REQS(0)
+        B1_FENCE
         B1_READ(ax, bx, 2, so)
-        B1_WAIT(6, ay, by) B1_PROD(ay, by) B1_REQ(2) B1_REQ(3) B1_FENCE
-        XSTAMP(p.stamps, xrec, 5);
+        if (early) B1_REQS(1)
+        B1_WAIT(MI + 2, ay, by) B1_PROD(ay, by)
+        if (late) B1_REQS(1)
+        B1_FENCE
         B1_READ(ay, by, 3, so)
-        B1_WAIT(6, ax, bx) B1_PROD(ax, bx) B1_REQ(4) B1_REQ(5) B1_FENCE
-        XSTAMP(p.stamps, xrec, 6);
-        B1_WAIT(0, ay, by) B1_PROD(ay, by) B1_REQ(6) B1_REQ(7) B1_FENCE
-        XSTAMP(p.stamps, xrec, 7);
-#undef B1_REQ
+        if (early) B1_REQS(2)
+        B1_WAIT(MI + 2, ax, bx) B1_PROD(ax, bx)
+        if (late) B1_REQS(2)
+        B1_FENCE
+        if (early) B1_REQS(3)
+        B1_WAIT(0, ay, by) B1_PROD(ay, by)
+        if (late) B1_REQS(3)
+        B1_FENCE
+#undef B1_REQS
     };
-    {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) glds16b(src[j], ldst + j * 1024);
-        int s = 0;
-        for (; s + 1 < nk; ++s) stage(s, std::true_type{});
-        stage(s, std::false_type{});
+
+    int m0, n0;
+    tile_of(q, m0, n0);
+    __amdgpu_buffer_rsrc_t ra = rsrc_a(m0), rb = rsrc_b(n0);
+    {   // the launch's only prologue: stage 0 of the first tile
+        B1_REQ(0, ra, rb, 0, 0) B1_REQ(1, ra, rb, 0, 0) B1_REQ(2, ra, rb, 0, 0) B1_REQ(3, ra, rb, 0, 0) B1_REQ(4, ra, rb, 0, 0)
+        B1_REQ(5, ra, rb, 0, 0) B1_REQ(6, ra, rb, 0, 0) B1_REQ(7, ra, rb, 0, 0) B1_REQ(8, ra, rb, 0, 0)
     }
+    bool wait_all = true;
+    int s = 0;
+    int qn = q + gx;
+    int m1 = 0, n1 = 0;
+    if (qn < q_end) tile_of(qn, m1, n1);
+    __amdgpu_buffer_rsrc_t ra1 = rsrc_a(m1), rb1 = rsrc_b(n1);
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    for (int g = 0;; ++g) {             // the stages of all of this workgroup's tiles, one after the other
+        const bool has_next = qn < q_end;
+        for (; s + 1 < nk; ++s, ++g) {
+            stage(g, std::true_type{}, true, ra, rb, (s + 1) * 128, wait_all);
+            wait_all = true;
+        }
+        stage(g, std::false_type{}, has_next, ra1, rb1, 0, wait_all);      // the tile's last stage requests the next tile's first
+        wait_all = true;
+
+        // ---- epilogue (the next tile's first stage is in flight under these stores).  The 32x32 accumulator layout gives a
+        // lane ONE column and 16 rows; stored as it stands that is 32 MI dword store instructions per wave, and a tile's
+        // epilogue is bound by their issue (16 us of a 44-us tile at K = 1024: with a quarter of them, timing only, the K = 1000
+        // shapes ran 20-25 % faster).  So every 4x4 block (registers 4j..4j+3 x the lanes of a quad) is transposed inside the
+        // quad (DPP quad_perm, two butterfly rounds) and a lane stores FOUR consecutive columns of one row as 16 bytes: a wave
+        // instruction then writes 8 rows x 128 B, a quarter of the instructions for the same bytes.
+        const bool full_m = m0 + TM <= p.M;
+        {
+            // (the lane's coordinates are made opaque here: address arithmetic of the epilogue that does not depend on the tile
+            // would otherwise be hoisted out of the tile loop and held in registers across the stage pipeline)
+            int e_li = li, e_lh = lh;
+            asm volatile("" : "+v"(e_li), "+v"(e_lh));
+            const int t = e_li & 3;
+            const bool odd = t & 1, hi = t & 2;
+            const int ncol = n0 + wn * 64 + (e_li & ~3);                   // first of this lane's four columns (ni = 0)
+            const bool vec = p.slabs ? ((p.N & 3) == 0 && (reinterpret_cast<uintptr_t>(p.slabs) & 15) == 0)
+                                     : ((p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0);      // 16-byte rows
+            f32x4 bv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            if (p.bias && !p.slabs) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int n = ncol + ni * 32 + k;
+                        bv[ni][k] = n < p.N ? p.bias[n] : 0.f;
+                    }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + wm * 32 * MI + mi * 32 + 8 * j + 4 * e_lh + t;      // this lane's row after the transpose
+                    f32x4 v[2];
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        float a0 = acc[mi][ni][4 * j], a1 = acc[mi][ni][4 * j + 1], a2 = acc[mi][ni][4 * j + 2], a3 = acc[mi][ni][4 * j + 3];
+                        // round 1: lanes t <-> t ^ 1 exchange (a0, a1) and (a2, a3) crosswise; round 2: t <-> t ^ 2, (a0, a2) and (a1, a3)
+                        float s, r;
+                        s = odd ? a0 : a1; r = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));
+                        a0 = odd ? r : a0; a1 = odd ? a1 : r;
+                        s = odd ? a2 : a3; r = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));
+                        a2 = odd ? r : a2; a3 = odd ? a3 : r;
+                        s = hi ? a0 : a2; r = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, false));
+                        a0 = hi ? r : a0; a2 = hi ? a2 : r;
+                        s = hi ? a1 : a3; r = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, false));
+                        a1 = hi ? r : a1; a3 = hi ? a3 : r;
+                        v[ni] = f32x4{a0, a1, a2, a3};
+                    }
+                    if (m >= p.M) continue;
+                    float* row = p.slabs ? p.slabs + ((int64_t)blockIdx.y * p.M + m) * p.N : p.C + (int64_t)map_row(p.cmap, m) * p.ldc;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const int n = ncol + ni * 32;
+                        f32x4 o = v[ni];
+                        if (!p.slabs) { o[0] += bv[ni][0]; o[1] += bv[ni][1]; o[2] += bv[ni][2]; o[3] += bv[ni][3]; }
+                        if (vec && n + 4 <= p.N) {
+                            f32x4* q4 = reinterpret_cast<f32x4*>(row + n);
+                            if (p.accumulate && !p.slabs) { const f32x4 c = *q4; o[0] += c[0]; o[1] += c[1]; o[2] += c[2]; o[3] += c[3]; }
+                            *q4 = o;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (n + k < p.N) {
+                                    float x = o[k];
+                                    if (p.accumulate && !p.slabs) x += row[n + k];
+                                    row[n + k] = x;
+                                }
+                        }
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        // (the epilogue issues 8 MI = 16-40 store instructions per wave: fewer than the 63 the counted wait would need to tell the
+        // requests apart from the stores behind them, so the first stage of the next tile waits for everything - by then the
+        // stores have had the whole epilogue's issue time to retire)
+        wait_all = true;
+        (void)full_m;
+        q = qn; m0 = m1; n0 = n1; ra = ra1; rb = rb1;
+        qn = q + gx;
+        if (qn < q_end) tile_of(qn, m1, n1);
+        ra1 = rsrc_a(m1); rb1 = rsrc_b(n1);
+        s = 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    }
+#undef B1_REQ
 #undef B1_RD
 #undef B1_READ
 #undef B1_WAIT
 #undef B1_PROD
 #undef B1_FENCE
-
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m >= p.M) continue;
-            if (p.slabs) {
-                float* srow = p.slabs + ((int64_t)blockIdx.y * p.M + m) * p.N;
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int n = n0 + wn * 64 + ni * 32 + li;
-                    if (n < p.N) srow[n] = acc[mi][ni][r];
-                }
-                continue;
-            }
-            float* crow = p.C + (int64_t)map_row(p.cmap, m) * p.ldc;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int n = n0 + wn * 64 + ni * 32 + li;
-                if (n >= p.N) continue;
-                float v = acc[mi][ni][r];
-                if (p.bias) v += p.bias[n];
-                if (p.accumulate) v += crow[n];
-                crow[n] = v;
-            }
-        }
-    }
 }
 
 int splitk_reduce(hipStream_t stream, const float* slabs, int nsplit, int M, int N, float* C, int64_t ldc, RowMap cmap,
                   const float* bias, bool accumulate);
 
-#ifdef S2VT_EXPERIMENT_STAMPS
-static unsigned long long* g_b1_stamps = nullptr;
-static int g_b1_block = 0;
-extern "C" int s2vt_experiment_set_b1_stamps(unsigned long long* buf, int block) { g_b1_stamps = buf; g_b1_block = block; return 0; }
-#endif
+// Per-tile cost model (us) of the launcher: a k64 stage of a (64 MI) x 256 tile and the tile's epilogue, measured with
+// tools/bench_gemm_shapes.py under S2VT_B1_MI (the stage is co-limited by the matrix pipes and by the ~65 GB/s a compute unit
+// takes in from L2: a 128-row tile moves 3/4 of the bytes of a 256-row tile for half of its products)
+static const double kB1Stage[6] = {0, 0, 1.15, 1.50, 1.70, 2.25};
+static const double kB1Epi[6] = {0, 0, 4.5, 6.0, 8.0, 10.0};
+
+static int g_b1_force_mi = -1, g_b1_force_n = -1;
+void gemm_b1_tune(int tile_rows, int nsplit) {
+    g_b1_force_mi = (tile_rows >= 128 && tile_rows <= 320 && tile_rows % 64 == 0) ? tile_rows / 64 : 0;
+    g_b1_force_n = nsplit > 0 ? nsplit : 0;
+}
+
 int gemm_b1(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
             int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
             size_t splitk_ws_floats) {
@@ -203,34 +332,66 @@ int gemm_b1(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
     S2VT_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K &&
                      (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0,
                  "gemm_b1: K must be the zero-padded multiple of 64 of the bf16 rows, rows 16-B aligned");
+    S2VT_REQUIRE(lda < (1 << 21) && ldb < (1 << 21), "gemm_b1: row stride beyond the 32-bit offsets of a 320-row tile");
     GemmB1Args p;
     p.M = M; p.N = N; p.K = K;
     p.A = A; p.lda = lda;
     p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.cmap = cmap; p.bias = bias; p.accumulate = accumulate ? 1 : 0;
-    p.stamps = nullptr; p.stamp_block = -1;
-#ifdef S2VT_EXPERIMENT_STAMPS
-    p.stamps = g_b1_stamps; p.stamp_block = g_b1_block;
-#endif
-    const int tiles = cdiv(M, BT) * cdiv(N, BT);
-    // split K by the same kind of time model as gemm_x3 (one sixth of its MFMA work per k unit)
-    int nsplit = 1;
-    if (splitk_ws && K >= 512) {
-        double best = 1e30;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        (void)hipGetLastError();
+        ncu = n / 8 * 8;
+    }
+    // S2VT_B1_MI=2..5 / S2VT_B1_NSPLIT=n or s2vt_gemm_tune(): overrides of the time model (kernel tests run every tile height,
+    // tools/bench_gemm_shapes.py calibrates the model with them)
+    if (g_b1_force_mi < 0) { const char* e = getenv("S2VT_B1_MI"); g_b1_force_mi = e ? atoi(e) : 0; }
+    if (g_b1_force_n < 0) { const char* e = getenv("S2VT_B1_NSPLIT"); g_b1_force_n = e ? atoi(e) : 0; }
+    const int force_mi = g_b1_force_mi, force_n = g_b1_force_n;
+    // tile height, split-K factor and grid by the time model: every workgroup walks ceil(its XCD's chunk / workgroups of the
+    // XCD) tiles of nk stages + an epilogue; split-K adds the fixed-order slab combine ((n + 1) passes over M x N floats at
+    // ~3.5 TB/s + a launch)
+    const int ntn = cdiv(N, 256);
+    int best_mi = 4, best_ns = 1, best_g = 8;
+    double best = 1e30;
+    static const int order[4] = {4, 5, 3, 2};
+    for (int oi = 0; oi < 4; ++oi) {
+        const int mi = order[oi];
+        if (force_mi && force_mi != mi) continue;
+        const int tiles = cdiv(M, 64 * mi) * ntn;
         for (int n = 1; n <= 16; ++n) {
-            if (n > 1 && (K / n < 256 || (size_t)n * M * N > splitk_ws_floats)) break;
+            if (n > 1 && (!splitk_ws || K < 512 || K / n < 256 || (size_t)n * M * N > splitk_ws_floats)) break;
+            if (force_n && n != force_n) continue;
             const int ks = cdiv(cdiv(K, n), 64) * 64, nn = cdiv(K, ks);
             if (nn != n) continue;
-            const double rounds = (double)cdiv(tiles * nn, 256);
-            const double t = rounds * (ks * 0.035 + 6.0) + (nn > 1 ? (nn + 1.0) * M * (double)N * 4.0 / 3.5e6 + 8.0 : 0.0);
-            if (t < best * 0.97) { best = t; nsplit = nn; }
+            int g = ncu / nn / 8 * 8;
+            if (g < 8) g = 8;
+            if (g > cdiv(tiles, 8) * 8) g = cdiv(tiles, 8) * 8;
+            const int per_wg = cdiv(cdiv(tiles, 8), g / 8);
+            const double rounds = (double)cdiv(g * nn, ncu);           // (more workgroups than compute units: they queue)
+            const double t = rounds * per_wg * ((ks / 64) * kB1Stage[mi] + kB1Epi[mi]) + 3.0 +
+                             (nn > 1 ? (nn + 1.0) * M * (double)N * 4.0 / 3.5e6 + 8.0 : 0.0);
+            if (t < best * 0.98) { best = t; best_mi = mi; best_ns = nn; best_g = g; }
         }
     }
-    p.ksplit = (nsplit > 1) ? cdiv(cdiv(K, nsplit), 64) * 64 : K;
-    if (nsplit > 1) nsplit = cdiv(K, p.ksplit);
+    if (best > 1e29) {      // (an override that no candidate met: one slice of 256-row tiles)
+        best_mi = 4; best_ns = 1;
+        best_g = cdiv(cdiv(M, 256) * ntn, 8) * 8;
+        if (best_g > ncu) best_g = ncu;
+    }
+    p.ntm = cdiv(M, 64 * best_mi); p.ntn = ntn;
+    p.ksplit = (best_ns > 1) ? cdiv(cdiv(K, best_ns), 64) * 64 : K;
+    const int nsplit = (best_ns > 1) ? cdiv(K, p.ksplit) : 1;
     p.slabs = (nsplit > 1) ? splitk_ws : nullptr;
-    const dim3 grid(cdiv(tiles, 8) * 8, nsplit);
-    hipLaunchKernelGGL(gemm_b1_kernel, grid, dim3(512), 0, stream, p);
+    const dim3 grid(best_g, nsplit);
+    switch (best_mi) {
+        case 2: hipLaunchKernelGGL(gemm_b1_kernel<2>, grid, dim3(512), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL(gemm_b1_kernel<3>, grid, dim3(512), 0, stream, p); break;
+        case 5: hipLaunchKernelGGL(gemm_b1_kernel<5>, grid, dim3(512), 0, stream, p); break;
+        default: hipLaunchKernelGGL(gemm_b1_kernel<4>, grid, dim3(512), 0, stream, p); break;
+    }
     S2VT_LAUNCH_CHECK("gemm_b1_kernel");
     if (nsplit > 1) return splitk_reduce(stream, splitk_ws, nsplit, M, N, C, ldc, cmap, bias, accumulate);
     return 0;

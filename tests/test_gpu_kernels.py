@@ -101,6 +101,37 @@ def test_plain_bf16_gemm_rows(lib, M, N, K):
     assert torch.equal(goti, ai @ bi.t())
 
 
+
+@pytest.mark.parametrize("tile_rows", [128, 192, 256, 320])
+def test_plain_bf16_gemm_every_tile_height_persistent(lib, tile_rows):
+    """gemm_b1_kernel<MI> for every tile height, as a PERSISTENT launch (more tiles than compute units: a workgroup walks
+    several, its stage pipeline running on across them), with ragged M / N, a gathered / permuted C row map, bias, split-K -
+    and with NaNs planted in the operand rows beyond M and N (the padding rows of the plane buffers, which the tiles' loads
+    do touch): nothing of them may reach the output.  Integer operands: exact."""
+    from s2vt_video_caption_amd import capi, ops
+    lib.s2vt_gemm_tune(1, tile_rows, 0)
+    try:
+        for (M, N, K, ns) in ((6001, 2900, 192, 0), (4100, 1000, 2048, 3), (333, 77, 64, 0), (20480 // 4, 1000, 512, 0)):
+            lib.s2vt_gemm_tune(1, tile_rows, ns)
+            g = torch.Generator().manual_seed(M + N + tile_rows)
+            ai = torch.randint(-4, 5, (M, K), generator=g).float()
+            bi = torch.randint(-4, 5, (N, K), generator=g).float()
+            bias = torch.randint(-8, 9, (N,), generator=g).float()
+            pa, pb = ops.split_planes(ai.to(DEV), 1), ops.split_planes(bi.to(DEV), 1)
+            pa[0][M:].fill_(0x7FC0)                                  # bf16 NaN in every padding row
+            pb[0][N:].fill_(0x7FC0)
+            ws = torch.empty(4 * M * N + 1, device=DEV)
+            got = ops.gemm_planes(pa, pb, M, N, nplanes=1, bias=bias.to(DEV), splitk_ws=ws).cpu()
+            assert torch.equal(got, ai @ bi.t() + bias), (M, N, K, ns)
+            c0 = torch.randint(-8, 9, (M, N), generator=g).float()
+            out = c0.to(DEV).clone()
+            ops.gemm_planes(pa, pb, M, N, nplanes=1, out=out, accumulate=True, splitk_ws=ws)
+            assert torch.equal(out.cpu(), ai @ bi.t() + c0), (M, N, K, ns, "accumulate")
+        capi.check_async_error()
+    finally:
+        lib.s2vt_gemm_tune(1, 0, 0)
+
+
 def test_split_precision_gemm_mixed_tile_heights(lib):
     """gx1 of config 2 (5120 x 4000 x 1000): 320 tiles of 256 rows would be two rounds of the chip with the second a quarter
     full, so the launcher runs 16 row tiles of 256 rows and the last 1024 rows as 128-row tiles (two launches, gemm_x3.hip):
