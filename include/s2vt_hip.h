@@ -198,9 +198,9 @@ int s2vt_gemm_bf16_nt(int32_t nplanes, int32_t M, int32_t N, int32_t K, const ui
                       int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t accumulate, float* ws,
                       size_t ws_floats, void* stream);
 
-/* Test / calibration hook of s2vt_gemm_bf16_nt(nplanes = 1): force the workgroup tile height (128, 192, 256 or 320 rows; 0 = the
- * launcher's time model picks the height whose tile count fills whole rounds of the compute units) and the split-K factor
- * (0 = model).  Results do not depend on the tile height beyond the order of the fp32 sums along k, which it does not change
+/* Test / calibration hook of s2vt_gemm_bf16_nt: force the workgroup tile height (nplanes = 1: 128, 192, 256 or 320 rows; nplanes = 3:
+ * 128, 192 or 256; 0 = the launcher's time model picks the height whose tile count fills whole rounds of the compute units) and
+ * the split-K factor (0 = model).  Results do not depend on the tile height beyond the order of the fp32 sums along k, which it does not change
  * either (split-K does). */
 int s2vt_gemm_tune(int32_t nplanes, int32_t tile_rows, int32_t nsplit);
 

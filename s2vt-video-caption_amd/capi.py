@@ -9,7 +9,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libs2vt_hip.so")
+# S2VT_LIB: another build of the library (A/B timing of two builds on one GPU box: tools/bench_gemm_shapes.py); never set in production
+LIB_PATH = os.environ.get("S2VT_LIB") or os.path.join(_HERE, "libs2vt_hip.so")
 
 
 class Dims(ctypes.Structure):

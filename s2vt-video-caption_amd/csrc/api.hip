@@ -2428,8 +2428,9 @@ int s2vt_set_gemm_mode(int32_t mode) {
 }
 
 int s2vt_gemm_tune(int32_t nplanes, int32_t tile_rows, int32_t nsplit) {
-    S2VT_REQUIRE(nplanes == 1, "s2vt_gemm_tune: only the bf16 kernel (nplanes = 1) takes overrides");
-    gemm_b1_tune(tile_rows, nsplit);
+    S2VT_REQUIRE(nplanes == 1 || nplanes == 3, "s2vt_gemm_tune: nplanes must be 1 (bf16 kernel) or 3 (split-precision kernel)");
+    if (nplanes == 1) gemm_b1_tune(tile_rows, nsplit);
+    else gemm_x3_tune(tile_rows, nsplit);
     return 0;
 }
 

@@ -143,14 +143,14 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
     // One k64 stage of the running pipeline (g counts stages across tiles: ring slot g & 1).  more (wave-uniform): a next
     // stage exists - of this tile (ra / rb = its descriptors, koff = its byte offset) or the first of the workgroup's next
     // tile - and is requested into the other slot while this one is multiplied.  wait_all = false: the stage follows an
-    // epilogue of >= 64 store instructions per wave, so "at most 63 operations outstanding" already says that the requests
-    // issued BEFORE those stores have landed (the counter retires in issue order) and the wave does not sit out its stores.
+    // epilogue of >= 8 MI store instructions of this wave, so "at most 8 MI operations outstanding" already says that the
+    // requests issued BEFORE those stores have landed (the counter retires in issue order): the wave does not sit out its stores.
     auto stage = [&](int g, auto more_tag, bool more_rt, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int koff, bool wait_all) {
         const bool more = decltype(more_tag)::value || more_rt;       // (compile-time true inside a tile: no branch around the requests)
         // this wave's requests of stage g are the only loads outstanding; after the barrier all pieces of stage g are in and
         // every wave has finished reading stage g-1 (its slot takes stage g+1)
         if (wait_all) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(63) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 * MI) : "memory");
         asm volatile("s_barrier" ::: "memory");
         const unsigned so = (unsigned)((g & 1) * STAGE);
         const int ns = (g + 1) & 1;
@@ -285,11 +285,10 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
             }
         }
         if (!has_next) break;
-        // (the epilogue issues 8 MI = 16-40 store instructions per wave: fewer than the 63 the counted wait would need to tell the
-        // requests apart from the stores behind them, so the first stage of the next tile waits for everything - by then the
-        // stores have had the whole epilogue's issue time to retire)
-        wait_all = true;
-        (void)full_m;
+        // at least 8 MI vector-memory instructions followed the requests of the next tile's first stage when all rows are valid and
+        // both column groups of the wave lie inside N: "at most 8 MI operations outstanding" then says those requests have landed
+        // (the counter retires in issue order) without sitting out the stores
+        wait_all = !(full_m && n0 + wn * 64 + 64 <= p.N);
         q = qn; m0 = m1; n0 = n1; ra = ra1; rb = rb1;
         qn = q + gx;
         if (qn < q_end) tile_of(qn, m1, n1);

@@ -5,14 +5,18 @@
 //   element (r, k, plane pl) at  (r/64)*(64*ld) + (k/16)*3072 + (pl*2 + (k%16)/8)*512 + (r%64)*8 + k%8   [bf16 units]
 // i.e. for every 64-row block and every 16-wide k chunk a contiguous 6 KB record of six 1-KB "pieces"; piece
 // (pl, half) holds, for the 64 rows in order, the 16 bytes the 32x32x16 MFMA wants from lane (row, half).  One
-// global_load_lds_dwordx4 wave-instruction moves one piece (64 lanes x 16 B, contiguous in HBM and in LDS), so the
-// tile is staged without touching a VGPR, without ds_write instructions and without any address arithmetic beyond a
-// running pointer; fragment reads are 512-B contiguous per half-wave (conflict-free, no padding, no swizzle).
+// LDS-DMA wave-instruction moves one piece (64 lanes x 16 B, contiguous in HBM and in LDS), so the tile is staged without
+// touching a VGPR, without ds_write instructions and without address arithmetic: a record is addressed through a buffer
+// descriptor of its row block, the piece and the k chunk through the instruction's SCALAR offset; fragment reads are 512-B
+// contiguous per half-wave (conflict-free, no padding, no swizzle).
 //
-// Tile 256x256, k chunk 16 per stage (48 KB), 3-stage ring (144 KB of the 160-KB LDS, one workgroup per CU), 8 waves
-// as 2(M) x 4(N), wave tile 128x64 = 4x2 MFMA tiles -> 18 ds_read_b128 feed 48 MFMAs per stage (0.375 reads per MFMA;
-// the 128x128 / 64x64-per-wave form needs 0.5 and its LDS pipe was the limiter).  Stage s+2 is requested right
-// after the barrier that opens stage s and stays in flight across the next barrier (counted vmcnt, raw s_barrier).
+// Tile (64 MI) x 256, MI = 2..4 (the host picks the height whose tile count fills the compute units best), k chunk 16 per
+// stage ((MI + 4) records of 6 KB), 3-stage ring (up to 144 KB of the 160-KB LDS, one workgroup per CU), 8 waves as 2(M) x
+// 4(N), wave tile (32 MI) x 64 -> 3 (MI + 2) ds_read_b128 feed 12 MI MFMAs per stage.  Stage s+2 is requested while stage s
+// is multiplied and stays in flight across the next barrier (counted vmcnt, raw s_barrier).
+// PERSISTENT: a launch is at most one workgroup per compute unit; each walks its share of the tiles (XCD-aware order) and
+// the ring runs ON across tiles - the last two stages of a tile request the first two of the next one, so no tile but the
+// first pays a prologue and the transfers land under the epilogue's stores.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -24,7 +28,6 @@ namespace s2vt {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int XT = 256;                    // tile rows = tile cols
 constexpr int X_REC = 6144;                // bytes of one (64-row block, k16 chunk) record: 6 pieces x 1 KB
 constexpr int X_NS = 3;                    // ring depth
 
@@ -37,163 +40,271 @@ struct GemmX3Args {
     int accumulate;
     int ksplit;
     float* slabs;
-    int m_base, m_tiles;                      // this launch covers m_tiles row tiles from row m_base (m_tiles == 0: all of M)
+    int ntm, ntn;                             // tile grid of this launch's tile height
 };
 
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+// 4x4 transpose inside every quad of lanes: lane t of a quad holds (a0..a3) = column t of a 4x4 block whose rows are the four
+// registers; afterwards it holds row t (two butterfly rounds of DPP quad_perm exchanges)
+__device__ __forceinline__ void quad_transpose4(float& a0, float& a1, float& a2, float& a3, bool odd, bool hi) {
+    float s, r;
+    s = odd ? a0 : a1; r = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));
+    a0 = odd ? r : a0; a1 = odd ? a1 : r;
+    s = odd ? a2 : a3; r = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0xB1, 0xF, 0xF, false));
+    a2 = odd ? r : a2; a3 = odd ? a3 : r;
+    s = hi ? a0 : a2; r = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, false));
+    a0 = hi ? r : a0; a2 = hi ? a2 : r;
+    s = hi ? a1 : a3; r = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), 0x4E, 0xF, 0xF, false));
+    a1 = hi ? r : a1; a3 = hi ? a3 : r;
 }
 
-// MI = 32-row MFMA tiles per wave in M: 4 -> 256x256 workgroup tile (wave tile 128x64), 2 -> 128x256 (wave tile 64x64:
-// twice the tiles for grids that would otherwise leave CUs idle or need split-K; 12 reads per 24 MFMAs instead of 18
-// per 48).  The A operand fills MI 64-row records of a stage, the B operand always four.
+// MI = 32-row MFMA tiles per wave in M: workgroup tile (64 MI) x 256, wave tile (32 MI) x 64.  The A operand fills MI 64-row
+// records of a stage, the B operand always four.
 template <int MI>
 __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
     constexpr int NRA = MI, TMR = 64 * MI, X_STAGE = (NRA + 4) * X_REC;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[X_NS * X_STAGE];
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 31, lh = lane >> 5;
 
-    const int ntn = (p.N + XT - 1) / XT, ntm = p.m_tiles ? p.m_tiles : (p.M + TMR - 1) / TMR;
-    const int nwg = ntm * ntn, cpx = (nwg + 7) >> 3;
-    const int t = (blockIdx.x & 7) * cpx + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= cpx || t >= nwg) return;
-    constexpr int GM = 4;
-    const int gsz = GM * ntn, grp = t / gsz, first_m = grp * GM;
-    const int gm = (ntm - first_m < GM) ? (ntm - first_m) : GM;
-    const int tm = first_m + (t % gsz) % gm, tn = (t % gsz) / gm;
-    const int m0 = p.m_base + tm * TMR, n0 = tn * XT;
+    // ---- this workgroup's share of the tiles (as gemm_b1_kernel): the XCD of blockIdx % 8 owns a contiguous chunk of the
+    // grouped tile order, its gridDim / 8 workgroups walk that chunk side by side
+    const int items = p.ntm * p.ntn;
+    const int cpx = (items + 7) >> 3, gx = (int)gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int q_end = ((xcd + 1) * cpx < items) ? (xcd + 1) * cpx : items;
+    int q = xcd * cpx + (int)(blockIdx.x >> 3);
+    if (q >= q_end) return;
     const int kbeg = blockIdx.y * p.ksplit;
     const int kend = (kbeg + p.ksplit < p.K) ? kbeg + p.ksplit : p.K;
-    const int nk = (kend - kbeg) >> 4;                 // k16 stages
+    const int nk = (kend - kbeg) >> 4;                 // k16 stages per tile (a multiple of 4)
+    auto tile_of = [&](int t, int& m0, int& n0) {
+        constexpr int GM = 4;
+        const int gsz = GM * p.ntn, grp = t / gsz, first_m = grp * GM;
+        const int gm = (p.ntm - first_m < GM) ? (p.ntm - first_m) : GM;
+        m0 = (first_m + (t % gsz) % gm) * TMR;
+        n0 = ((t % gsz) / gm) * 256;
+    };
 
-    // loader role: waves 0..NRA-1 stream the A row-blocks of the tile, the next four waves the B row-blocks (wave index
-    // = record index inside a stage; with MI = 2 waves 6 and 7 load nothing); a row-block past the operand's last one
-    // is clamped onto it (its outputs are never stored)
-    const bool loader = (NRA + 4 == 8) || wave < NRA + 4;      // compile-time true at MI = 4
-    const unsigned char* src;
-    {
+    // ---- loader role: waves 0..NRA-1 stream the A row-blocks of the tile, the next four waves the B row-blocks (wave index
+    // = record index inside a stage; with MI < 4 the last waves load nothing); a row-block past the operand's last one is
+    // clamped onto it (its outputs are never stored).  Descriptor = the record stream of this wave's row block over the k
+    // range; a request = (descriptor, lane * 16, scalar offset of stage and piece)
+    const bool loader = wave < NRA + 4;
+    auto rsrc_of = [&](int m0, int n0) {
         const bool isA = wave < NRA;
         const int nrb = ((isA ? p.M : p.N) + 63) >> 6;
         int rb = isA ? (m0 >> 6) + wave : (n0 >> 6) + (wave - NRA);
-        rb = rb < 0 ? 0 : rb;
         rb = rb < nrb ? rb : nrb - 1;
         const unsigned short* base = isA ? p.A : p.B;
         const int64_t ld = isA ? p.lda : p.ldb;
-        src = reinterpret_cast<const unsigned char*>(base + (int64_t)rb * 64 * ld) + (int64_t)(kbeg >> 4) * X_REC + lane * 16;
-    }
-    unsigned char* const ldst = smem + wave * X_REC;   // + stage * X_STAGE + piece * 1024 (+ lane * 16 by the DMA)
-    auto request = [&](int s) {                        // stage s of this tile's k range -> ring slot s % 3
-        const unsigned char* g = src + (int64_t)s * X_REC;
-        unsigned char* l = ldst + (s % X_NS) * X_STAGE;
-        if (!loader) return;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) glds16(g + j * 1024, l + j * 1024);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base + (int64_t)rb * 64 * ld + (int64_t)(kbeg >> 4) * (X_REC / 2)), 0,
+                                                 nk * X_REC, 0x00020000);
     };
+    const int vlane = lane * 16;
+    // piece J of stage `st` (of the tile behind descriptor R) -> ring slot SLOT
+#define X3_REQ1(J, R, ST, SLOT)                                                                                           \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(R, (__attribute__((address_space(3))) void*)(smem + (SLOT) * X_STAGE + wave * X_REC + (J) * 1024), \
+                                             16, vlane, (ST) * X_REC + (J) * 1024, 0, 0);
 
     f32x16 acc[MI][2];
+
+    // fragment addresses inside a stage: 32-row tile x = wm MI + mi of the workgroup tile sits in A record x / 2, rows
+    // (x & 1) * 32 + li; B record NRA + wn, rows ni * 32 + li
+    unsigned la[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int x = wm * MI + mi;
+        la[mi] = lbase + (unsigned)((x >> 1) * X_REC + (x & 1) * 512 + lh * 1024 + li * 16);
+    }
+    const unsigned lb = lbase + (unsigned)((NRA + wn) * X_REC + lh * 1024 + li * 16);
+
+    // One k16 stage of the running ring (g counts stages across tiles: slot g % 3).  more: stage g + 2 exists - of this tile or
+    // of the workgroup's next one (descriptor r2, stage index s2 there) - and is requested while this one is multiplied;
+    // nwait = how many of this wave's youngest vector-memory operations may still be outstanding when stage g must have landed
+    // (the 6 requests of stage g + 1, plus the store instructions of an epilogue issued between them and now)
+    auto stage = [&](int g, auto more_tag, bool more_rt, __amdgpu_buffer_rsrc_t r2, int s2, int nwait) {
+        const bool more = decltype(more_tag)::value || more_rt;       // (compile-time true inside a tile: no branch around the requests)
+        if (nwait == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else if (nwait == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(6 + 8 * MI) : "memory");
+        const int slot = g % X_NS, slot2 = (g + 2) % X_NS;
+        const unsigned so = (unsigned)(slot * X_STAGE);
+        bf16x8 a[3][MI], b[3][2];
+        // Fragment reads are issued in the order the products consume them - (a1 b1) (a0 b2) (a2 b0) - as inline asm
+        // with hand-counted lgkmcnt waits: all 8 waves read right after the barrier, so the last read of a wave returns
+        // ~1150 cycles later (144 KB through a 128 B/clk LDS) but its first third after ~400; hipcc would wait for all of them
+        // before the first MFMA (lgkmcnt(0)), the counted waits start each product group when ITS operands are in.
+        // (LDS returns in order; nothing else in the loop uses lgkmcnt.)
+#define X3_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF));
+#define X3_LDA(PL) _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) { X3_RD(a[PL][mi], la[mi] + so, (PL) * 2048) }
+#define X3_LDB(PL) { const unsigned b_ = lb + so; X3_RD(b[PL][0], b_, (PL) * 2048) X3_RD(b[PL][1], b_, (PL) * 2048 + 512) }
+        // wait until at most N reads are outstanding; the empty statements tie the fragments to the wait
+#define X3_WAIT(N, PA, PB)                                                                                     \
+    {                                                                                                          \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < MI; ++i_) asm volatile("" : "+v"(a[PA][i_]));                  \
+        asm volatile("" : "+v"(b[PB][0]));                                                                     \
+        asm volatile("" : "+v"(b[PB][1]));                                                                     \
+    }
+        __builtin_amdgcn_sched_barrier(0);
+        X3_LDA(1) X3_LDB(1) X3_LDA(0) X3_LDB(2) X3_LDA(2) X3_LDB(0)
+        // six plane products, smallest terms first; product-major order keeps 2 MI independent MFMAs between two updates of the
+        // same accumulator.  The DMA requests of stage g + 2 are spread over the MFMA groups: issuing one costs the wave ~100
+        // cycles, which a running MFMA group of its SIMD partner hides (the partner-staggered issue that gemm_b1_kernel uses -
+        // waves 4-7 in front of a group, waves 0-3 behind it - measured neutral here, 4.047 vs 4.044 ms over the 14 shapes: one
+        // request per 8 MI MFMAs is not what this kernel waits for)
+#define X3_PROD(PA, PB)                                                                                          \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)           \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][mi], b[PB][ni], acc[mi][ni], 0, 0, 0);
+        const bool req = more && loader;
+#define X3_GROUP(N, PA, PB, J, DOWAIT)                                     \
+    if constexpr (DOWAIT) { X3_WAIT(N, PA, PB) }                           \
+    X3_PROD(PA, PB)                                                        \
+    if (req) { X3_REQ1(J, r2, s2, slot2) }                                 \
+    __builtin_amdgcn_sched_barrier(0);
+        X3_GROUP(2 * (MI + 2), 1, 1, 0, true)
+        X3_GROUP(MI + 2, 0, 2, 1, true)
+        X3_GROUP(0, 2, 0, 2, true)
+        X3_GROUP(0, 0, 1, 3, false)
+        X3_GROUP(0, 1, 0, 4, false)
+        X3_GROUP(0, 0, 0, 5, false)
+#undef X3_GROUP
+#undef X3_PROD
+#undef X3_WAIT
+#undef X3_RD
+#undef X3_LDA
+#undef X3_LDB
+    };
+
+    int m0, n0;
+    tile_of(q, m0, n0);
+    __amdgpu_buffer_rsrc_t r0 = rsrc_of(m0, n0);
+    if (loader) {   // the launch's only prologue: stages 0 and 1 of the first tile
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { X3_REQ1(j, r0, 0, 0) }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { X3_REQ1(j, r0, 1, 1) }
+    }
+    int s = 0;
+    int qn = q + gx;
+    int m1 = 0, n1 = 0;
+    if (qn < q_end) tile_of(qn, m1, n1);
+    __amdgpu_buffer_rsrc_t r1 = rsrc_of(m1, n1);
+    int nwait = 6;
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    // fragment addresses inside a stage: wave row wm covers tile rows [wm*32*MI, +32*MI): A record wm*MI/2 + mi/2, row
-    // (mi&1)*32 + li; B record NRA + wn, row ni*32 + li
-    const int a_off = (wm * (MI / 2)) * X_REC + lh * 1024 + li * 16;
-    const int b_off = (NRA + wn) * X_REC + lh * 1024 + li * 16;
-
-    // One k16 stage.  MORE (compile time): stage s+2 exists and is requested during this stage.
-    auto stage = [&](int s, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value;
-        // stage s has landed for this wave once at most the 6 requests of stage s+1 are outstanding; the barrier makes
-        // that true for every wave's pieces and also says everyone is done reading slot (s+2)%3 (= stage s-1)
-        if (MORE || s + 1 < nk) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const unsigned char* g2 = src + (int64_t)(s + 2) * X_REC;
-        unsigned char* l2 = ldst + ((s + 2) % X_NS) * X_STAGE;
-        const unsigned char* st = smem + (s % X_NS) * X_STAGE;
-        bf16x8 a[3][MI], b[3][2];
-        // Fragment reads are issued in the order the products consume them - (a1 b1) (a0 b2) (a2 b0) - as inline asm
-        // with hand-counted lgkmcnt waits: all 8 waves read right after the barrier, so the 18th read of a wave returns
-        // ~1150 cycles later (144 KB through a 128 B/clk LDS) but its 6th after ~400; hipcc would wait for all 18
-        // before the first MFMA (lgkmcnt(0)), the counted waits start each product group when ITS operands are in.
-        // (LDS returns in order; nothing else in the loop uses lgkmcnt.)
-        const unsigned la = lbase + (unsigned)((s % X_NS) * X_STAGE + a_off), lb = lbase + (unsigned)((s % X_NS) * X_STAGE + b_off);
-#define X3_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF));
-#define X3_LDA(PL) X3_RD(a[PL][0], la, (PL) * 2048) X3_RD(a[PL][1], la, (PL) * 2048 + 512)                        \
-    if constexpr (MI == 4) { X3_RD(a[PL][MI - 2], la, X_REC + (PL) * 2048) X3_RD(a[PL][MI - 1], la, X_REC + (PL) * 2048 + 512) }
-#define X3_LDB(PL) X3_RD(b[PL][0], lb, (PL) * 2048) X3_RD(b[PL][1], lb, (PL) * 2048 + 512)
-        // wait until at most N4 (MI = 4) / N2 (MI = 2) reads are outstanding; the operands tie the products to the wait
-#define X3_WAIT(N4, N2, PA, PB)                                                                                          \
-    if constexpr (MI == 4) asm volatile("s_waitcnt lgkmcnt(" #N4 ")" : "+v"(a[PA][0]), "+v"(a[PA][1]), "+v"(a[PA][MI - 2]),   \
-                                        "+v"(a[PA][MI - 1]), "+v"(b[PB][0]), "+v"(b[PB][1]));                                  \
-    else asm volatile("s_waitcnt lgkmcnt(" #N2 ")" : "+v"(a[PA][0]), "+v"(a[PA][1]), "+v"(b[PB][0]), "+v"(b[PB][1]));
-        X3_LDA(1) X3_LDB(1) X3_LDA(0) X3_LDB(2) X3_LDA(2) X3_LDB(0)
-        // six plane products, smallest terms first; product-major order keeps 8 independent MFMAs between two
-        // updates of the same accumulator.  The DMA requests of stage s+2 are spread over the MFMA groups: issuing
-        // one costs the wave ~100 cycles, which a running MFMA group hides
-#define X3_PROD(PA, PB)                                                                                          \
-    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)           \
-        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][mi], b[PB][ni], acc[mi][ni], 0, 0, 0);
-#define X3_REQ(J) if (MORE && loader) glds16(g2 + (J) * 1024, l2 + (J) * 1024);
-        X3_WAIT(12, 8, 1, 1) X3_PROD(1, 1) X3_REQ(0) X3_WAIT(6, 4, 0, 2) X3_PROD(0, 2) X3_REQ(1) X3_WAIT(0, 0, 2, 0) X3_PROD(2, 0) X3_REQ(2)
-        X3_PROD(0, 1) X3_REQ(3) X3_PROD(1, 0) X3_REQ(4) X3_PROD(0, 0) X3_REQ(5)
-#undef X3_WAIT
-#undef X3_RD
-#undef X3_LDA
-#undef X3_LDB
-        // pin the issue order: 18 fragment reads, then 6 x (8 MFMAs, 1 DMA request)
-        __builtin_amdgcn_sched_group_barrier(0x100, 3 * (MI + 2), 0);
-#pragma unroll
-        for (int g = 0; g < 6; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * MI, 0);
-            if (MORE && MI == 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+    for (int g = 0;; ++g) {             // the stages of all of this workgroup's tiles, one after the other
+        const bool has_next = qn < q_end;
+        for (; s + 2 < nk; ++s, ++g) {
+            stage(g, std::true_type{}, true, r0, s + 2, nwait);
+            nwait = 6;
         }
-#undef X3_REQ
-#undef X3_PROD
-    };
-    request(0);
-    if (nk > 1) request(1);
-    int s = 0;
-    for (; s + 2 < nk; ++s) stage(s, std::true_type{});
-    for (; s < nk; ++s) stage(s, std::false_type{});
+        stage(g, std::false_type{}, has_next, r1, 0, nwait);            // the tile's last two stages request the next tile's
+        ++g;                                                            // first two
+        stage(g, std::false_type{}, has_next, r1, 1, has_next ? 6 : 0);
 
+        // ---- epilogue (the next tile's first stages are in flight under these stores).  The 32x32 accumulator layout gives a
+        // lane ONE column and 16 rows; stored as it stands that is 32 MI dword store instructions per wave, and a tile's
+        // epilogue is bound by their issue.  Every 4x4 block (registers 4j..4j+3 x the lanes of a quad) is transposed inside
+        // the quad and a lane stores FOUR consecutive columns of one row as 16 bytes: a wave instruction then writes 8 rows x
+        // 128 B, a quarter of the instructions for the same bytes.
+        bool counted;
+        {
+            // (the lane's coordinates are made opaque here: address arithmetic of the epilogue that does not depend on the tile
+            // would otherwise be hoisted out of the tile loop and held in registers across the stage pipeline)
+            int e_li = li, e_lh = lh;
+            asm volatile("" : "+v"(e_li), "+v"(e_lh));
+            const int t = e_li & 3;
+            const bool odd = t & 1, hi = t & 2;
+            const int ncol = n0 + wn * 64 + (e_li & ~3);                   // first of this lane's four columns (ni = 0)
+            const bool vec = p.slabs ? ((p.N & 3) == 0 && (reinterpret_cast<uintptr_t>(p.slabs) & 15) == 0)
+                                     : ((p.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0);      // 16-byte rows
+            // at least 8 MI vector-memory instructions follow the requests of the next tile's first stages: all rows valid and
+            // both column groups of the wave inside N (the next stage's counted wait relies on that lower bound)
+            counted = m0 + TMR <= p.M && n0 + wn * 64 + 64 <= p.N;
+            f32x4 bv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            if (p.bias && !p.slabs) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+                for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m >= p.M) continue;
-            if (p.slabs) {
-                float* srow = p.slabs + ((int64_t)blockIdx.y * p.M + m) * p.N;
+                    for (int k = 0; k < 4; ++k) {
+                        const int n = ncol + ni * 32 + k;
+                        bv[ni][k] = n < p.N ? p.bias[n] : 0.f;
+                    }
+            }
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    const int n = n0 + wn * 64 + ni * 32 + li;
-                    if (n < p.N) srow[n] = acc[mi][ni][r];
+            for (int mi = 0; mi < MI; ++mi) {
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int m = m0 + wm * 32 * MI + mi * 32 + 8 * j + 4 * e_lh + t;      // this lane's row after the transpose
+                    f32x4 v[2];
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        float a0 = acc[mi][ni][4 * j], a1 = acc[mi][ni][4 * j + 1], a2 = acc[mi][ni][4 * j + 2], a3 = acc[mi][ni][4 * j + 3];
+                        quad_transpose4(a0, a1, a2, a3, odd, hi);
+                        v[ni] = f32x4{a0, a1, a2, a3};
+                    }
+                    if (m >= p.M) continue;
+                    float* row = p.slabs ? p.slabs + ((int64_t)blockIdx.y * p.M + m) * p.N : p.C + (int64_t)map_row(p.cmap, m) * p.ldc;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        const int n = ncol + ni * 32;
+                        f32x4 o = v[ni];
+                        if (!p.slabs) { o[0] += bv[ni][0]; o[1] += bv[ni][1]; o[2] += bv[ni][2]; o[3] += bv[ni][3]; }
+                        if (vec && n + 4 <= p.N) {
+                            f32x4* q4 = reinterpret_cast<f32x4*>(row + n);
+                            if (p.accumulate && !p.slabs) { const f32x4 c = *q4; o[0] += c[0]; o[1] += c[1]; o[2] += c[2]; o[3] += c[3]; }
+                            *q4 = o;
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                if (n + k < p.N) {
+                                    float x = o[k];
+                                    if (p.accumulate && !p.slabs) x += row[n + k];
+                                    row[n + k] = x;
+                                }
+                        }
+                    }
                 }
-                continue;
-            }
-            float* crow = p.C + (int64_t)map_row(p.cmap, m) * p.ldc;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int n = n0 + wn * 64 + ni * 32 + li;
-                if (n >= p.N) continue;
-                float v = acc[mi][ni][r];
-                if (p.bias) v += p.bias[n];
-                if (p.accumulate) v += crow[n];
-                crow[n] = v;
             }
         }
+        if (!has_next) break;
+        nwait = counted ? 6 + 8 * MI : 6;       // (6: everything but the youngest six operations - also correct, only later)
+        q = qn; m0 = m1; n0 = n1; r0 = r1;
+        qn = q + gx;
+        if (qn < q_end) tile_of(qn, m1, n1);
+        r1 = rsrc_of(m1, n1);
+        s = 0;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     }
+#undef X3_REQ1
 }
 
 int splitk_reduce(hipStream_t stream, const float* slabs, int nsplit, int M, int N, float* C, int64_t ldc, RowMap cmap,
                   const float* bias, bool accumulate);
+
+// Per-tile cost model (us) of the launcher: a k16 stage of a (64 MI) x 256 tile and the tile's epilogue (tools/bench_gemm_shapes.py
+// under S2VT_X3_MI); the stage is bound by the six plane products (12 MI MFMAs per wave)
+static const double kX3Stage[5] = {0, 0, 1.35, 1.75, 2.15};
+static const double kX3Epi[5] = {0, 0, 4.5, 6.0, 8.0};
+static int g_x3_force_mi = -1, g_x3_force_n = -1;
+void gemm_x3_tune(int tile_rows, int nsplit) {
+    g_x3_force_mi = (tile_rows >= 128 && tile_rows <= 256 && tile_rows % 64 == 0) ? tile_rows / 64 : 0;
+    g_x3_force_n = nsplit > 0 ? nsplit : 0;
+}
 
 // A, B: blocked 3-plane operands (see the header of this file); K = their common padded k extent for this call.
 int gemm_x3(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
@@ -208,67 +319,58 @@ int gemm_x3(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
     p.A = A; p.lda = lda;
     p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.cmap = cmap; p.bias = bias; p.accumulate = accumulate ? 1 : 0;
-    p.m_base = 0; p.m_tiles = 0;
-    // One workgroup per CU.  Tile height (256 or 128 rows) and split-K factor are chosen by a time model: rounds of 256
-    // workgroups x per-tile time + the fixed-order slab combine.  Per k unit of a tile ~0.14 us at 256x256 (2.2 us per
-    // k16 stage) and ~0.092 us at 128x256 (measured: tools/bench_x3_split.py with S2VT_X3_TM); ~6 us per tile of prologue/epilogue; combine = (n + 1) passes over M x N
-    // floats at ~3.5 TB/s + a launch.
-    static int force_tm = -1;    // S2VT_X3_TM=128|256: experiment override
-    if (force_tm < 0) { const char* e = getenv("S2VT_X3_TM"); force_tm = e ? atoi(e) : 0; }
-    int nsplit = 1, tmr = 256;
-    {
-        double best = 1e30;
-        for (int shape = 0; shape < 2; ++shape) {
-            const int rows = shape ? 128 : 256;
-            if (force_tm && force_tm != rows) continue;
-            const double ck = shape ? 0.092 : 0.14;
-            const int tiles = cdiv(M, rows) * cdiv(N, XT);
-            for (int n = 1; n <= 16; ++n) {
-                if (n > 1 && (!splitk_ws || K < 512 || K / n < 256 || (size_t)n * M * N > splitk_ws_floats)) break;
-                const int ks = cdiv(cdiv(K, n), 64) * 64, nn = cdiv(K, ks);
-                if (nn != n) continue;
-                const double rounds = (double)cdiv(tiles * nn, 256);
-                const double t = rounds * (ks * ck + 6.0) + (nn > 1 ? (nn + 1.0) * M * (double)N * 4.0 / 3.5e6 + 8.0 : 0.0);
-                if (t < best * 0.97) { best = t; nsplit = nn; tmr = rows; }
-            }
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        (void)hipGetLastError();
+        ncu = n / 8 * 8;
+    }
+    // S2VT_X3_MI=2..4 / S2VT_X3_NSPLIT=n or s2vt_gemm_tune(3, ...): overrides of the time model
+    if (g_x3_force_mi < 0) { const char* e = getenv("S2VT_X3_MI"); g_x3_force_mi = e ? atoi(e) : 0; }
+    if (g_x3_force_n < 0) { const char* e = getenv("S2VT_X3_NSPLIT"); g_x3_force_n = e ? atoi(e) : 0; }
+    const int force_mi = g_x3_force_mi, force_n = g_x3_force_n;
+    // One workgroup per CU.  Tile height, split-K factor and grid by the time model: every workgroup walks ceil(its XCD's chunk /
+    // workgroups of the XCD) tiles of nk stages + an epilogue; split-K adds the fixed-order slab combine ((n + 1) passes over
+    // M x N floats at ~3.5 TB/s + a launch)
+    const int ntn = cdiv(N, 256);
+    int best_mi = 4, best_ns = 1, best_g = 8;
+    double best = 1e30;
+    static const int order[3] = {4, 3, 2};
+    for (int oi = 0; oi < 3; ++oi) {
+        const int mi = order[oi];
+        if (force_mi && force_mi != mi) continue;
+        const int tiles = cdiv(M, 64 * mi) * ntn;
+        for (int n = 1; n <= 16; ++n) {
+            if (n > 1 && (!splitk_ws || K < 512 || K / n < 256 || (size_t)n * M * N > splitk_ws_floats)) break;
+            if (force_n && n != force_n) continue;
+            const int ks = cdiv(cdiv(K, n), 64) * 64, nn = cdiv(K, ks);
+            if (nn != n) continue;
+            int g = ncu / nn / 8 * 8;
+            if (g < 8) g = 8;
+            if (g > cdiv(tiles, 8) * 8) g = cdiv(tiles, 8) * 8;
+            const int per_wg = cdiv(cdiv(tiles, 8), g / 8);
+            const double rounds = (double)cdiv(g * nn, ncu);
+            const double t = rounds * per_wg * ((ks / 16) * kX3Stage[mi] + kX3Epi[mi]) + 3.0 +
+                             (nn > 1 ? (nn + 1.0) * M * (double)N * 4.0 / 3.5e6 + 8.0 : 0.0);
+            if (t < best * 0.98) { best = t; best_mi = mi; best_ns = nn; best_g = g; }
         }
     }
-    // Tile quantisation without split-K: 320 tiles of 256 rows are two rounds of the chip with the second a quarter full.  Two
-    // launches instead - `a` row tiles of 256 rows that fill whole rounds, the remaining rows as 128-row tiles - when the same
-    // time model says so (gx1 / gxe of config 2: 20 x 16 tiles -> 16 x 16 of 256 rows + 8 x 16 of 128: 299 -> 249 us).
-    static int mixed_on = -1;    // S2VT_X3_MIXED=0: off
-    if (mixed_on < 0) { const char* e = getenv("S2VT_X3_MIXED"); mixed_on = e ? (atoi(e) != 0) : 1; }
-    if (mixed_on && !force_tm && nsplit == 1 && tmr == 256) {
-        const int ntn = cdiv(N, XT), ntm = cdiv(M, 256);
-        const double c256 = K * 0.14 + 6.0, c128 = K * 0.092 + 6.0;
-        const double t_single = (double)cdiv(ntm * ntn, 256) * c256;
-        int best_a = 0;
-        double best_t = t_single * 0.93;                 // (a second launch has to pay for itself)
-        for (int a = 1; a < ntm; ++a) {
-            const int rest = cdiv(M - a * 256, 128);
-            const double t = (double)cdiv(a * ntn, 256) * c256 + (double)cdiv(rest * ntn, 256) * c128 + 2.0;
-            if (t < best_t) { best_t = t; best_a = a; }
-        }
-        if (best_a > 0) {
-            p.ksplit = K; p.slabs = nullptr;
-            p.m_base = 0; p.m_tiles = best_a;
-            hipLaunchKernelGGL(gemm_x3_kernel<4>, dim3(cdiv(best_a * ntn, 8) * 8, 1), dim3(512), 0, stream, p);
-            p.m_base = best_a * 256; p.m_tiles = cdiv(M - best_a * 256, 128);
-            hipLaunchKernelGGL(gemm_x3_kernel<2>, dim3(cdiv(p.m_tiles * ntn, 8) * 8, 1), dim3(512), 0, stream, p);
-            S2VT_LAUNCH_CHECK("gemm_x3_kernel");
-            return 0;
-        }
+    if (best > 1e29) {      // (an override that no candidate met: one slice of 256-row tiles)
+        best_mi = 4; best_ns = 1;
+        best_g = cdiv(cdiv(M, 256) * ntn, 8) * 8;
+        if (best_g > ncu) best_g = ncu;
     }
-    const int tiles = cdiv(M, tmr) * cdiv(N, XT);
-    static int force_n = -1;     // S2VT_X3_NSPLIT=n: experiment override (tools/bench_x3_split.py)
-    if (force_n < 0) { const char* e = getenv("S2VT_X3_NSPLIT"); force_n = e ? atoi(e) : 0; }
-    if (force_n > 0 && splitk_ws && (size_t)force_n * M * N <= splitk_ws_floats && K / force_n >= 64) nsplit = force_n;
-    p.ksplit = (nsplit > 1) ? cdiv(cdiv(K, nsplit), 64) * 64 : K;
-    if (nsplit > 1) nsplit = cdiv(K, p.ksplit);
+    p.ntm = cdiv(M, 64 * best_mi); p.ntn = ntn;
+    p.ksplit = (best_ns > 1) ? cdiv(cdiv(K, best_ns), 64) * 64 : K;
+    const int nsplit = (best_ns > 1) ? cdiv(K, p.ksplit) : 1;
     p.slabs = (nsplit > 1) ? splitk_ws : nullptr;
-    const dim3 grid(cdiv(tiles, 8) * 8, nsplit);
-    if (tmr == 256) hipLaunchKernelGGL(gemm_x3_kernel<4>, grid, dim3(512), 0, stream, p);
-    else hipLaunchKernelGGL(gemm_x3_kernel<2>, grid, dim3(512), 0, stream, p);
+    const dim3 grid(best_g, nsplit);
+    switch (best_mi) {
+        case 2: hipLaunchKernelGGL(gemm_x3_kernel<2>, grid, dim3(512), 0, stream, p); break;
+        case 3: hipLaunchKernelGGL(gemm_x3_kernel<3>, grid, dim3(512), 0, stream, p); break;
+        default: hipLaunchKernelGGL(gemm_x3_kernel<4>, grid, dim3(512), 0, stream, p); break;
+    }
     S2VT_LAUNCH_CHECK("gemm_x3_kernel");
     if (nsplit > 1) return splitk_reduce(stream, splitk_ws, nsplit, M, N, C, ldc, cmap, bias, accumulate);
     return 0;

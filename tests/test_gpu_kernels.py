@@ -102,6 +102,37 @@ def test_plain_bf16_gemm_rows(lib, M, N, K):
 
 
 
+@pytest.mark.parametrize("tile_rows", [128, 192, 256])
+def test_split_precision_gemm_every_tile_height_persistent(lib, tile_rows):
+    """gemm_x3_kernel<MI> for every tile height as a PERSISTENT launch (more tiles than compute units, the 3-slot ring running on
+    across the tiles of a workgroup), ragged M / N, bias, accumulate, split-K, NaN planes in the padding rows of the 64-row
+    blocks: integer operands must come out exact (every plane product and every fp32 sum is exact then), random operands within
+    the fp32-equivalent bound of test_split_precision_gemm_blocked_planes."""
+    from s2vt_video_caption_amd import capi, ops
+    try:
+        for (M, N, K, ns) in ((6001, 2900, 192, 0), (4100, 1000, 2048, 3), (333, 77, 64, 0), (5120, 1000, 512, 0)):
+            lib.s2vt_gemm_tune(3, tile_rows, ns)
+            g = torch.Generator().manual_seed(M + N + tile_rows)
+            ai = torch.randint(-4, 5, (M, K), generator=g).float()
+            bi = torch.randint(-4, 5, (N, K), generator=g).float()
+            bias = torch.randint(-8, 9, (N,), generator=g).float()
+            pa, pb = ops.split_planes(ai.to(DEV), 3), ops.split_planes(bi.to(DEV), 3)
+            ws = torch.empty(4 * M * N + 1, device=DEV)
+            got = ops.gemm_planes(pa, pb, M, N, nplanes=3, bias=bias.to(DEV), splitk_ws=ws).cpu()
+            assert torch.equal(got, ai @ bi.t() + bias), (M, N, K, ns)
+            c0 = torch.randint(-8, 9, (M, N), generator=g).float()
+            out = c0.to(DEV).clone()
+            ops.gemm_planes(pa, pb, M, N, nplanes=3, out=out, accumulate=True, splitk_ws=ws)
+            assert torch.equal(out.cpu(), ai @ bi.t() + c0), (M, N, K, ns, "accumulate")
+            a, b = _r(M, K, seed=M), _r(N, K, seed=N)
+            ref = a.double() @ b.double().t()
+            got = ops.gemm_planes(ops.split_planes(a.to(DEV), 3), ops.split_planes(b.to(DEV), 3), M, N, nplanes=3, splitk_ws=ws).cpu()
+            assert (got.double() - ref).abs().max().item() < 4e-6 * ref.abs().max().item() + 1e-6, (M, N, K, ns)
+        capi.check_async_error()
+    finally:
+        lib.s2vt_gemm_tune(3, 0, 0)
+
+
 @pytest.mark.parametrize("tile_rows", [128, 192, 256, 320])
 def test_plain_bf16_gemm_every_tile_height_persistent(lib, tile_rows):
     """gemm_b1_kernel<MI> for every tile height, as a PERSISTENT launch (more tiles than compute units: a workgroup walks
@@ -132,10 +163,10 @@ def test_plain_bf16_gemm_every_tile_height_persistent(lib, tile_rows):
         lib.s2vt_gemm_tune(1, 0, 0)
 
 
-def test_split_precision_gemm_mixed_tile_heights(lib):
-    """gx1 of config 2 (5120 x 4000 x 1000): 320 tiles of 256 rows would be two rounds of the chip with the second a quarter
-    full, so the launcher runs 16 row tiles of 256 rows and the last 1024 rows as 128-row tiles (two launches, gemm_x3.hip):
-    every output row against fp64 (a row range served twice or not at all would show), integers exact, bias and accumulate."""
+def test_split_precision_gemm_at_the_gx1_shape_of_config2(lib):
+    """gx1 of config 2 (5120 x 4000 x 1000): 320 tiles of 256 rows = 1.25 rounds of the chip, the shape the launcher's time model
+    picks a tile height for (a persistent launch in which some workgroups walk two tiles): every output row against fp64 (a row
+    range served twice or not at all would show), integers exact, bias and accumulate."""
     from s2vt_video_caption_amd import ops
     M, N, K = 5120, 4000, 1000
     g = torch.Generator().manual_seed(9)
