@@ -125,7 +125,12 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
     // of the workgroup's next one (descriptor r2, stage index s2 there) - and is requested while this one is multiplied;
     // nwait = how many of this wave's youngest vector-memory operations may still be outstanding when stage g must have landed
     // (the 6 requests of stage g + 1, plus the store instructions of an epilogue issued between them and now)
-    auto stage = [&](int g, auto more_tag, bool more_rt, __amdgpu_buffer_rsrc_t r2, int s2, int nwait) {
+    // DEFERRED hi*hi group: the sixth product group of a stage (plane 0 x plane 0, whose operands are in registers) is issued at the
+    // START of the next stage, right behind that stage's 3 (MI + 2) fragment reads - the 2 MI MFMAs per wave (both waves of a SIMD:
+    // ~512 cycles) run while the reads cross the LDS pipe, where every wave of the workgroup used to sit idle for the ~400 cycles
+    // until its first fragments were back.  The order of the MFMAs on each accumulator is unchanged (bitwise the same sums).
+    bf16x8 a0p[MI], b0p[2];
+    auto stage = [&](int g, auto more_tag, bool more_rt, __amdgpu_buffer_rsrc_t r2, int s2, int nwait, bool deferred) {
         const bool more = decltype(more_tag)::value || more_rt;       // (compile-time true inside a tile: no branch around the requests)
         if (nwait == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         else if (nwait == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -165,12 +170,23 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
     X3_PROD(PA, PB)                                                        \
     if (req) { X3_REQ1(J, r2, s2, slot2) }                                 \
     __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);       // (the deferred group stays BEHIND the fragment reads: it is what covers their latency)
+        if (deferred) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0p[mi], b0p[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (req) { X3_REQ1(5, r2, s2, slot2) }
+        __builtin_amdgcn_sched_barrier(0);
         X3_GROUP(2 * (MI + 2), 1, 1, 0, true)
         X3_GROUP(MI + 2, 0, 2, 1, true)
         X3_GROUP(0, 2, 0, 2, true)
         X3_GROUP(0, 0, 1, 3, false)
         X3_GROUP(0, 1, 0, 4, false)
-        X3_GROUP(0, 0, 0, 5, false)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) a0p[mi] = a[0][mi];
+        b0p[0] = b[0][0]; b0p[1] = b[0][1];
 #undef X3_GROUP
 #undef X3_PROD
 #undef X3_WAIT
@@ -203,12 +219,16 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
     for (int g = 0;; ++g) {             // the stages of all of this workgroup's tiles, one after the other
         const bool has_next = qn < q_end;
         for (; s + 2 < nk; ++s, ++g) {
-            stage(g, std::true_type{}, true, r0, s + 2, nwait);
+            stage(g, std::true_type{}, true, r0, s + 2, nwait, s > 0);
             nwait = 6;
         }
-        stage(g, std::false_type{}, has_next, r1, 0, nwait);            // the tile's last two stages request the next tile's
+        stage(g, std::false_type{}, has_next, r1, 0, nwait, true);      // the tile's last two stages request the next tile's
         ++g;                                                            // first two
-        stage(g, std::false_type{}, has_next, r1, 1, has_next ? 6 : 0);
+        stage(g, std::false_type{}, has_next, r1, 1, has_next ? 6 : 0, true);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)                                 // the last stage's deferred group
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0p[mi], b0p[ni], acc[mi][ni], 0, 0, 0);
 
         // ---- epilogue (the next tile's first stages are in flight under these stores).  The 32x32 accumulator layout gives a
         // lane ONE column and 16 rows; stored as it stands that is 32 MI dword store instructions per wave, and a tile's
