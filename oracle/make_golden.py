@@ -205,7 +205,10 @@ def gen_long(name="c1long", cfg="c1", seed=31, n_steps=40, lr=1e-3):
 
 
 ATT_CONFIGS = {"att_tiny": dict(B=5, L=8, F=48, H=32, E=24, V=60, seed=3, full=True),
-               "att_mid": dict(B=16, L=20, F=256, H=128, E=96, V=300, seed=4, full=False)}
+               "att_mid": dict(B=16, L=20, F=256, H=128, E=96, V=300, seed=4, full=False),
+               # the reference's OWN size (train.py:20-48 defaults as committed upstream: batch 16, 80 frames of 4096 features,
+               # dim_hidden = dim_embed = 512; vocabulary of the order of MSVD's): round-3 verdict, weak #3
+               "att_full": dict(B=16, L=80, F=4096, H=512, E=512, V=12000, seed=5, full=False)}
 
 
 def gen_att(name):
@@ -467,7 +470,7 @@ if __name__ == "__main__":
         gen_long()
     if "mid64long" in which:
         gen_long("mid64long", "mid64", seed=41)
-    for att in ("att_tiny", "att_mid"):
+    for att in ("att_tiny", "att_mid", "att_full"):
         if att in which:
             gen_att(att)
     if "c2long" in which:   # BASELINE configs[1] (the headline) at its own size: 10 fp32 reference Adam steps (lr 1e-3) on one B=64

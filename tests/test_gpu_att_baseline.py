@@ -27,7 +27,7 @@ def _setup(name):
     return g, m.to(DEV), feats.to(DEV), caps.to(DEV), mask.to(DEV)
 
 
-@pytest.mark.parametrize("name", ["att_tiny", "att_mid"])
+@pytest.mark.parametrize("name", ["att_tiny", "att_mid", "att_full"])
 def test_att_baseline_train_step_against_reference(lib, name):
     import utils
     g, m, feats, caps, mask = _setup(name)
@@ -58,7 +58,7 @@ def test_att_baseline_train_step_against_reference(lib, name):
             assert np.abs(got.numpy() - full).max() <= 2e-6 + 2e-4 * np.abs(full).max(), k
 
 
-@pytest.mark.parametrize("name", ["att_tiny", "att_mid"])
+@pytest.mark.parametrize("name", ["att_tiny", "att_mid", "att_full"])
 def test_att_baseline_greedy_ids_against_reference(lib, name):
     """mode='test': L greedy steps from <sos>.  A row is compared up to (not including) its first decision whose top-2 logit
     margin in the reference is below 2e-5 - the bound the train-mode logits are held to above; a flip below it is legitimate and
