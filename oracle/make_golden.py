@@ -400,6 +400,28 @@ def gen_c5full(seed, out_scale, beam_width=5, workers=6, name="c5full"):
     print(f"[{name}] wrote {name}.npz")
 
 
+def gen_c5raw(seed, name="c5raw"):
+    """The UNSCALED companion of c5full (round-3 verdict, weak #2): the reference's greedy decode of the same B=128 batch with the
+    recipe's weights as they are (out_scale 1: logit margins of the size random-init weights really give, weakest 2.6e-4 for this
+    seed), ids + per-decision top-2 margins.  The GPU test compares every row whose weakest margin is >= 1e-4."""
+    S2VT, _ = _reference()
+    d = synth.CONFIGS["c5"]
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed, out_scale=1.0)
+    feats, _, _ = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
+    m = _ref_model(S2VT, d, sd)
+    m.eval()
+    with torch.no_grad():
+        ids = m(feats, mode="test")
+    oids, marg = orc.greedy_decode(sd, feats, return_margins=True)
+    rm = marg.min(dim=1).values.numpy()
+    same = (ids == oids).all(dim=1).numpy()
+    assert all(rm[i] < 1e-4 for i in np.nonzero(~same)[0]), rm[~same]
+    print(f"[{name}] oracle == reference on {int(same.sum())}/{d['B']} rows; weakest margin {rm.min():.3e}, rows < 1e-4: {int((rm < 1e-4).sum())}")
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), seed=seed, out_scale=1.0, dims=np.array([d[k] for k in "BLFHEV"], dtype=np.int64),
+                        greedy_ids=ids.numpy(), greedy_margin=marg.numpy().astype(np.float32), greedy_oracle_equal=same)
+    print(f"[{name}] wrote {name}.npz")
+
+
 def gen_pickle():
     """A full-module pickle WRITTEN BY THE REFERENCE class (train.py:167-168 style) at tiny
     dims, to test that the drop-in S2VTModel.S2VT loads reference checkpoints."""
@@ -479,5 +501,7 @@ if __name__ == "__main__":
         gen_long("c3long", "c3", seed=5, n_steps=10)       # the bf16 GPU trajectory is compared with it step by step
     if "c5full" in which:
         gen_c5full(*C5FULL_CHOICE)
+    if "c5raw" in which:
+        gen_c5raw(C5FULL_CHOICE[0])
     if "c5beam" in which:
         gen_beam_only("c5beam", "c5", seed=C5_CHOICE[0], beam_b=4, beam_width=5, out_scale=C5_CHOICE[1])

@@ -167,3 +167,12 @@ def test_c5_full_batch_fixture_pins_the_oracle(golden):
     sents = orc.beam_search(sd, feats[rows], beam_width=int(g["beam_width"]), max_depth=30)
     for r, s in zip(rows, sents):
         assert s == [int(x) for x in g["beam_ids"][r] if x >= 0], int(r)
+
+
+def test_c5_unscaled_fixture_is_the_references(golden):
+    """c5raw.npz (out_scale 1, the same B=128 batch as c5full): written from the reference's own greedy decode with the oracle
+    equal on every row at generation time; no row rests on a top-2 margin below 1e-4 (what the GPU test's row filter keeps)."""
+    g = golden("c5raw")
+    assert tuple(g["greedy_ids"].shape) == (128, 79) and float(g["out_scale"]) == 1.0
+    assert bool(g["greedy_oracle_equal"].all())
+    assert float(g["greedy_margin"].min()) >= 1e-4
