@@ -109,6 +109,25 @@ int s2vt_beam_step(const s2vt_dims* d, const s2vt_params* p, int32_t R, const in
                    const float* word_h_in, const float* word_c_in, float* word_h_out, float* word_c_out, int32_t* top_ix,
                    float* top_lp, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The reference's per-sample priority queues of the beam search (S2VTModel.py:186-238) ON THE DEVICE, all samples of the batch in one
+ * launch per depth: heapq's own sift-down / sift-up replayed per sample (one lane each, heap in LDS), so that the pop order - also
+ * among EQUAL scores, where it depends on the binary heap's layout - is the reference's.  `state`: s2vt_beam_queue_bytes() of
+ * caller-owned device memory that lives for one search.  Rows of the batched step are fixed: r = b * beam_width + slot.
+ *   depth = 1          : initialise, pop the roots; writes row_b / row_state / row_tok for the first s2vt_beam_step
+ *   depth = 2..max     : push the children of the depth just stepped (top_ix / top_lp [B*beam_width][20] of s2vt_beam_step), record
+ *                        each sample's best entry, freeze samples whose queue holds <= beam_width entries (:227-228), pop the next
+ *                        beam (queue cleared, finished entries re-inserted: :190-202) and write the rows of the next step
+ *   depth = 0          : the final push (nothing is popped any more)
+ * A frozen sample's slots carry token 0 / state row 0 (their step results are ignored).  The int32 at byte 0 of `state` counts the
+ * frozen samples (== B: the reference's loop would stop; further calls change nothing).
+ * s2vt_beam_queue_result: back-trace of every sample's best entry (:231-236) -> out_tokens[b][0..out_len[b]) = <sos> .. last word. */
+size_t s2vt_beam_queue_bytes(int32_t B, int32_t beam_width, int32_t max_depth);
+int s2vt_beam_queue_step(int32_t B, int32_t beam_width, int32_t max_depth, int32_t sos_ix, int32_t eos_ix, int32_t depth, void* state,
+                         size_t state_bytes, const int32_t* top_ix, const float* top_lp, int32_t* row_b, int32_t* row_state,
+                         int32_t* row_tok, void* stream);
+int s2vt_beam_queue_result(int32_t B, int32_t beam_width, int32_t max_depth, void* state, size_t state_bytes, int32_t* out_tokens,
+                           int32_t out_cap, int32_t* out_len, void* stream);
+
 /* Data-parallel overlap (no reference counterpart: the reference is single-device).  After s2vt_train_backward has
  * RETURNED (all of its work is enqueued), make `stream` wait until a group of that call's parameter gradients is
  * final, so that their all-reduce can run under the rest of the backward:

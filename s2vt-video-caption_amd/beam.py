@@ -86,8 +86,10 @@ def beam_search(model, feats, params, beam_width=3, max_depth=30):
     import ctypes
     from .functional import _ptr, _stream, _dims, _params_struct
     lib = capi.load()
-    queues = (BeamQueues if FAST_QUEUES else HeapQueues)(B, beam_width, sos, eos)
     max_rows = max(B * beam_width, B)
+    if DEVICE_QUEUES and lib.s2vt_beam_queue_bytes(B, beam_width, max_depth) > 0:
+        return _beam_search_device_queues(lib, feats, params, B, H, beam_width, max_depth, sos, eos, vid_h, vid_c, word_h, word_c)
+    queues = (BeamQueues if FAST_QUEUES else HeapQueues)(B, beam_width, sos, eos)
     pcs = tuple(p.contiguous() for p in (w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, w_f, b_f, w_o, b_o, emb))
     d = _dims(feats, pcs)
     ps = _params_struct(capi.Params, pcs)
@@ -133,6 +135,73 @@ def beam_search(model, feats, params, beam_width=3, max_depth=30):
 
 
 FAST_QUEUES = True
+DEVICE_QUEUES = True         # the queues on the device (csrc/beam_queue.hip): no host work and no transfer per depth
+
+
+def _beam_search_device_queues(lib, feats, params, B, H, beam_width, max_depth, sos, eos, vid_h, vid_c, word_h, word_c):
+    """The depth loop with the queue bookkeeping on the device: per depth ONE s2vt_beam_queue_step (push the children of the
+    depth before, freeze finished samples, pop the next beam with heapq's own sift order, write the rows of the step) and ONE
+    s2vt_beam_step over the fixed rows r = b * beam_width + slot; nothing crosses PCIe until the back-traced sequences at the
+    end.  The reference's early exit (all samples stopped, S2VTModel.py:189) is polled without blocking: the frozen-sample
+    counter is copied to pinned memory after every depth and read one depth late - extra depths change nothing."""
+    import ctypes
+    from .functional import _ptr, _stream, _dims, _params_struct
+    dev = feats.device
+    R = B * beam_width
+    pcs = tuple(p.detach().contiguous() for p in params)
+    d = _dims(feats, pcs)
+    ps = _params_struct(capi.Params, pcs)
+    with torch.cuda.device(dev):
+        nbytes = lib.s2vt_beam_workspace_bytes(ctypes.byref(d), R)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        qbytes = lib.s2vt_beam_queue_bytes(B, beam_width, max_depth)
+        qs = torch.empty(qbytes, dtype=torch.uint8, device=dev)
+        vid = [(vid_h.contiguous(), vid_c.contiguous()), (torch.empty(B, H, device=dev), torch.empty(B, H, device=dev))]
+        tab = [(torch.zeros(R, H, device=dev), torch.zeros(R, H, device=dev)) for _ in range(2)]
+        tab[0][0][:B].copy_(word_h)
+        tab[0][1][:B].copy_(word_c)
+        rows = torch.zeros(3, R, dtype=torch.int32, device=dev)
+        top_ix = torch.zeros(R, FANOUT, dtype=torch.int32, device=dev)
+        top_lp = torch.zeros(R, FANOUT, dtype=torch.float32, device=dev)
+        frozen = torch.zeros(max_depth + 2, dtype=torch.int32).pin_memory()
+        frozen_dev = qs[:4].view(torch.int32)
+        events = []
+        st = _stream(dev)
+
+        def qstep(depth):
+            capi.check(lib.s2vt_beam_queue_step(B, beam_width, max_depth, sos, eos, depth, _ptr(qs), qbytes, _ptr(top_ix), _ptr(top_lp),
+                                                _ptr(rows[0]), _ptr(rows[1]), _ptr(rows[2]), st), "s2vt_beam_queue_step")
+        depth = 0
+        while depth < max_depth:
+            if depth >= 2 and events[depth - 2].query() and int(frozen[depth - 1]) == B:
+                break                                   # every sample had stopped two depths ago: the reference's loop ended there
+            depth += 1
+            qstep(depth)
+            if depth > 1:
+                frozen[depth].copy_(frozen_dev[0], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            events.append(ev)
+            (vh_in, vc_in), (vh_out, vc_out) = vid[(depth - 1) & 1], vid[depth & 1]
+            (wh_in, wc_in), (wh_out, wc_out) = tab[(depth - 1) & 1], tab[depth & 1]
+            capi.check(lib.s2vt_beam_step(ctypes.byref(d), ctypes.byref(ps), R, _ptr(rows[0]), _ptr(rows[1]), _ptr(rows[2]),
+                                          _ptr(vh_in), _ptr(vc_in), _ptr(vh_out), _ptr(vc_out), _ptr(wh_in), _ptr(wc_in),
+                                          _ptr(wh_out), _ptr(wc_out), _ptr(top_ix), _ptr(top_lp), _ptr(ws), nbytes, st), "s2vt_beam_step")
+        qstep(0)                                        # the last depth's push
+        cap = max_depth + 2
+        out = torch.empty(B, cap, dtype=torch.int32, device=dev)
+        out_len = torch.empty(B, dtype=torch.int32, device=dev)
+        capi.check(lib.s2vt_beam_queue_result(B, beam_width, max_depth, _ptr(qs), qbytes, _ptr(out), cap, _ptr(out_len), st),
+                   "s2vt_beam_queue_result")
+        host = torch.cat([out, out_len[:, None]], dim=1).cpu().numpy()        # (the one synchronisation of the search)
+        lens = host[:, cap].tolist()
+        flat = torch.as_tensor(np.concatenate([host[b, :lens[b]] for b in range(B)]).astype(np.int64), device=dev)
+    sentences, o = [], 0
+    for b in range(B):
+        t = flat[o:o + lens[b]]
+        o += lens[b]
+        sentences.append([t[:1].view(1, 1)] + list(t[1:].unbind(0)))
+    return sentences
 
 
 class HeapQueues(object):

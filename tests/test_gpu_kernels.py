@@ -411,6 +411,67 @@ def test_feat_proj_fwd_bwd(lib):
     assert (dfe.cpu() - dx_bm @ w).abs().max().item() < 1e-5
 
 
+
+@pytest.mark.parametrize("ties", [False, True])
+def test_device_beam_queues_match_reference_heap(lib, ties):
+    """csrc/beam_queue.hip against the literal heap bookkeeping of S2VTModel.py:186-236 (beam.HeapQueues): the same synthetic
+    top-20 tables (ascending token ids, random log-probs - small integers in the `ties` case, where WHICH entries pop first
+    depends on the binary heap's internal layout) are fed to both, depth by depth; popped tokens, the set of frozen samples at
+    every depth and the back-traced sequences must be identical.  <eos> = 2 occurs among the tokens, so entries finish, are
+    re-inserted unchanged and samples stop early."""
+    import ctypes
+    from s2vt_video_caption_amd import beam
+    from s2vt_video_caption_amd.functional import _ptr, _stream
+    B, bw, D, V, sos, eos = 37, 5, 12, 23, 1, 2
+    R = B * bw
+    for seed in range(4):
+        rng = np.random.default_rng(seed + (100 if ties else 0))
+        q = beam.HeapQueues(B, bw, sos, eos)
+        nbytes = lib.s2vt_beam_queue_bytes(B, bw, D)
+        state = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+        rows = torch.zeros(3, R, dtype=torch.int32, device=DEV)
+        tix = torch.zeros(R, 20, dtype=torch.int32, device=DEV)
+        tlp = torch.zeros(R, 20, dtype=torch.float32, device=DEV)
+
+        def qstep(depth):
+            from s2vt_video_caption_amd import capi
+            capi.check(lib.s2vt_beam_queue_step(B, bw, D, sos, eos, depth, _ptr(state), nbytes, _ptr(tix), _ptr(tlp), _ptr(rows[0]),
+                                                _ptr(rows[1]), _ptr(rows[2]), _stream(torch.device(DEV))), "s2vt_beam_queue_step")
+        depth = 0
+        while depth < D and not q.all_done():
+            depth += 1
+            rb, rs, rt = q.pop()
+            qstep(depth)
+            # the device's fixed rows r = b * bw + slot against the host's compact (sample, slot) rows of this depth
+            dev_tok = rows[2].cpu().numpy().reshape(B, bw)
+            want = np.zeros((B, bw), dtype=np.int64)
+            slots = []
+            for b in range(B):
+                if q.beams[b] is None:
+                    continue
+                for j, (key, n) in enumerate(q.beams[b]):
+                    if not (n.wordid == eos and n.prevNode is not None):
+                        want[b, j] = n.wordid
+                        slots.append(b * bw + j)
+            np.testing.assert_array_equal(dev_tok, want, err_msg="depth %d seed %d" % (depth, seed))
+            assert len(slots) == len(rb)
+            T_ix = np.sort(np.stack([rng.choice(V, 20, replace=False) for _ in range(R)]), axis=1).astype(np.int32)
+            T_lp = (-rng.integers(1, 6, size=(R, 20)).astype(np.float32) if ties else -rng.random((R, 20), dtype=np.float32) * 10)
+            tix.copy_(torch.from_numpy(T_ix))
+            tlp.copy_(torch.from_numpy(T_lp))
+            q.push(T_ix[slots].astype(np.int64) if slots else None, T_lp[slots] if slots else None)
+        qstep(0)
+        frozen = int(state[:4].view(torch.int32).item())
+        assert frozen == sum(q.done)
+        out = torch.zeros(B, D + 2, dtype=torch.int32, device=DEV)
+        out_len = torch.zeros(B, dtype=torch.int32, device=DEV)
+        from s2vt_video_caption_amd import capi
+        capi.check(lib.s2vt_beam_queue_result(B, bw, D, _ptr(state), nbytes, _ptr(out), D + 2, _ptr(out_len), _stream(torch.device(DEV))),
+                   "s2vt_beam_queue_result")
+        got = [out[b, :int(out_len[b])].cpu().tolist() for b in range(B)]
+        assert got == q.finish(), seed
+
+
 def test_beam_step_matches_cell_and_topk(lib):
     """s2vt_beam_step (vid step, gathered word step with in-kernel embedding rows, out_linear, log_softmax + top-20 in
     ascending token order) against the oracle's cell and torch's log_softmax/topk on the CPU."""

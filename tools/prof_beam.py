@@ -40,3 +40,14 @@ if os.environ.get("CPROFILE"):
         torch.cuda.synchronize()
         pr.disable()
     pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+# the same call with the queues on the host (round 3's path) beside the device queues (default since round 4)
+for dq in (True, False, True, False):
+    beam.DEVICE_QUEUES = dq
+    with torch.no_grad():
+        m(feats, mode="beam_search", beam_width=bw, max_beam_depth=30)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            m(feats, mode="beam_search", beam_width=bw, max_beam_depth=30)
+        torch.cuda.synchronize()
+    print("device queues %s: %.2f ms per call" % (dq, (time.perf_counter() - t0) / 3 * 1e3))
