@@ -108,6 +108,14 @@ int s2vt_beam_step(const s2vt_dims* d, const s2vt_params* p, int32_t R, const in
                    const int32_t* tok, const float* vid_h_in, const float* vid_c_in, float* vid_h_out, float* vid_c_out,
                    const float* word_h_in, const float* word_c_in, float* word_h_out, float* word_c_out, int32_t* top_ix,
                    float* top_lp, void* workspace, size_t workspace_bytes, void* stream);
+/* The same depth with the weight-derived images of a greedy decode of the SAME weights (`cache` as filled by
+ * s2vt_greedy_decode_cached: plane images of W_v / W_o, the per-token gate table): vid_out's half of the gate input once per sample,
+ * the embedded word from the table, out_linear in split precision on the bf16 matrix cores.  Results as s2vt_beam_step to fp32
+ * rounding (the fixtures' beam ids are unchanged). */
+int s2vt_beam_step_cached(const s2vt_dims* d, const s2vt_params* p, int32_t R, const int32_t* row_b, const int32_t* row_state,
+                          const int32_t* tok, const float* vid_h_in, const float* vid_c_in, float* vid_h_out, float* vid_c_out,
+                          const float* word_h_in, const float* word_c_in, float* word_h_out, float* word_c_out, int32_t* top_ix,
+                          float* top_lp, void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, void* stream);
 
 /* The reference's per-sample priority queues of the beam search (S2VTModel.py:186-238) ON THE DEVICE, all samples of the batch in one
  * launch per depth: heapq's own sift-down / sift-up replayed per sample (one lane each, heap in LDS), so that the pop order - also

@@ -88,7 +88,7 @@ def beam_search(model, feats, params, beam_width=3, max_depth=30):
     lib = capi.load()
     max_rows = max(B * beam_width, B)
     if DEVICE_QUEUES and lib.s2vt_beam_queue_bytes(B, beam_width, max_depth) > 0:
-        return _beam_search_device_queues(lib, feats, params, B, H, beam_width, max_depth, sos, eos, vid_h, vid_c, word_h, word_c)
+        return _beam_search_device_queues(lib, model, feats, params, B, H, beam_width, max_depth, sos, eos, vid_h, vid_c, word_h, word_c)
     queues = (BeamQueues if FAST_QUEUES else HeapQueues)(B, beam_width, sos, eos)
     pcs = tuple(p.contiguous() for p in (w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, w_f, b_f, w_o, b_o, emb))
     d = _dims(feats, pcs)
@@ -138,7 +138,10 @@ FAST_QUEUES = True
 DEVICE_QUEUES = True         # the queues on the device (csrc/beam_queue.hip): no host work and no transfer per depth
 
 
-def _beam_search_device_queues(lib, feats, params, B, H, beam_width, max_depth, sos, eos, vid_h, vid_c, word_h, word_c):
+PLANE_STEP = True            # s2vt_beam_step_cached: the depth's GEMMs on the plane path, from the decode cache of the same weights
+
+
+def _beam_search_device_queues(lib, model, feats, params, B, H, beam_width, max_depth, sos, eos, vid_h, vid_c, word_h, word_c):
     """The depth loop with the queue bookkeeping on the device: per depth ONE s2vt_beam_queue_step (push the children of the
     depth before, freeze finished samples, pop the next beam with heapq's own sift order, write the rows of the step) and ONE
     s2vt_beam_step over the fixed rows r = b * beam_width + slot; nothing crosses PCIe until the back-traced sequences at the
@@ -151,6 +154,18 @@ def _beam_search_device_queues(lib, feats, params, B, H, beam_width, max_depth, 
     pcs = tuple(p.detach().contiguous() for p in params)
     d = _dims(feats, pcs)
     ps = _params_struct(capi.Params, pcs)
+    # the weight-derived images of mode='test' (plane images of W_v / W_o, the per-token gate table) serve the beam's depth step
+    # as well; a model that has not decoded with these weights yet runs ONE greedy decode of this batch to fill them (7 ms, once
+    # per weight version - eval.py decodes the whole validation set with one set of weights)
+    from . import functional
+    cache = None
+    if PLANE_STEP:
+        cache, valid = functional.decode_cache_entry(model, params, d, dev, lib)
+        if cache is not None and not valid:
+            functional.greedy_decode(feats, params, sos, owner=model)
+            cache, valid = functional.decode_cache_entry(model, params, d, dev, lib)
+            if not valid:
+                cache = None
     with torch.cuda.device(dev):
         nbytes = lib.s2vt_beam_workspace_bytes(ctypes.byref(d), R)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -184,9 +199,15 @@ def _beam_search_device_queues(lib, feats, params, B, H, beam_width, max_depth, 
             events.append(ev)
             (vh_in, vc_in), (vh_out, vc_out) = vid[(depth - 1) & 1], vid[depth & 1]
             (wh_in, wc_in), (wh_out, wc_out) = tab[(depth - 1) & 1], tab[depth & 1]
-            capi.check(lib.s2vt_beam_step(ctypes.byref(d), ctypes.byref(ps), R, _ptr(rows[0]), _ptr(rows[1]), _ptr(rows[2]),
-                                          _ptr(vh_in), _ptr(vc_in), _ptr(vh_out), _ptr(vc_out), _ptr(wh_in), _ptr(wc_in),
-                                          _ptr(wh_out), _ptr(wc_out), _ptr(top_ix), _ptr(top_lp), _ptr(ws), nbytes, st), "s2vt_beam_step")
+            if cache is not None:
+                capi.check(lib.s2vt_beam_step_cached(ctypes.byref(d), ctypes.byref(ps), R, _ptr(rows[0]), _ptr(rows[1]), _ptr(rows[2]),
+                                                     _ptr(vh_in), _ptr(vc_in), _ptr(vh_out), _ptr(vc_out), _ptr(wh_in), _ptr(wc_in),
+                                                     _ptr(wh_out), _ptr(wc_out), _ptr(top_ix), _ptr(top_lp), _ptr(ws), nbytes,
+                                                     _ptr(cache), cache.numel(), st), "s2vt_beam_step_cached")
+            else:
+                capi.check(lib.s2vt_beam_step(ctypes.byref(d), ctypes.byref(ps), R, _ptr(rows[0]), _ptr(rows[1]), _ptr(rows[2]),
+                                              _ptr(vh_in), _ptr(vc_in), _ptr(vh_out), _ptr(vc_out), _ptr(wh_in), _ptr(wc_in),
+                                              _ptr(wh_out), _ptr(wc_out), _ptr(top_ix), _ptr(top_lp), _ptr(ws), nbytes, st), "s2vt_beam_step")
         qstep(0)                                        # the last depth's push
         cap = max_depth + 2
         out = torch.empty(B, cap, dtype=torch.int32, device=dev)

@@ -1500,6 +1500,7 @@ static DecodeConst carve_decode_const(const s2vt_dims& d, void* base) {
 struct BeamWS {
     float *bsum1, *bsum2, *ph, *pc, *gx, *logits, *gws;
     int* err;                // [0]: a token id outside [0, V) reached the word step (reported as S2VT_ERR_INDEX)
+    PB pvid, pword;          // plane path (s2vt_beam_step_cached): planes of vid_rnn's h [B rows] and of the word step's h_t [R rows]
     size_t gws_floats, bytes;
 };
 static BeamWS carve_beam(const s2vt_dims& d, int max_rows, void* base) {
@@ -1515,6 +1516,13 @@ static BeamWS carve_beam(const s2vt_dims& d, int max_rows, void* base) {
     w.gws_floats = 4 * R * (V > 4 * H ? V : 4 * H);
     w.gws = c.take<float>(w.gws_floats);
     w.err = c.take<int>(4);
+    {
+        const int kp = pad64((int)H);
+        w.pvid.kpad = w.pword.kpad = kp;
+        w.pvid.ld = w.pword.ld = 3 * (int64_t)kp;
+        w.pvid.p = c.take<unsigned short>(rows64((size_t)d.B) * (size_t)w.pvid.ld);
+        w.pword.p = c.take<unsigned short>(rows64(R) * (size_t)w.pword.ld);
+    }
     w.bytes = align_up(c.off, 256);
     return w;
 }
@@ -1524,10 +1532,29 @@ size_t s2vt_beam_workspace_bytes(const s2vt_dims* d, int32_t max_rows) {
     return carve_beam(*d, max_rows, nullptr).bytes;
 }
 
+static int beam_step_impl(const s2vt_dims* d, const s2vt_params* p, int32_t R, const int32_t* row_b, const int32_t* row_state,
+                          const int32_t* tok, const float* vid_h_in, const float* vid_c_in, float* vid_h_out, float* vid_c_out,
+                          const float* word_h_in, const float* word_c_in, float* word_h_out, float* word_c_out, int32_t* top_ix,
+                          float* top_lp, void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, void* stream);
 int s2vt_beam_step(const s2vt_dims* d, const s2vt_params* p, int32_t R, const int32_t* row_b, const int32_t* row_state,
                    const int32_t* tok, const float* vid_h_in, const float* vid_c_in, float* vid_h_out, float* vid_c_out,
                    const float* word_h_in, const float* word_c_in, float* word_h_out, float* word_c_out, int32_t* top_ix,
                    float* top_lp, void* workspace, size_t workspace_bytes, void* stream) {
+    return beam_step_impl(d, p, R, row_b, row_state, tok, vid_h_in, vid_c_in, vid_h_out, vid_c_out, word_h_in, word_c_in, word_h_out,
+                          word_c_out, top_ix, top_lp, workspace, workspace_bytes, nullptr, 0, stream);
+}
+int s2vt_beam_step_cached(const s2vt_dims* d, const s2vt_params* p, int32_t R, const int32_t* row_b, const int32_t* row_state,
+                          const int32_t* tok, const float* vid_h_in, const float* vid_c_in, float* vid_h_out, float* vid_c_out,
+                          const float* word_h_in, const float* word_c_in, float* word_h_out, float* word_c_out, int32_t* top_ix,
+                          float* top_lp, void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, void* stream) {
+    S2VT_REQUIRE(cache, "s2vt_beam_step_cached: null cache");
+    return beam_step_impl(d, p, R, row_b, row_state, tok, vid_h_in, vid_c_in, vid_h_out, vid_c_out, word_h_in, word_c_in, word_h_out,
+                          word_c_out, top_ix, top_lp, workspace, workspace_bytes, cache, cache_bytes, stream);
+}
+static int beam_step_impl(const s2vt_dims* d, const s2vt_params* p, int32_t R, const int32_t* row_b, const int32_t* row_state,
+                          const int32_t* tok, const float* vid_h_in, const float* vid_c_in, float* vid_h_out, float* vid_c_out,
+                          const float* word_h_in, const float* word_c_in, float* word_h_out, float* word_c_out, int32_t* top_ix,
+                          float* top_lp, void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, void* stream) {
     S2VT_REQUIRE(d && p && vid_h_in && vid_c_in && vid_h_out && vid_c_out && workspace, "s2vt_beam_step: null argument");
     S2VT_REQUIRE(R >= 0 && (R == 0 || (row_b && row_state && tok && word_h_in && word_c_in && word_h_out && word_c_out &&
                                         top_ix && top_lp)),
@@ -1554,6 +1581,34 @@ int s2vt_beam_step(const s2vt_dims* d, const s2vt_params* p, int32_t R, const in
     // with the embedding rows gathered inside the kernel's second K segment (:211-212)
     if ((rc = gather_rows_f32(st, word_h_in, H, row_state, R, H, w.ph))) return rc;
     if ((rc = gather_rows_f32(st, word_c_in, H, row_state, R, H, w.pc))) return rc;
+    if (cache && planes_ok(*d) && H <= 1024) {
+        // PLANE PATH (the weight-derived images of a greedy decode of the same weights, s2vt_greedy_decode_cached: W_v and W_o
+        // as blocked 3-plane operands, the per-token gate table): the vid_out half of the gate input once per SAMPLE (every beam
+        // slot reads its sample's row), the embedded word from the table, out_linear on the bf16 matrix cores in split
+        // precision (fp32-equivalent) from the h_t planes the step kernel writes itself
+        XP = 3;
+        S2VT_REQUIRE(cache_bytes >= carve_decode_const(*d, nullptr).bytes, "s2vt_beam_step_cached: cache too small");
+        const DecodeConst kc = carve_decode_const(*d, cache);
+        if ((rc = psplit(ln, w.pvid, 0, vid_h_out, H, ID, B, H))) return rc;
+        if ((rc = pgemm(ln, B, 4 * H, H, w.pvid, 0, 0, kc.wv, 0, 0, w.gx, 4 * H, ID, w.bsum2, false))) return rc;
+        if ((rc = fill_zero(st, w.pword.p, rows64((size_t)R) * (size_t)w.pword.ld * sizeof(unsigned short)))) return rc;
+        {
+            StepFwdArgs a = {};
+            a.B = R; a.H = H;
+            a.h_prev = w.ph; a.ldh = H; a.w_hh = p->word_w_hh; a.ldw = H;
+            a.gx_tab = kc.gtab; a.ldtab = 4 * (int64_t)H; a.tok_idx = tok;
+            a.tok_limit = V; a.tok_err = w.err;
+            a.gx = w.gx; a.ldgx = 4 * H; a.gx_idx = row_b;
+            a.c_prev = w.pc; a.ldc = H;
+            a.h_out = word_h_out; a.ldho = H; a.c_out = word_c_out; a.ldco = H;
+            a.h_planes = w.pword.p; a.ldhp = w.pword.ld;
+            if ((rc = fill_zero(st, w.err, 4 * sizeof(int)))) return rc;
+            if ((rc = lstm_step_fwd(st, a))) return rc;
+        }
+        if ((rc = pgemm(ln, R, V, H, w.pword, 0, 0, kc.wo, 0, 0, w.logits, V, ID, p->out_b, false))) return rc;
+        if ((rc = top20_logprob(st, w.logits, V, R, V, top_ix, top_lp))) return rc;
+        return post_async_error(st, w.err);
+    }
     if ((rc = lgemm(ln, true, true, R, 4 * H, H, vid_h_out, H, gather(row_b), p->word_w_ih + E, E + H, ID, w.gx, 4 * H, ID,
                     w.bsum2, false)))
         return rc;

@@ -54,6 +54,8 @@ struct StepFwdArgs {
     int tok_const;                           // one token for every row (<sos>); used when both null
     // pre-computed gate input (x-part + both biases) per batch row, or bias only
     const float* gx; int64_t ldgx;
+    const int32_t* gx_idx;                   // optional: batch row b reads gx row gx_idx[b] (beam search: every beam slot of a sample
+                                             // shares the sample's vid_rnn half of the gate input)
     const float* bias;                       // [4H], used when gx == nullptr
     const float* c_prev; int64_t ldc;        // nullptr: c = 0
     float* h_out; int64_t ldho;

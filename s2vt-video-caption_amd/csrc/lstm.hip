@@ -234,7 +234,7 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
     const bool evalid = (tid < TM * UN) && (eb < p.B) && (eunit < p.H);
     float gxv[4], cpv;
     {
-        const float* gsrc = p.gx ? p.gx + (int64_t)eb * p.ldgx : p.bias;
+        const float* gsrc = p.gx ? p.gx + (int64_t)((p.gx_idx && evalid) ? p.gx_idx[eb] : eb) * p.ldgx : p.bias;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float* q = (evalid && gsrc) ? gsrc + (int64_t)g * p.H + eunit : g_zero4;

@@ -185,6 +185,25 @@ def clear_decode_cache(model=None):
         _DECODE_CACHES.pop(model, None)
 
 
+def decode_cache_entry(owner, raw_params, d, dev, lib):
+    """(cache tensor, valid) of `owner`'s weight-derived decode images for the parameters as they stand, or (None, False) where
+    the cache does not apply (no owner, DECODE_CACHE off, a batch that is not a multiple of 64, fp32-MFMA mode).  valid = False:
+    the tensor is fresh and the next s2vt_greedy_decode_cached call must fill it (cache_valid = 0)."""
+    if owner is None or not DECODE_CACHE or d.B % 64 != 0 or lib.s2vt_set_gemm_mode(-1) == 0:
+        return None, False
+    # (the batch size, the recurrence mode and the pipeline block are NOT in the key: a filling call writes every
+    # image the cache holds, whichever of them its own batch / modes read - s2vt_greedy_decode_cached)
+    key = (tuple((p.data_ptr(), p._version) for p in raw_params), (d.L, d.F, d.H, d.E, d.V), lib.s2vt_set_gemm_mode(-1),
+           str(dev), torch.cuda.current_stream(dev).cuda_stream)
+    entry = _DECODE_CACHES.get(owner)
+    cbytes = lib.s2vt_decode_cache_bytes(ctypes.byref(d))
+    valid = entry is not None and entry[0] == key and entry[1].numel() >= cbytes
+    if not valid:
+        entry = (key, torch.empty(cbytes, dtype=torch.uint8, device=dev))
+        _DECODE_CACHES[owner] = entry
+    return entry[1], valid
+
+
 @torch.no_grad()
 def greedy_decode(feats, params, sos_ix, owner=None):
     """ids int64 [B, L-1] of S2VT.forward(mode='test').  `owner`: the module the parameters belong to (enables the
@@ -200,19 +219,10 @@ def greedy_decode(feats, params, sos_ix, owner=None):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         ids = torch.empty(d.B, d.L - 1, dtype=torch.int64, device=dev)
         ps = _params_struct(capi.Params, params)
-        if owner is not None and DECODE_CACHE and d.B % 64 == 0 and lib.s2vt_set_gemm_mode(-1) != 0:
-            # (the batch size, the recurrence mode and the pipeline block are NOT in the key: a filling call writes every
-            # image the cache holds, whichever of them its own batch / modes read - s2vt_greedy_decode_cached)
-            key = (tuple((p.data_ptr(), p._version) for p in raw), (d.L, d.F, d.H, d.E, d.V), lib.s2vt_set_gemm_mode(-1),
-                   str(dev), torch.cuda.current_stream(dev).cuda_stream)
-            entry = _DECODE_CACHES.get(owner)
-            cbytes = lib.s2vt_decode_cache_bytes(ctypes.byref(d))
-            valid = entry is not None and entry[0] == key and entry[1].numel() >= cbytes
-            if not valid:
-                entry = (key, torch.empty(cbytes, dtype=torch.uint8, device=dev))
-                _DECODE_CACHES[owner] = entry
+        cache, valid = decode_cache_entry(owner, raw, d, dev, lib)
+        if cache is not None:
             capi.check(lib.s2vt_greedy_decode_cached(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), int(sos_ix), _ptr(ids),
-                                                     _ptr(ws), nbytes, _ptr(entry[1]), entry[1].numel(), 1 if valid else 0,
+                                                     _ptr(ws), nbytes, _ptr(cache), cache.numel(), 1 if valid else 0,
                                                      _stream(dev)), "s2vt_greedy_decode_cached")
         else:
             capi.check(lib.s2vt_greedy_decode(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), int(sos_ix), _ptr(ids),
