@@ -72,6 +72,8 @@ SIGNATURES = {
                                     c_int32, c_void_p]),
     "s2vt_gemm_bf16_nt": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
                                     c_int64, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
+    "s2vt_gemm_bf16_tt": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                    c_int64, c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "s2vt_gemm_tune": (c_int32, [c_int32, c_int32, c_int32]),
     "s2vt_beam_queue_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "s2vt_beam_queue_step": (c_int32, [c_int32] * 6 + [c_void_p, c_size_t] + [c_void_p] * 6),

@@ -547,6 +547,8 @@ struct PlaneWS {
     PB feats, wf, x1, wih1, h1, we, wv, emb, h2r, wo, whh1, whh2;
     // backward
     PB dlog, woT, dlogT, h2decT, wvT, weT, wih1T, dg2, dg2T, h2T, h1T, embT, dg1, dg1T, x1T, dx1T, featsT, whh1T, whh2T;
+    PB h2decB;               // decode-step hidden states as ROW planes in batch-major order (the k order of dlogits' rows): dW_o's B operand
+                             // when the weight-gradient GEMMs read their operands transposed (tt_on())
     size_t bytes;
 };
 
@@ -574,6 +576,7 @@ static PlaneWS carve_planes(const s2vt_dims& d, void* base) {
     w.dg2T = mk(4 * H, T * B); w.h2T = mk(H, T * B); w.h1T = mk(H, T * B);   w.embT = mk(E, R);
     w.dg1 = mk(T * B, 4 * H); w.dg1T = mk(4 * H, T * B); w.x1T = mk(H, L * B); w.dx1T = mk(H, L * B);
     w.featsT = mk(F, L * B);
+    w.h2decB = mk(R, H);
     w.bytes = align_up(c.off, 256);
     return w;
 }
@@ -600,6 +603,22 @@ static int pgemm(const Lane& ln, int M, int N, int K, const PB& A, int a0, int k
     ProfScope ps(ln.s, K_GEMM, 1);
     return gemm_bf16_nt(ln.s, XP, M, N, pad64(K), A.p + (int64_t)a0 * A.ld + koff(ka), A.ld,
                         B.p + (int64_t)b0 * B.ld + koff(kb), B.ld, C, ldc, cm, bias, acc, ln.gws, ln.gws_floats);
+}
+
+// Split-precision mode: the weight-gradient GEMMs (dW = dG^T h, dW_o = dlogits^T h2) read BOTH operands transposed from the row
+// planes the forward / the BPTT hand-over already wrote (gemm_x3_kernel<4, true>), so the transposed twins of dG, dlogits, h, x1
+// and the embedded words are never written (S2VT_TT=0: round 3's transposed planes, for A/B timing)
+static bool tt_on() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("S2VT_TT"); on = e ? (atoi(e) != 0) : 1; }
+    return on != 0 && XP == 3;
+}
+// C[M,N] = A_img[a_row0 .., :M]^T . B_img[b_row0 .., :N] over K image rows (row offsets: multiples of 64)
+static int pgemm_tt(const Lane& ln, int M, int N, int K, const PB& A, int a_row0, const PB& B, int b_row0, float* C, int64_t ldc,
+                    RowMap cm, const float* bias, bool acc) {
+    ProfScope ps(ln.s, K_GEMM, 1);
+    return gemm_x3_tt(ln.s, M, N, K, A.p + (int64_t)a_row0 * A.ld, A.ld, B.p + (int64_t)b_row0 * B.ld, B.ld, C, ldc, cm, bias, acc,
+                      ln.gws, ln.gws_floats);
 }
 
 // bf16-operand layer forward over steps [t0, t1): hb = bf16 row images of h (time-major, ld = hb.ld), the k-major
@@ -815,12 +834,18 @@ static int check_forward_record(const void* ws, const s2vt_dims& d, bool planes,
 
 // out_mask: optional out_drop mask (S2VTModel.py:79), time-major [(L-1)*B, H], entries 0 or 1/(1-p); nullptr = no dropout.
 // The masked decode-step hidden states replace the row planes of the logits GEMM (the recurrence is done with them by then).
-static int masked_logits_planes(const Lane& ln, const TrainWS& w, const PlaneWS& q, const float* out_mask, int B, int L, int H) {
+// (tt_on(): the weight-gradient GEMMs read the UNMASKED rows of q.h2r transposed in the backward, so the masked rows go to the
+// scratch image q.h2decB - which the backward fills itself before it reads it - and *a_img / *a_row0 name the logits GEMM's operand)
+static bool tt_on();
+static int masked_logits_planes(const Lane& ln, const TrainWS& w, const PlaneWS& q, const float* out_mask, int B, int L, int H,
+                                const PB** a_img, int* a_row0) {
+    *a_img = &q.h2r; *a_row0 = L * B;
     if (!out_mask) return 0;
     const int R = (L - 1) * B;
     int rc;
     if ((rc = mul_vectors(ln.s, w.h2 + (int64_t)L * B * H, out_mask, w.dh2dec, (int64_t)R * H))) return rc;   // dh2dec: free in the forward
-    return psplit(ln, q.h2r, L * B, w.dh2dec, H, ID, R, H);
+    if (tt_on()) { *a_img = &q.h2decB; *a_row0 = 0; }
+    return psplit(ln, **a_img, *a_row0, w.dh2dec, H, ID, R, H);
 }
 
 static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
@@ -857,14 +882,15 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
     if ((rc = pdual(lb, p->word_w_ih, E + H, ID, 4 * H, E, &q.we, 0, &q.weT, 0, nullptr))) return rc;
     if ((rc = pdual(lb, p->word_w_ih + E, E + H, ID, 4 * H, H, &q.wv, 0, &q.wvT, 0, nullptr))) return rc;
     if ((rc = pdual(lb, p->out_w, H, ID, V, H, &q.wo, 0, &q.woT, 0, nullptr))) return rc;
-    if ((rc = pdual(lb, p->emb_w, E, gather(w.tok), R, E, &q.emb, 0, &q.embT, 0, nullptr))) return rc;
+    const bool tt = tt_on();
+    if ((rc = pdual(lb, p->emb_w, E, gather(w.tok), R, E, &q.emb, 0, tt ? nullptr : &q.embT, 0, nullptr))) return rc;
     if ((rc = pgemm(lb, R, 4 * H, E, q.emb, 0, 0, q.we, 0, 0, w.s2 + (int64_t)L * B4H, 4 * H, ID, w.bsum2, false))) return rc;
     // lane A: feature projection and vid_rnn input GEMM                       S2VTModel.py:54, 64-67
     if ((rc = psplit(la, q.feats, 0, feats, F, ID, B * L, F))) return rc;
     if ((rc = psplit(la, q.wf, 0, p->feat_w, F, ID, H, F))) return rc;
     if ((rc = pdual(la, p->vid_w_ih, H, ID, 4 * H, H, &q.wih1, 0, &q.wih1T, 0, nullptr))) return rc;
     if ((rc = pgemm(la, B * L, H, F, q.feats, 0, 0, q.wf, 0, 0, w.x1, H, perm(L, B), p->feat_b, false))) return rc;
-    if ((rc = pdual(la, w.x1, H, ID, L * B, H, &q.x1, 0, &q.x1T, 0, nullptr))) return rc;
+    if ((rc = pdual(la, w.x1, H, ID, L * B, H, &q.x1, 0, tt ? nullptr : &q.x1T, 0, nullptr))) return rc;
     if ((rc = pgemm(la, L * B, 4 * H, H, q.x1, 0, 0, q.wih1, 0, 0, w.s1, 4 * H, ID, w.bsum1, false))) return rc;
     const bool pbf_fwd = bf && blk > 0 && persist_fwd_ok(B, H, q.whh1, q.h1);
     const std::vector<int> bd = pipe_bounds(T, L, (pbf_fwd || px3_fwd) ? balanced_block(L, blk) : blk);
@@ -895,20 +921,22 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
             if (hw) {
                 const int t0 = bd[k - 1], t1 = bd[k];
                 const bool cap = t0 >= L;
-                if ((rc = pdual(la, w.h2 + t0 * BH, H, ID, (t1 - t0) * B, H, cap ? &q.h2r : nullptr, t0 * B, &q.h2T, t0 * B, nullptr)))
+                if ((rc = pdual(la, w.h2 + t0 * BH, H, ID, (t1 - t0) * B, H, (cap || tt) ? &q.h2r : nullptr, t0 * B, tt ? nullptr : &q.h2T,
+                                t0 * B, nullptr)))
                     return rc;
             }
             if (hv) {
                 const int t0 = bd[k], t1 = bd[k + 1];
                 const bool cap = t0 >= L;
-                if ((rc = pdual(la, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H, &q.h1, t0 * B, &q.h1T, t0 * B, nullptr))) return rc;
+                if ((rc = pdual(la, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H, &q.h1, t0 * B, tt ? nullptr : &q.h1T, t0 * B, nullptr))) return rc;
                 if ((rc = pgemm(la, (t1 - t0) * B, 4 * H, H, q.h1, t0 * B, 0, q.wv, 0, 0, w.s2 + t0 * B4H, 4 * H, ID,
                                 cap ? nullptr : w.bsum2, cap)))
                     return rc;
             }
         }
-        if ((rc = masked_logits_planes(la, w, q, out_mask, B, L, H))) return rc;
-        return pgemm(la, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
+        const PB* lg; int lg0;
+        if ((rc = masked_logits_planes(la, w, q, out_mask, B, L, H, &lg, &lg0))) return rc;
+        return pgemm(la, R, V, H, *lg, lg0, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
     }
     if (pbf_fwd) {
         // Persistent schedule, ONE stream: the launch of pipeline stage k runs vid_rnn block k next to word_rnn block k-1
@@ -940,8 +968,9 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
                     return rc;
             }
         }
-        if ((rc = masked_logits_planes(la, w, q, out_mask, B, L, H))) return rc;
-        return pgemm(la, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
+        const PB* lg; int lg0;
+        if ((rc = masked_logits_planes(la, w, q, out_mask, B, L, H, &lg, &lg0))) return rc;
+        return pgemm(la, R, V, H, *lg, lg0, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
     }
     for (size_t k = 0; k + 1 < bd.size(); ++k) {
         const int t0 = bd[k], t1 = bd[k + 1];
@@ -952,7 +981,7 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
         }
         if ((rc = handoff(st, sx, ev++))) return rc;
         const bool cap = t0 >= L;
-        if ((rc = pdual(lb, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H, bf ? nullptr : &q.h1, t0 * B, &q.h1T, t0 * B, nullptr)))
+        if ((rc = pdual(lb, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H, bf ? nullptr : &q.h1, t0 * B, tt ? nullptr : &q.h1T, t0 * B, nullptr)))
             return rc;
         if ((rc = pgemm(lb, (t1 - t0) * B, 4 * H, H, q.h1, t0 * B, 0, q.wv, 0, 0, w.s2 + t0 * B4H, 4 * H, ID,
                         cap ? nullptr : w.bsum2, cap)))
@@ -963,12 +992,13 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
             if ((rc = seq_fwd(sx, t0, t1, B, H, w.s2, T, w.bsum2, p->word_w_hh, w.h2, w.c2, true))) return rc;
         }
         // h2 planes: transposed (k = time-major row) for dW_hh2; row planes of the decode steps for the logits GEMM
-        if ((rc = pdual(lb, w.h2 + t0 * BH, H, ID, (t1 - t0) * B, H, (cap && !bf) ? &q.h2r : nullptr, t0 * B, &q.h2T,
+        if ((rc = pdual(lb, w.h2 + t0 * BH, H, ID, (t1 - t0) * B, H, ((cap || tt) && !bf) ? &q.h2r : nullptr, t0 * B, tt ? nullptr : &q.h2T,
                         t0 * B, nullptr)))
             return rc;
     }
-    if ((rc = masked_logits_planes(lb, w, q, out_mask, B, L, H))) return rc;
-    if ((rc = pgemm(lb, R, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false))) return rc;
+    const PB* lg; int lg0;
+    if ((rc = masked_logits_planes(lb, w, q, out_mask, B, L, H, &lg, &lg0))) return rc;
+    if ((rc = pgemm(lb, R, V, H, *lg, lg0, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false))) return rc;
     return handoff(sx, st, ev++);
 }
 
@@ -993,17 +1023,27 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     // lane A: dlogits planes in both orientations + its column sums (one read), gradient into the decode-step
     // hidden states (k = V), then word_rnn BPTT.  (W^T planes were written by the forward.)
     // (dlog_ready: s2vt_mean_ce_backward_fused wrote these planes and partial sums straight from the logits)
-    if (!dlog_ready && (rc = pdual(la, dlogits, V, ID, R, V, &q.dlog, 0, &q.dlogT, 0, w.colsum_c))) return rc;
+    const bool tt = tt_on();
+    if (!dlog_ready && (rc = pdual(la, dlogits, V, ID, R, V, &q.dlog, 0, tt ? nullptr : &q.dlogT, 0, w.colsum_c))) return rc;
     if ((rc = handoff(st, sx, ev++))) return rc;
     if ((rc = pgemm(la, R, H, V, q.dlog, 0, 0, q.woT, 0, 0, w.dh2dec, H, perm(L - 1, B), nullptr, false))) return rc;
     if (out_mask && (rc = mul_vectors(st, w.dh2dec, out_mask, w.dh2dec, (int64_t)R * H))) return rc;      // autograd of out_drop
     if ((rc = transpose_f32(st, p->word_w_hh, 4 * H, H, w.wt2))) return rc;
     // lane B meanwhile: out_linear weight/bias gradients (k = batch-major row index) and W_hh1^T
-    if (out_mask) {      // dW_o sees the masked hidden states (dx1 is free until the vid_rnn input gradient)
-        if ((rc = mul_vectors(sx, w.h2 + L * BH, out_mask, w.dx1, (int64_t)R * H))) return rc;
-        if ((rc = psplitT(lb, q.h2decT, 0, w.dx1, H, perm(L - 1, B), R, H))) return rc;
-    } else if ((rc = psplitT(lb, q.h2decT, 0, w.h2 + L * BH, H, perm(L - 1, B), R, H))) return rc;
-    if ((rc = pgemm(lb, V, H, R, q.dlogT, 0, 0, q.h2decT, 0, 0, g->out_w, H, ID, nullptr, false))) return rc;
+    {
+        const float* h2dec = w.h2 + L * BH;
+        if (out_mask) {      // dW_o sees the masked hidden states (dx1 is free until the vid_rnn input gradient)
+            if ((rc = mul_vectors(sx, w.h2 + L * BH, out_mask, w.dx1, (int64_t)R * H))) return rc;
+            h2dec = w.dx1;
+        }
+        if (tt) {            // rows in dlogits' (batch-major) order, read transposed by the GEMM
+            if ((rc = psplit(lb, q.h2decB, 0, h2dec, H, perm(L - 1, B), R, H))) return rc;
+            if ((rc = pgemm_tt(lb, V, H, R, q.dlog, 0, q.h2decB, 0, g->out_w, H, ID, nullptr, false))) return rc;
+        } else {
+            if ((rc = psplitT(lb, q.h2decT, 0, h2dec, H, perm(L - 1, B), R, H))) return rc;
+            if ((rc = pgemm(lb, V, H, R, q.dlogT, 0, 0, q.h2decT, 0, 0, g->out_w, H, ID, nullptr, false))) return rc;
+        }
+    }
     if ((rc = colsum_finish(sx, w.colsum_c, cdiv(R, 64), V, g->out_b, false))) return rc;
     if ((rc = grads_ready(0, sx))) return rc;
     if ((rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
@@ -1044,7 +1084,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
             }
             if (hw) {
                 const int t0 = bd[k], t1 = bd[k + 1];
-                if ((rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, &q.dg2, t0 * B, &q.dg2T, t0 * B,
+                if ((rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, &q.dg2, t0 * B, tt ? nullptr : &q.dg2T, t0 * B,
                                 w.colsum_a + (int64_t)(t0 * B / 64) * 4 * H)))
                     return rc;
                 if ((rc = pgemm(la, (t1 - t0) * B, H, 4 * H, q.dg2, t0 * B, 0, q.wvT, 0, 0, w.dh1 + t0 * BH, H, ID, nullptr, false)))
@@ -1052,8 +1092,8 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
             }
             if (hv) {
                 const int t0 = bd[k + 1], t1 = bd[k + 2];
-                if ((rc = pdual(la, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, (t0 < L) ? &q.dg1 : nullptr, t0 * B, &q.dg1T,
-                                t0 * B, w.colsum_b + (int64_t)(t0 * B / 64) * 4 * H)))
+                if ((rc = pdual(la, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, (t0 < L || tt) ? &q.dg1 : nullptr, t0 * B,
+                                tt ? nullptr : &q.dg1T, t0 * B, w.colsum_b + (int64_t)(t0 * B / 64) * 4 * H)))
                     return rc;
             }
         }
@@ -1119,7 +1159,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
         }
         // dG2 of this block: row planes (dh1, d-embedding GEMMs), transposed planes (weight gradients) and the
         // bias-gradient partial sums, all from one read
-        if ((rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, bf ? nullptr : &q.dg2, t0 * B, &q.dg2T, t0 * B,
+        if ((rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, bf ? nullptr : &q.dg2, t0 * B, tt ? nullptr : &q.dg2T, t0 * B,
                         w.colsum_a + (int64_t)(t0 * B / 64) * 4 * H)))
             return rc;
         if ((rc = pgemm(la, (t1 - t0) * B, H, 4 * H, q.dg2, t0 * B, 0, q.wvT, 0, 0, w.dh1 + t0 * BH, H, ID, nullptr, false)))
@@ -1132,16 +1172,22 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
         } else {
             if ((rc = seq_bwd(sx, T, t0, t1, B, H, w.wt1, w.dh1, 0, w.c1, w.s1, w.dc1))) return rc;
         }
-        if ((rc = pdual(lb, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, (t0 < L && !bf) ? &q.dg1 : nullptr, t0 * B, &q.dg1T,
-                        t0 * B, w.colsum_b + (int64_t)(t0 * B / 64) * 4 * H)))
+        if ((rc = pdual(lb, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, ((t0 < L || tt) && !bf) ? &q.dg1 : nullptr, t0 * B,
+                        tt ? nullptr : &q.dg1T, t0 * B, w.colsum_b + (int64_t)(t0 * B / 64) * 4 * H)))
             return rc;
     }
     if (px3_lanes && (rc = grads_ready(0, st))) return rc;         // (as behind the one-stream persistent schedules above)
     }
     // lane A: word_rnn parameter gradients + embedding gradient
+    if (tt) {            // dW = dG^T . (h | emb): row planes of both, read transposed
+        if ((rc = pgemm_tt(la, 4 * H, H, (T - 1) * B, q.dg2, B, q.h2r, 0, g->word_w_hh, H, ID, nullptr, false))) return rc;
+        if ((rc = pgemm_tt(la, 4 * H, H, T * B, q.dg2, 0, q.h1, 0, g->word_w_ih + E, E + H, ID, nullptr, false))) return rc;
+        if ((rc = pgemm_tt(la, 4 * H, E, R, q.dg2, L * B, q.emb, 0, g->word_w_ih, E + H, ID, nullptr, false))) return rc;
+    } else {
     if ((rc = pgemm(la, 4 * H, H, (T - 1) * B, q.dg2T, 0, B, q.h2T, 0, 0, g->word_w_hh, H, ID, nullptr, false))) return rc;
     if ((rc = pgemm(la, 4 * H, H, T * B, q.dg2T, 0, 0, q.h1T, 0, 0, g->word_w_ih + E, E + H, ID, nullptr, false))) return rc;
     if ((rc = pgemm(la, 4 * H, E, R, q.dg2T, 0, L * B, q.embT, 0, 0, g->word_w_ih, E + H, ID, nullptr, false))) return rc;
+    }
     if ((rc = colsum_finish(st, w.colsum_a, T * B / 64, 4 * H, g->word_b_ih, false))) return rc;
     S2VT_HIP(hipMemcpyAsync(g->word_b_hh, g->word_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
     if ((rc = pgemm(la, R, E, 4 * H, q.dg2, L * B, 0, q.weT, 0, 0, w.de, E, ID, nullptr, false))) return rc;
@@ -1151,8 +1197,13 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     // an experiment switch: two MFMA-bound GEMMs side by side share the chip, neither gets faster)
     static const bool serial_tail = getenv("S2VT_SERIAL_TAIL") && atoi(getenv("S2VT_SERIAL_TAIL")) != 0;
     const Lane lt = serial_tail ? Lane{st, w.gws_b, w.gws_floats, w.colsum_b} : lb;
+    if (tt) {
+        if ((rc = pgemm_tt(lt, 4 * H, H, (T - 1) * B, q.dg1, B, q.h1, 0, g->vid_w_hh, H, ID, nullptr, false))) return rc;
+        if ((rc = pgemm_tt(lt, 4 * H, H, L * B, q.dg1, 0, q.x1, 0, g->vid_w_ih, H, ID, nullptr, false))) return rc;
+    } else {
     if ((rc = pgemm(lt, 4 * H, H, (T - 1) * B, q.dg1T, 0, B, q.h1T, 0, 0, g->vid_w_hh, H, ID, nullptr, false))) return rc;
     if ((rc = pgemm(lt, 4 * H, H, L * B, q.dg1T, 0, 0, q.x1T, 0, 0, g->vid_w_ih, H, ID, nullptr, false))) return rc;
+    }
     if ((rc = colsum_finish(lt.s, w.colsum_b, T * B / 64, 4 * H, g->vid_b_ih, false))) return rc;
     S2VT_HIP(hipMemcpyAsync(g->vid_b_hh, g->vid_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, lt.s));
     if ((rc = pgemm(lt, L * B, H, 4 * H, q.dg1, 0, 0, q.wih1T, 0, 0, w.dx1, H, ID, nullptr, false))) return rc;
@@ -1733,14 +1784,18 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
     }
     // one word_rnn step on stream s (+ out_linear / argmax for a decode step): encode steps see a zero embedding (:84-86), decode
     // steps Emb[prev token] (:89-103)
-    auto word_step = [&](hipStream_t s, int t, const float* hprev, const float* cprev) -> int {
+    // (b0, nb): the batch rows [b0, b0 + nb) of the step - the whole batch, or one half of it when the decode runs as two
+    // independent chains on two streams (b0 a multiple of 64: the plane images are blocked by 64 rows)
+    auto word_step = [&](hipStream_t s, int t, const float* hprev, const float* cprev, int b0 = 0, int nb = -1) -> int {
         int r;
+        if (nb < 0) nb = B;
+        const int64_t o1 = (int64_t)b0 * H, o4 = 4 * o1;
         {
             ProfScope ps(s, K_STEP_FWD, 1);
             StepFwdArgs a;
             memset(&a, 0, sizeof(a));
-            a.B = B; a.H = H;
-            a.h_prev = hprev; a.ldh = H;
+            a.B = nb; a.H = H;
+            a.h_prev = hprev ? hprev + o1 : nullptr; a.ldh = H;
             a.w_hh = p->word_w_hh; a.ldw = H;
             if (t >= L) {
                 if (use_tab) {
@@ -1749,36 +1804,36 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
                     a.x2 = p->emb_w; a.ldx2 = E; a.K2 = E;
                     a.w2 = p->word_w_ih; a.ldw2 = E + H;
                 }
-                a.tok_packed = (t > L) ? w.packed + (int64_t)(t - L - 1) * B : nullptr;
+                a.tok_packed = (t > L) ? w.packed + (int64_t)(t - L - 1) * B + b0 : nullptr;
                 a.tok_const = sos_ix;
                 // the packed word is the previous step's argmax: a producer that left it unwritten would decode as token
                 // 0xFFFFFFFF - clamped and flagged (w.err[0], S2VT_ERR_INDEX) instead of read from beyond the table
                 a.tok_limit = V; a.tok_err = w.err;
             }
-            a.gx = w.gx2 + t * B4H; a.ldgx = 4 * (int64_t)H;
-            a.c_prev = cprev; a.ldc = H;
-            a.h_out = w.h2 + (t & 1) * BH; a.ldho = H;
-            a.c_out = w.c2; a.ldco = H;
-            if (t >= L && ax3) { a.h_planes = w.ph2.p; a.ldhp = w.ph2.ld; }
+            a.gx = w.gx2 + t * B4H + o4; a.ldgx = 4 * (int64_t)H;
+            a.c_prev = cprev ? cprev + o1 : nullptr; a.ldc = H;
+            a.h_out = w.h2 + (t & 1) * BH + o1; a.ldho = H;
+            a.c_out = w.c2 + o1; a.ldco = H;
+            if (t >= L && ax3) { a.h_planes = w.ph2.p + (int64_t)b0 * w.ph2.ld; a.ldhp = w.ph2.ld; }
             if ((r = lstm_step_fwd(s, a))) return r;
         }
         if (t >= L && ax3) {  // out_linear + argmax (:95-96, :105-106) on the bf16 matrix cores (argmax_x3.hip); the
             ProfScope ps(s, K_ARGMAX, 1);       // step kernel above wrote h_t as planes (StepFwdArgs::h_planes)
             ArgmaxX3Args ax;
-            ax.B = B; ax.V = V; ax.K = kc.wo.kpad;
+            ax.B = nb; ax.V = V; ax.K = kc.wo.kpad;
             ax.W = kc.wo.p; ax.ldw = kc.wo.ld;
-            ax.Hp = w.ph2.p; ax.ldh = w.ph2.ld;
+            ax.Hp = w.ph2.p + (int64_t)b0 * w.ph2.ld; ax.ldh = w.ph2.ld;
             ax.bias = p->out_b;
-            ax.packed = w.packed + (int64_t)(t - L) * B;
+            ax.packed = w.packed + (int64_t)(t - L) * B + b0;
             ax.dbg = 0; ax.stamps = nullptr;
             if ((r = logits_argmax_x3(s, ax))) return r;
         } else if (t >= L) {  // the same on the fp32-input MFMA (lstm.hip), for batches the plane path does not take
             ProfScope ps(s, K_ARGMAX, 1);
             LogitsArgmaxArgs la2;
-            la2.B = B; la2.H = H; la2.V = V;
-            la2.h = w.h2 + (t & 1) * BH; la2.ldh = H;
+            la2.B = nb; la2.H = H; la2.V = V;
+            la2.h = w.h2 + (t & 1) * BH + o1; la2.ldh = H;
             la2.w_out = p->out_w; la2.ldw = H; la2.b_out = p->out_b;
-            la2.packed = w.packed + (int64_t)(t - L) * B;
+            la2.packed = w.packed + (int64_t)(t - L) * B + b0;
             la2.stamps = nullptr;
             if ((r = logits_argmax(s, la2))) return r;
         }
@@ -1819,10 +1874,19 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
             if ((rc = lstm_seq_fwd_x3_persist2(st, av, nullptr))) return rc;
         }
         if ((rc = gx2_block(L, T))) return rc;
+        // The 79 token-dependent steps.  A decode step is two dependent launches (word_rnn step, out_linear + argmax) that
+        // each leave part of the chip idle (188 of 256 compute units in the argmax; launch gaps and tails between the two) and
+        // batch rows never interact: at B % 128 == 0 the two halves of the batch run as two INDEPENDENT chains on the two
+        // streams, so one half's step kernel fills the other half's gaps (S2VT_DECODE_HALVES=0: one chain)
+        static const bool halves_off = getenv("S2VT_DECODE_HALVES") && atoi(getenv("S2VT_DECODE_HALVES")) == 0;
+        const int nh = (!halves_off && ax3 && B % 128 == 0 && sx != st) ? 2 : 1;
+        if (nh == 2 && (rc = handoff(st, sx, ev++))) return rc;
         for (int t = L; t < T; ++t)
-            if ((rc = word_step(st, t, t == L ? w.h2_all + (int64_t)(L - 1) * BH : w.h2 + ((t - 1) & 1) * BH,
-                                t == L ? w.c2_all + (int64_t)(L - 1) * BH : w.c2)))
-                return rc;
+            for (int hf = 0; hf < nh; ++hf)
+                if ((rc = word_step(hf ? sx : st, t, t == L ? w.h2_all + (int64_t)(L - 1) * BH : w.h2 + ((t - 1) & 1) * BH,
+                                    t == L ? w.c2_all + (int64_t)(L - 1) * BH : w.c2, hf * (B / nh), B / nh)))
+                    return rc;
+        if (nh == 2 && (rc = handoff(sx, st, ev++))) return rc;
         if ((rc = unpack_tokens(st, w.packed, L - 1, B, ids))) return rc;
         return post_async_error(st, w.err);                   // (a timed-out hand-off surfaces like the train path's)
     }
@@ -1916,8 +1980,9 @@ int s2vt_mean_ce_backward_fused(const s2vt_dims* d, const float* logits, const i
     int rc;
     {
         ProfScope ps(st, K_CE, 1);
-        if ((rc = split_planes_dual(st, XP, logits, V, ID, R, V, q.dlog.p, q.dlog.ld, q.dlog.kpad, q.dlogT.p + koff(0), q.dlogT.ld, pad64(R),
-                                    w.colsum_c, &ce)))
+        const bool tt = tt_on();
+        if ((rc = split_planes_dual(st, XP, logits, V, ID, R, V, q.dlog.p, q.dlog.ld, q.dlog.kpad, tt ? nullptr : q.dlogT.p + koff(0),
+                                    tt ? 0 : q.dlogT.ld, tt ? 0 : pad64(R), w.colsum_c, &ce)))
             return rc;
     }
     std::lock_guard<std::mutex> lock(g_fwd_mutex);
@@ -1952,6 +2017,14 @@ int s2vt_gemm_bf16_nt(int32_t nplanes, int32_t M, int32_t N, int32_t K, const ui
     ProfScope ps((hipStream_t)stream, K_GEMM, 1);
     return gemm_bf16_nt((hipStream_t)stream, nplanes, M, N, K, A, lda, B, ldb, C, ldc, ID, bias, accumulate != 0, ws,
                         ws_floats);
+}
+
+int s2vt_gemm_bf16_tt(int32_t nplanes, int32_t M, int32_t N, int32_t K, const uint16_t* A, int64_t lda, const uint16_t* B,
+                      int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t accumulate, float* ws, size_t ws_floats,
+                      void* stream) {
+    S2VT_REQUIRE(nplanes == 3, "s2vt_gemm_bf16_tt: only the split-precision (3-plane) operands have the transposed-read form");
+    ProfScope ps((hipStream_t)stream, K_GEMM, 1);
+    return gemm_x3_tt((hipStream_t)stream, M, N, K, A, lda, B, ldb, C, ldc, ID, bias, accumulate != 0, ws, ws_floats);
 }
 
 int s2vt_feat_proj_fwd(const s2vt_dims* d, const float* feats, const float* w, const float* bias, float* x1,

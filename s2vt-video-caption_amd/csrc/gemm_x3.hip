@@ -27,6 +27,7 @@
 namespace s2vt {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int X_REC = 6144;                // bytes of one (64-row block, k16 chunk) record: 6 pieces x 1 KB
 constexpr int X_NS = 3;                    // ring depth
@@ -59,8 +60,17 @@ __device__ __forceinline__ void quad_transpose4(float& a0, float& a1, float& a2,
 
 // MI = 32-row MFMA tiles per wave in M: workgroup tile (64 MI) x 256, wave tile (32 MI) x 64.  The A operand fills MI 64-row
 // records of a stage, the B operand always four.
-template <int MI>
+// TT = true: BOTH operands are read TRANSPOSED from the row images of their source tensors - C[M,N] = A^T B with A stored
+// as the blocked planes of X_A [K rows][M columns] and B as those of X_B [K rows][N columns] (k = the images' ROWS: the
+// weight-gradient GEMMs dW = dG^T h, whose operands the recurrence / the row split already wrote as row planes; no transposed
+// twin of dG / dlogits / h is ever written).  A k16 stage is then a QUARTER of a 64-row block: per (plane, 32 columns) a 1-KB
+// block [16 k rows][2 chunks x 2 halves x 16 B], gathered by ONE LDS-DMA instruction from four 256-B runs of the image (lane ->
+// (row, chunk parity, half): constant per-lane offset, everything else in the scalar offset), and a fragment is two
+// ds_read_b64_tr_b16 per lane (4 k rows x 16 columns each, transposed by the LDS hardware): a half-wave reads 4 rows x 64 B =
+// 256 contiguous bytes, conflict-free.  Same bytes staged, twice the (half-size) fragment reads, same MFMAs, same epilogue.
+template <int MI, bool TT>
 __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
+    static_assert(!TT || MI == 4, "the transposed-read variant is built for 256-row tiles (6 requests per wave and stage)");
     constexpr int NRA = MI, TMR = 64 * MI, X_STAGE = (NRA + 4) * X_REC;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[X_NS * X_STAGE];
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address
@@ -94,6 +104,18 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
     // range; a request = (descriptor, lane * 16, scalar offset of stage and piece)
     const bool loader = wave < NRA + 4;
     auto rsrc_of = [&](int m0, int n0) {
+        if constexpr (TT) {
+            // waves 0-3: the A image's columns m0.., waves 4-7: the B image's columns n0..; descriptor = the image from the k
+            // range's first row block and the tile's first column chunk on
+            const bool isA = wave < 4;
+            const unsigned short* base = isA ? p.A : p.B;
+            const int64_t ld = isA ? p.lda : p.ldb;
+            const int c0 = (isA ? m0 : n0) >> 4;
+            const int64_t off = (int64_t)(kbeg >> 6) * 64 * ld + (int64_t)c0 * (X_REC / 2);
+            int64_t bytes = ((int64_t)((kend - kbeg) >> 6) * 64 * ld - (int64_t)c0 * (X_REC / 2)) * 2;
+            if (bytes > 0xFFFFF000ll) bytes = 0xFFFFF000ll;
+            return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base + off), 0, (int)bytes, 0x00020000);
+        }
         const bool isA = wave < NRA;
         const int nrb = ((isA ? p.M : p.N) + 63) >> 6;
         int rb = isA ? (m0 >> 6) + wave : (n0 >> 6) + (wave - NRA);
@@ -103,11 +125,19 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(base + (int64_t)rb * 64 * ld + (int64_t)(kbeg >> 4) * (X_REC / 2)), 0,
                                                  nk * X_REC, 0x00020000);
     };
-    const int vlane = lane * 16;
-    // piece J of stage `st` (of the tile behind descriptor R) -> ring slot SLOT
+    const int vlane = TT ? ((lane >> 1) & 1) * X_REC + (lane & 1) * 1024 + (lane >> 2) * 16 : lane * 16;
+    const int64_t tt_ld2 = (wave < 4 ? p.lda : p.ldb) * 128;        // bytes between two 64-row blocks of this wave's image (TT)
+    // piece J of stage `st` (of the tile behind descriptor R) -> ring slot SLOT.  TT: request J of a wave = (column pair 2 (w & 3) +
+    // J / 3, plane J % 3) of its operand: image offset = column pair x 2 records + plane x 2 KB + row quarter x 256 B + row block
 #define X3_REQ1(J, R, ST, SLOT)                                                                                           \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(R, (__attribute__((address_space(3))) void*)(smem + (SLOT) * X_STAGE + wave * X_REC + (J) * 1024), \
-                                             16, vlane, (ST) * X_REC + (J) * 1024, 0, 0);
+    if constexpr (TT) {                                                                                                   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(R, (__attribute__((address_space(3))) void*)(smem + (SLOT) * X_STAGE + (wave >> 2) * (4 * X_REC) + \
+                                                     ((2 * (wave & 3) + (J) / 3) * 3 + (J) % 3) * 1024),                  \
+                                                 16, vlane, (int)(((ST) >> 2) * tt_ld2) + (2 * (wave & 3) + (J) / 3) * 2 * X_REC + ((J) % 3) * 2048 + ((ST) & 3) * 256, 0, 0); \
+    } else {                                                                                                              \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(R, (__attribute__((address_space(3))) void*)(smem + (SLOT) * X_STAGE + wave * X_REC + (J) * 1024), \
+                                                 16, vlane, (ST) * X_REC + (J) * 1024, 0, 0);                             \
+    }
 
     f32x16 acc[MI][2];
 
@@ -120,6 +150,13 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
         la[mi] = lbase + (unsigned)((x >> 1) * X_REC + (x & 1) * 512 + lh * 1024 + li * 16);
     }
     const unsigned lb = lbase + (unsigned)((NRA + wn) * X_REC + lh * 1024 + li * 16);
+    // TT: lane (li, lh) of a 32-column tile: 16-lane group g = li / 16 (chunk parity), row q = (li % 16) / 4 of a 4-row block, 8-byte
+    // part p = li % 4 of the group's 32 bytes; k rows 8 lh + 4 j + q (j = 0, 1: the two transposed reads of a fragment)
+    const unsigned tt_lane = (unsigned)((8 * lh + ((li & 15) >> 2)) * 64 + (li >> 4) * 32 + (li & 3) * 8);
+    const unsigned lb_t = lbase + tt_lane + (unsigned)(4 * X_REC + wn * 2 * 3072);
+    unsigned lat[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) lat[mi] = lbase + tt_lane + (unsigned)((wm * MI + mi) * 3072);
 
     // One k16 stage of the running ring (g counts stages across tiles: slot g % 3).  more: stage g + 2 exists - of this tile or
     // of the workgroup's next one (descriptor r2, stage index s2 there) - and is requested while this one is multiplied;
@@ -144,8 +181,20 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
         // before the first MFMA (lgkmcnt(0)), the counted waits start each product group when ITS operands are in.
         // (LDS returns in order; nothing else in the loop uses lgkmcnt.)
 #define X3_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF));
-#define X3_LDA(PL) _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) { X3_RD(a[PL][mi], la[mi] + so, (PL) * 2048) }
-#define X3_LDB(PL) { const unsigned b_ = lb + so; X3_RD(b[PL][0], b_, (PL) * 2048) X3_RD(b[PL][1], b_, (PL) * 2048 + 512) }
+        // transposed fragment: two 8-byte reads (k rows +0..3, +4..7 of the lane's half) -> the 8 k values of the MFMA operand
+#define X3_RDT(DST, ADDR, OFF)                                                                                               \
+    {                                                                                                                        \
+        bf16x4 lo_, hi_;                                                                                                     \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo_) : "v"(ADDR), "n"(OFF));                               \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi_) : "v"(ADDR), "n"((OFF) + 256));                       \
+        DST = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);                                                     \
+    }
+#define X3_LDA(PL)                                                                                                           \
+    if constexpr (TT) { _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) { X3_RDT(a[PL][mi], lat[mi] + so, (PL) * 1024) } } \
+    else { _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) { X3_RD(a[PL][mi], la[mi] + so, (PL) * 2048) } }
+#define X3_LDB(PL)                                                                                                           \
+    if constexpr (TT) { const unsigned b_ = lb_t + so; X3_RDT(b[PL][0], b_, (PL) * 1024) X3_RDT(b[PL][1], b_, (3 + (PL)) * 1024) } \
+    else { const unsigned b_ = lb + so; X3_RD(b[PL][0], b_, (PL) * 2048) X3_RD(b[PL][1], b_, (PL) * 2048 + 512) }
         // wait until at most N reads are outstanding; the empty statements tie the fragments to the wait
 #define X3_WAIT(N, PA, PB)                                                                                     \
     {                                                                                                          \
@@ -155,7 +204,9 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
         asm volatile("" : "+v"(b[PB][1]));                                                                     \
     }
         __builtin_amdgcn_sched_barrier(0);
-        X3_LDA(1) X3_LDB(1) X3_LDA(0) X3_LDB(2) X3_LDA(2) X3_LDB(0)
+        X3_LDA(1) X3_LDB(1) X3_LDA(0) X3_LDB(2)
+        if constexpr (!TT) { X3_LDA(2) X3_LDB(0) }      // (TT: 12 half-size reads per pair - the third pair follows the first product group,
+                                                        //  the LGKM counter holds 15)
         // six plane products, smallest terms first; product-major order keeps 2 MI independent MFMAs between two updates of the
         // same accumulator.  The DMA requests of stage g + 2 are spread over the MFMA groups: issuing one costs the wave ~100
         // cycles, which a running MFMA group of its SIMD partner hides (the partner-staggered issue that gemm_b1_kernel uses -
@@ -179,9 +230,16 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
         }
         if (req) { X3_REQ1(5, r2, s2, slot2) }
         __builtin_amdgcn_sched_barrier(0);
-        X3_GROUP(2 * (MI + 2), 1, 1, 0, true)
-        X3_GROUP(MI + 2, 0, 2, 1, true)
-        X3_GROUP(0, 2, 0, 2, true)
+        if constexpr (TT) {
+            X3_GROUP(2 * (MI + 2), 1, 1, 0, true)
+            X3_LDA(2) X3_LDB(0)
+            X3_GROUP(2 * (MI + 2), 0, 2, 1, true)
+            X3_GROUP(0, 2, 0, 2, true)
+        } else {
+            X3_GROUP(2 * (MI + 2), 1, 1, 0, true)
+            X3_GROUP(MI + 2, 0, 2, 1, true)
+            X3_GROUP(0, 2, 0, 2, true)
+        }
         X3_GROUP(0, 0, 1, 3, false)
         X3_GROUP(0, 1, 0, 4, false)
 #pragma unroll
@@ -191,6 +249,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
 #undef X3_PROD
 #undef X3_WAIT
 #undef X3_RD
+#undef X3_RDT
 #undef X3_LDA
 #undef X3_LDB
     };
@@ -326,11 +385,32 @@ void gemm_x3_tune(int tile_rows, int nsplit) {
     g_x3_force_n = nsplit > 0 ? nsplit : 0;
 }
 
+static int gemm_x3_impl(hipStream_t stream, bool tt, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
+                       int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
+                       size_t splitk_ws_floats);
 // A, B: blocked 3-plane operands (see the header of this file); K = their common padded k extent for this call.
 int gemm_x3(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
             int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
             size_t splitk_ws_floats) {
+    return gemm_x3_impl(stream, false, M, N, K, A, lda, B, ldb, C, ldc, cmap, bias, accumulate, splitk_ws, splitk_ws_floats);
+}
+// C[M,N] (+)= X_A^T X_B: A / B = blocked 3-plane ROW images of X_A [K rows][M columns] (lda >= 3 pad64(M)) and X_B [K rows][N
+// columns], both starting at a 64-row block; K = rows contracted (a multiple of 64)
+int gemm_x3_tt(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
+               int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
+               size_t splitk_ws_floats) {
+    return gemm_x3_impl(stream, true, M, N, K, A, lda, B, ldb, C, ldc, cmap, bias, accumulate, splitk_ws, splitk_ws_floats);
+}
+static int gemm_x3_impl(hipStream_t stream, bool tt, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
+                       int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
+                       size_t splitk_ws_floats) {
     if (M <= 0 || N <= 0) return 0;
+    if (tt) {
+        S2VT_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= 3 * (int64_t)((M + 63) / 64 * 64) &&
+                         ldb >= 3 * (int64_t)((N + 63) / 64 * 64) && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (int64_t)K * lda * 2 < (1ll << 32) && (int64_t)K * ldb * 2 < (1ll << 32),
+                     "gemm_x3_tt: K (image rows) must be a multiple of 64, the row images hold pad64(M) / pad64(N) columns, < 4 GB each");
+    } else
     S2VT_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= 3 * (int64_t)K && ldb >= 3 * (int64_t)K &&
                      (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0,
                  "gemm_x3: K must be the zero-padded multiple of 64 of the blocked plane layout, operands 16-B aligned");
@@ -359,7 +439,7 @@ int gemm_x3(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
     static const int order[3] = {4, 3, 2};
     for (int oi = 0; oi < 3; ++oi) {
         const int mi = order[oi];
-        if (force_mi && force_mi != mi) continue;
+        if (tt ? mi != 4 : (force_mi && force_mi != mi)) continue;
         const int tiles = cdiv(M, 64 * mi) * ntn;
         for (int n = 1; n <= 16; ++n) {
             if (n > 1 && (!splitk_ws || K < 512 || K / n < 256 || (size_t)n * M * N > splitk_ws_floats)) break;
@@ -386,10 +466,14 @@ int gemm_x3(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
     const int nsplit = (best_ns > 1) ? cdiv(K, p.ksplit) : 1;
     p.slabs = (nsplit > 1) ? splitk_ws : nullptr;
     const dim3 grid(best_g, nsplit);
-    switch (best_mi) {
-        case 2: hipLaunchKernelGGL(gemm_x3_kernel<2>, grid, dim3(512), 0, stream, p); break;
-        case 3: hipLaunchKernelGGL(gemm_x3_kernel<3>, grid, dim3(512), 0, stream, p); break;
-        default: hipLaunchKernelGGL(gemm_x3_kernel<4>, grid, dim3(512), 0, stream, p); break;
+    if (tt) {
+        hipLaunchKernelGGL((gemm_x3_kernel<4, true>), grid, dim3(512), 0, stream, p);
+    } else {
+        switch (best_mi) {
+            case 2: hipLaunchKernelGGL((gemm_x3_kernel<2, false>), grid, dim3(512), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL((gemm_x3_kernel<3, false>), grid, dim3(512), 0, stream, p); break;
+            default: hipLaunchKernelGGL((gemm_x3_kernel<4, false>), grid, dim3(512), 0, stream, p); break;
+        }
     }
     S2VT_LAUNCH_CHECK("gemm_x3_kernel");
     if (nsplit > 1) return splitk_reduce(stream, splitk_ws, nsplit, M, N, C, ldc, cmap, bias, accumulate);

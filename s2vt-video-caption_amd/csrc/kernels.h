@@ -18,6 +18,10 @@ int gemm_bf16_nt(hipStream_t stream, int nplanes, int M, int N, int K, const uns
 int gemm_x3(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
             int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
             size_t splitk_ws_floats);
+// C[M,N] (+)= X_A^T X_B from the blocked ROW-plane images of X_A [K][M], X_B [K][N] (transposed fragment reads, gemm_x3.hip)
+int gemm_x3_tt(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
+               int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
+               size_t splitk_ws_floats);
 // plain bf16 GEMM on bf16 rows with LDS-DMA staging (gemm_b1.hip); gemm_bf16_nt(nplanes = 1) forwards here
 int gemm_b1(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
             int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
