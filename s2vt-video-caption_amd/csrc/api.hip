@@ -1206,13 +1206,21 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     }
     if ((rc = colsum_finish(lt.s, w.colsum_b, T * B / 64, 4 * H, g->vid_b_ih, false))) return rc;
     S2VT_HIP(hipMemcpyAsync(g->vid_b_hh, g->vid_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, lt.s));
+    if (tt) {
+        // dx1 comes out in BATCH-major row order (the order of feats' rows, whose row planes the forward wrote): dW_f = dx1^T feats
+        // reads both transposed - no time-major transposed copy of the features, no transposed dx1 (q.x1 is free: dW_ih1 is done)
+        if ((rc = pgemm(lt, L * B, H, 4 * H, q.dg1, 0, 0, q.wih1T, 0, 0, w.dx1, H, perm(B, L), nullptr, false))) return rc;
+        if ((rc = pdual(lt, w.dx1, H, ID, L * B, H, &q.x1, 0, nullptr, 0, w.colsum_b))) return rc;
+        if ((rc = pgemm_tt(lt, H, F, L * B, q.x1, 0, q.feats, 0, g->feat_w, F, ID, nullptr, false))) return rc;
+    } else {
     if ((rc = pgemm(lt, L * B, H, 4 * H, q.dg1, 0, 0, q.wih1T, 0, 0, w.dx1, H, ID, nullptr, false))) return rc;
     if ((rc = pdual(lt, w.dx1, H, ID, L * B, H, nullptr, 0, &q.dx1T, 0, w.colsum_b))) return rc;
     if ((rc = psplitT(lt, q.featsT, 0, feats, F, perm(B, L), L * B, F))) return rc;
     if ((rc = pgemm(lt, H, F, L * B, q.dx1T, 0, 0, q.featsT, 0, 0, g->feat_w, F, ID, nullptr, false))) return rc;
+    }
     if ((rc = colsum_finish(lt.s, w.colsum_b, L * B / 64, H, g->feat_b, false))) return rc;
     if (dfeats) {   // rarely requested (nothing reads it in the reference): fp32-MFMA GEMM
-        if ((rc = lgemm(lt, true, false, L * B, F, H, w.dx1, H, ID, p->feat_w, F, ID, dfeats, F, perm(B, L), nullptr, false)))
+        if ((rc = lgemm(lt, true, false, L * B, F, H, w.dx1, H, ID, p->feat_w, F, ID, dfeats, F, tt ? ID : perm(B, L), nullptr, false)))
             return rc;
     }
     return handoff(sx, st, ev++);
