@@ -228,7 +228,7 @@ int s2vt_gemm_bf16_nt(int32_t nplanes, int32_t M, int32_t N, int32_t K, const ui
  * above) of X_A [K rows][M columns], B = that of X_B [K rows][N columns], both starting at a 64-row block; K (a multiple of 64)
  * image rows are contracted.  The kernel reads its fragments transposed (ds_read_b64_tr_b16), so dG / dlogits / h are split ONCE,
  * as rows, and serve both the data-gradient GEMMs (as A[M,K]) and the weight-gradient GEMMs (autograd of S2VTModel.py:54,67,77,80).
- * nplanes = 3 only. */
+ * nplanes = 1: the same from plain bf16 row images (rows of at least M / N columns). */
 int s2vt_gemm_bf16_tt(int32_t nplanes, int32_t M, int32_t N, int32_t K, const uint16_t* A, int64_t lda, const uint16_t* B,
                       int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t accumulate, float* ws, size_t ws_floats,
                       void* stream);

@@ -593,6 +593,7 @@ static int psplitT(const Lane& ln, const PB& dst, int k0, const float* in, int64
 // 64-row partial column sums into colpart (each may be null)
 static int pdual(const Lane& ln, const float* in, int64_t ld, RowMap imap, int rows, int cols, const PB* r, int r0,
                  const PB* t, int k0, float* colpart) {
+    if (!r && !t && !colpart) return 0;          // (bf16 mode with transposed-read GEMMs: the recurrence kernels wrote the rows already)
     return split_planes_dual(ln.s, XP, in, ld, imap, rows, cols, r ? r->p + (int64_t)r0 * r->ld : nullptr, r ? r->ld : 0,
                              r ? r->kpad : 0, t ? t->p + koff(k0) : nullptr, t ? t->ld : 0, t ? pad64(rows) : 0,
                              colpart);
@@ -611,12 +612,15 @@ static int pgemm(const Lane& ln, int M, int N, int K, const PB& A, int a0, int k
 static bool tt_on() {
     static int on = -1;
     if (on < 0) { const char* e = getenv("S2VT_TT"); on = e ? (atoi(e) != 0) : 1; }
-    return on != 0 && XP == 3;
+    return on != 0;
 }
 // C[M,N] = A_img[a_row0 .., :M]^T . B_img[b_row0 .., :N] over K image rows (row offsets: multiples of 64)
 static int pgemm_tt(const Lane& ln, int M, int N, int K, const PB& A, int a_row0, const PB& B, int b_row0, float* C, int64_t ldc,
                     RowMap cm, const float* bias, bool acc) {
     ProfScope ps(ln.s, K_GEMM, 1);
+    if (XP == 1)
+        return gemm_b1_tt(ln.s, M, N, K, A.p + (int64_t)a_row0 * A.ld, A.ld, B.p + (int64_t)b_row0 * B.ld, B.ld, C, ldc, cm, bias, acc,
+                          ln.gws, ln.gws_floats);
     return gemm_x3_tt(ln.s, M, N, K, A.p + (int64_t)a_row0 * A.ld, A.ld, B.p + (int64_t)b_row0 * B.ld, B.ld, C, ldc, cm, bias, acc,
                       ln.gws, ln.gws_floats);
 }
@@ -957,12 +961,12 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
             }
             if (hw) {   // h2 of word block k-1: transposed planes for dW_hh2 (the row planes were written by the kernel)
                 const int t0 = bd[k - 1], t1 = bd[k];
-                if ((rc = pdual(la, w.h2 + t0 * BH, H, ID, (t1 - t0) * B, H, nullptr, t0 * B, &q.h2T, t0 * B, nullptr))) return rc;
+                if ((rc = pdual(la, w.h2 + t0 * BH, H, ID, (t1 - t0) * B, H, nullptr, t0 * B, tt ? nullptr : &q.h2T, t0 * B, nullptr))) return rc;
             }
             if (hv) {   // vid_out half of the word_rnn gate input for block k
                 const int t0 = bd[k], t1 = bd[k + 1];
                 const bool cap = t0 >= L;
-                if ((rc = pdual(la, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H, nullptr, t0 * B, &q.h1T, t0 * B, nullptr))) return rc;
+                if ((rc = pdual(la, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H, nullptr, t0 * B, tt ? nullptr : &q.h1T, t0 * B, nullptr))) return rc;
                 if ((rc = pgemm(la, (t1 - t0) * B, 4 * H, H, q.h1, t0 * B, 0, q.wv, 0, 0, w.s2 + t0 * B4H, 4 * H, ID,
                                 cap ? nullptr : w.bsum2, cap)))
                     return rc;
@@ -1118,7 +1122,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
             }
             if (hw) {
                 const int t0 = bd[k], t1 = bd[k + 1];
-                if ((rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, nullptr, t0 * B, &q.dg2T, t0 * B,
+                if ((rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, nullptr, t0 * B, tt ? nullptr : &q.dg2T, t0 * B,
                                 w.colsum_a + (int64_t)(t0 * B / 64) * 4 * H)))
                     return rc;
                 if ((rc = pgemm(la, (t1 - t0) * B, H, 4 * H, q.dg2, t0 * B, 0, q.wvT, 0, 0, w.dh1 + t0 * BH, H, ID, nullptr, false)))
@@ -1126,7 +1130,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
             }
             if (hv) {
                 const int t0 = bd[k + 1], t1 = bd[k + 2];
-                if ((rc = pdual(la, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, nullptr, t0 * B, &q.dg1T, t0 * B,
+                if ((rc = pdual(la, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, nullptr, t0 * B, tt ? nullptr : &q.dg1T, t0 * B,
                                 w.colsum_b + (int64_t)(t0 * B / 64) * 4 * H)))
                     return rc;
             }
@@ -2030,8 +2034,9 @@ int s2vt_gemm_bf16_nt(int32_t nplanes, int32_t M, int32_t N, int32_t K, const ui
 int s2vt_gemm_bf16_tt(int32_t nplanes, int32_t M, int32_t N, int32_t K, const uint16_t* A, int64_t lda, const uint16_t* B,
                       int64_t ldb, float* C, int64_t ldc, const float* bias, int32_t accumulate, float* ws, size_t ws_floats,
                       void* stream) {
-    S2VT_REQUIRE(nplanes == 3, "s2vt_gemm_bf16_tt: only the split-precision (3-plane) operands have the transposed-read form");
+    S2VT_REQUIRE(nplanes == 3 || nplanes == 1, "s2vt_gemm_bf16_tt: planes must be 1 or 3");
     ProfScope ps((hipStream_t)stream, K_GEMM, 1);
+    if (nplanes == 1) return gemm_b1_tt((hipStream_t)stream, M, N, K, A, lda, B, ldb, C, ldc, ID, bias, accumulate != 0, ws, ws_floats);
     return gemm_x3_tt((hipStream_t)stream, M, N, K, A, lda, B, ldb, C, ldc, ID, bias, accumulate != 0, ws, ws_floats);
 }
 

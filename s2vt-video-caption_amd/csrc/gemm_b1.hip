@@ -31,6 +31,7 @@
 namespace s2vt {
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
 
 struct GemmB1Args {
     int M, N, K;                              // K: multiple of 64 (zero-padded rows)
@@ -48,8 +49,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t b1_rsrc(const void* base, unsi
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
 }
 
-template <int MI>
+// TT = true (MI = 4): C[M,N] = X_A^T X_B with BOTH operands read transposed from bf16 ROW images X_A [K rows][lda >= M],
+// X_B [K rows][ldb >= N] (k = the images' rows): the weight-gradient GEMMs dW = dG^T h, whose operands the persistent recurrence
+// kernels already wrote as bf16 rows - no transposed copy of dG / dlogits / h is made.  Stage image per operand = [64 k rows]
+// [256 columns] (512-B rows: one LDS-DMA instruction = two whole rows); the 32-byte column groups of row k are stored at position
+// G ^ 2 (k & 3) (source-side swizzle again), and a fragment is two ds_read_b64_tr_b16 per lane (4 k rows x 16 columns each): the
+// 32 lanes of a half-wave then read 4 rows x 64 B that fall on 256 different bytes of the bank row.
+template <int MI, bool TT>
 __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
+    static_assert(!TT || MI == 4, "the transposed-read variant is built for 256-column tiles of both images");
     constexpr int TM = 64 * MI, ROWS = TM + 256, STAGE = ROWS * 128, IMG_A = TM * 128, NREQ = MI + 4;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -81,7 +89,16 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
     // 8w + 64(j - MI) ..): lane -> (row lane / 8, position lane % 8) <- piece (lane % 8) ^ ((row >> 1) & 7), and
     // (row >> 1) & 7 = (4w + lane / 16) & 7 for every j
     unsigned voa[MI], vob[4];
-    {
+    if constexpr (TT) {
+        // request j of wave w covers image rows 2w + 16j, + 1 of the stage (lane -> (row lane / 32, position lane % 32) <- 16-byte
+        // piece (lane % 32) ^ 4 (row & 3)); (row & 3) = (2w + lane / 32) & 3 for every j
+        const unsigned r = (unsigned)(2 * wave + (lane >> 5));
+        const unsigned piece = (unsigned)((lane & 31) ^ (4 * (r & 3)));
+#pragma unroll
+        for (int j = 0; j < MI; ++j) voa[j] = (r + 16u * j) * (unsigned)(p.lda * 2) + piece * 16u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vob[j] = (r + 16u * j) * (unsigned)(p.ldb * 2) + piece * 16u;
+    } else {
         const unsigned piece = (unsigned)((lane & 7) ^ ((4 * wave + (lane >> 4)) & 7));
         const unsigned r = (unsigned)(8 * wave + (lane >> 3));
 #pragma unroll
@@ -90,19 +107,31 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
         for (int j = 0; j < 4; ++j) vob[j] = (r + 64u * j) * (unsigned)(p.ldb * 2) + piece * 16u;
     }
     auto rsrc_a = [&](int m0) {
+        if constexpr (TT) {     // the image's columns m0.. over the k range's rows (a lane past the image's end reads nothing)
+            int64_t bytes = ((int64_t)(kend - kbeg) * p.lda - m0) * 2;
+            if (bytes > 0xFFFFF000ll) bytes = 0xFFFFF000ll;
+            return b1_rsrc(p.A + (int64_t)kbeg * p.lda + m0, (unsigned)bytes);
+        }
         const int rows = (p.M - m0 < TM) ? p.M - m0 : TM;
         return b1_rsrc(p.A + (int64_t)m0 * p.lda + kbeg, (unsigned)((rows - 1) * (int)(p.lda * 2) + (kend - kbeg) * 2));
     };
     auto rsrc_b = [&](int n0) {
+        if constexpr (TT) {
+            int64_t bytes = ((int64_t)(kend - kbeg) * p.ldb - n0) * 2;
+            if (bytes > 0xFFFFF000ll) bytes = 0xFFFFF000ll;
+            return b1_rsrc(p.B + (int64_t)kbeg * p.ldb + n0, (unsigned)bytes);
+        }
         const int rows = (p.N - n0 < 256) ? p.N - n0 : 256;
         return b1_rsrc(p.B + (int64_t)n0 * p.ldb + kbeg, (unsigned)((rows - 1) * (int)(p.ldb * 2) + (kend - kbeg) * 2));
     };
-    // request j of a stage: source descriptors ra / rb at byte offset koff of the k range, into ring slot `slot`
+    // request j of a stage: source descriptors ra / rb, k64 stage `koff` of the k range (ksa / ksb bytes per stage: 128 along the rows,
+    // or 64 image rows in the transposed-read variant), into ring slot `slot`
+    const int ksa = TT ? (int)(p.lda * 128) : 128, ksb = TT ? (int)(p.ldb * 128) : 128;
 #define B1_REQ(J, RA, RB, KOFF, SLOT)                                                                                       \
     if constexpr ((J) < NREQ) {                                                                                             \
         auto* dst = (__attribute__((address_space(3))) void*)(smem + (SLOT) * STAGE + wave * 1024 + (J) * 8192);            \
-        if constexpr ((J) < MI) __builtin_amdgcn_raw_ptr_buffer_load_lds(RA, dst, 16, (int)voa[(J) < MI ? (J) : 0], KOFF, 0, 0); \
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(RB, dst, 16, (int)vob[(J) >= MI ? (J) - MI : 0], KOFF, 0, 0);         \
+        if constexpr ((J) < MI) __builtin_amdgcn_raw_ptr_buffer_load_lds(RA, dst, 16, (int)voa[(J) < MI ? (J) : 0], (KOFF) * ksa, 0, 0); \
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(RB, dst, 16, (int)vob[(J) >= MI ? (J) - MI : 0], (KOFF) * ksb, 0, 0);         \
     }
 
     // fragment addresses: row r = tile row of lane ((r >> 1) & 7 == (li >> 1) & 7), k16 block c, half lh -> piece 2c+lh at
@@ -115,11 +144,33 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
         fb[c] = lbase + (unsigned)(IMG_A + (wn * 64 + li) * 128 + (((2 * c) ^ y) * 16));
     }
 
+    // TT: lane (li, lh): 16-lane group g = li / 16, row q = (li % 16) / 4 of a 4-row block, 8-byte part p = li % 4; tile X's 32-byte
+    // column groups 2X + g sit at position (2X + g) ^ 2q of their row: 64 ((X ^ q)) + 32 g bytes
+    unsigned fat[MI], fbt[2];
+    {
+        const int q_ = (li & 15) >> 2;
+        const unsigned lane_part = (unsigned)((8 * lh + q_) * 512 + (li >> 4) * 32 + (li & 3) * 8);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fat[mi] = lbase + lane_part + (unsigned)(64 * ((wm * MI + mi) ^ q_));
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) fbt[ni] = lbase + lane_part + (unsigned)(IMG_A + 64 * ((wn * 2 + ni) ^ q_));
+    }
+
     f32x16 acc[MI][2];
 
+#define B1_RDT(DST, ADDR, OFF)                                                                                            \
+    {                                                                                                                     \
+        bf16x4 lo_, hi_;                                                                                                  \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo_) : "v"(ADDR), "n"(OFF));                            \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi_) : "v"(ADDR), "n"((OFF) + 2048));                   \
+        DST = __builtin_shufflevector(lo_, hi_, 0, 1, 2, 3, 4, 5, 6, 7);                                                  \
+    }
 #define B1_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF));
 #define B1_READ(FA, FB, C, SO)                                                                                        \
-    {                                                                                                                 \
+    if constexpr (TT) {                                                                                               \
+        _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) { B1_RDT(FA[mi], fat[mi] + (SO), (C) * 8192) }             \
+        B1_RDT(FB[0], fbt[0] + (SO), (C) * 8192) B1_RDT(FB[1], fbt[1] + (SO), (C) * 8192)                            \
+    } else {                                                                                                          \
         const unsigned a_ = fa[C] + (SO), b_ = fb[C] + (SO);                                                          \
         B1_RD(FA[0], a_, 0) B1_RD(FA[1], a_, 4096)                                                                    \
         if constexpr (MI > 2) { B1_RD(FA[MI > 2 ? 2 : 0], a_, 8192) }                                                 \
@@ -161,19 +212,20 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
         const bool early = more && wave >= 4, late = more && wave < 4;
 #define B1_REQS(K) { B1_REQ(K, ra, rb, koff, ns) B1_REQ((K) + 4, ra, rb, koff, ns) if constexpr ((K) == 0) { B1_REQ(8, ra, rb, koff, ns) } }
         B1_FENCE
+        constexpr int NRD = TT ? 2 * (MI + 2) : MI + 2;          // LDS read instructions per k16 block
         B1_READ(ax, bx, 0, so) B1_READ(ay, by, 1, so)
         if (early) B1_REQS(0)
-        B1_WAIT(MI + 2, ax, bx) B1_PROD(ax, bx)
+        B1_WAIT(NRD, ax, bx) B1_PROD(ax, bx)
         if (late) B1_REQS(0)
         B1_FENCE
         B1_READ(ax, bx, 2, so)
         if (early) B1_REQS(1)
-        B1_WAIT(MI + 2, ay, by) B1_PROD(ay, by)
+        B1_WAIT(NRD, ay, by) B1_PROD(ay, by)
         if (late) B1_REQS(1)
         B1_FENCE
         B1_READ(ay, by, 3, so)
         if (early) B1_REQS(2)
-        B1_WAIT(MI + 2, ax, bx) B1_PROD(ax, bx)
+        B1_WAIT(NRD, ax, bx) B1_PROD(ax, bx)
         if (late) B1_REQS(2)
         B1_FENCE
         if (early) B1_REQS(3)
@@ -205,7 +257,7 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
     for (int g = 0;; ++g) {             // the stages of all of this workgroup's tiles, one after the other
         const bool has_next = qn < q_end;
         for (; s + 1 < nk; ++s, ++g) {
-            stage(g, std::true_type{}, true, ra, rb, (s + 1) * 128, wait_all);
+            stage(g, std::true_type{}, true, ra, rb, s + 1, wait_all);
             wait_all = true;
         }
         stage(g, std::false_type{}, has_next, ra1, rb1, 0, wait_all);      // the tile's last stage requests the next tile's first
@@ -303,6 +355,7 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
     }
 #undef B1_REQ
 #undef B1_RD
+#undef B1_RDT
 #undef B1_READ
 #undef B1_WAIT
 #undef B1_PROD
@@ -324,10 +377,29 @@ void gemm_b1_tune(int tile_rows, int nsplit) {
     g_b1_force_n = nsplit > 0 ? nsplit : 0;
 }
 
+static int gemm_b1_impl(hipStream_t stream, bool tt, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
+                       int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
+                       size_t splitk_ws_floats);
 int gemm_b1(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
             int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
             size_t splitk_ws_floats) {
+    return gemm_b1_impl(stream, false, M, N, K, A, lda, B, ldb, C, ldc, cmap, bias, accumulate, splitk_ws, splitk_ws_floats);
+}
+// C[M,N] (+)= X_A^T X_B from the bf16 ROW images X_A [K][lda >= pad(M)], X_B [K][ldb >= pad(N)]; K % 64 == 0
+int gemm_b1_tt(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
+               int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
+               size_t splitk_ws_floats) {
+    return gemm_b1_impl(stream, true, M, N, K, A, lda, B, ldb, C, ldc, cmap, bias, accumulate, splitk_ws, splitk_ws_floats);
+}
+static int gemm_b1_impl(hipStream_t stream, bool tt, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
+                       int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
+                       size_t splitk_ws_floats) {
     if (M <= 0 || N <= 0) return 0;
+    if (tt)
+        S2VT_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= M && ldb >= N &&
+                         (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0,
+                     "gemm_b1_tt: K (image rows) must be a multiple of 64, rows 16-B aligned and at least M / N columns long");
+    else
     S2VT_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K &&
                      (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0,
                  "gemm_b1: K must be the zero-padded multiple of 64 of the bf16 rows, rows 16-B aligned");
@@ -358,7 +430,7 @@ int gemm_b1(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
     static const int order[4] = {4, 5, 3, 2};
     for (int oi = 0; oi < 4; ++oi) {
         const int mi = order[oi];
-        if (force_mi && force_mi != mi) continue;
+        if (tt ? mi != 4 : (force_mi && force_mi != mi)) continue;
         const int tiles = cdiv(M, 64 * mi) * ntn;
         for (int n = 1; n <= 16; ++n) {
             if (n > 1 && (!splitk_ws || K < 512 || K / n < 256 || (size_t)n * M * N > splitk_ws_floats)) break;
@@ -385,11 +457,15 @@ int gemm_b1(hipStream_t stream, int M, int N, int K, const unsigned short* A, in
     const int nsplit = (best_ns > 1) ? cdiv(K, p.ksplit) : 1;
     p.slabs = (nsplit > 1) ? splitk_ws : nullptr;
     const dim3 grid(best_g, nsplit);
-    switch (best_mi) {
-        case 2: hipLaunchKernelGGL(gemm_b1_kernel<2>, grid, dim3(512), 0, stream, p); break;
-        case 3: hipLaunchKernelGGL(gemm_b1_kernel<3>, grid, dim3(512), 0, stream, p); break;
-        case 5: hipLaunchKernelGGL(gemm_b1_kernel<5>, grid, dim3(512), 0, stream, p); break;
-        default: hipLaunchKernelGGL(gemm_b1_kernel<4>, grid, dim3(512), 0, stream, p); break;
+    if (tt) {
+        hipLaunchKernelGGL((gemm_b1_kernel<4, true>), grid, dim3(512), 0, stream, p);
+    } else {
+        switch (best_mi) {
+            case 2: hipLaunchKernelGGL((gemm_b1_kernel<2, false>), grid, dim3(512), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL((gemm_b1_kernel<3, false>), grid, dim3(512), 0, stream, p); break;
+            case 5: hipLaunchKernelGGL((gemm_b1_kernel<5, false>), grid, dim3(512), 0, stream, p); break;
+            default: hipLaunchKernelGGL((gemm_b1_kernel<4, false>), grid, dim3(512), 0, stream, p); break;
+        }
     }
     S2VT_LAUNCH_CHECK("gemm_b1_kernel");
     if (nsplit > 1) return splitk_reduce(stream, splitk_ws, nsplit, M, N, C, ldc, cmap, bias, accumulate);

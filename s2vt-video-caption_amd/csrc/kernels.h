@@ -26,6 +26,9 @@ int gemm_x3_tt(hipStream_t stream, int M, int N, int K, const unsigned short* A,
 int gemm_b1(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
             int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
             size_t splitk_ws_floats);
+int gemm_b1_tt(hipStream_t stream, int M, int N, int K, const unsigned short* A, int64_t lda, const unsigned short* B,
+               int64_t ldb, float* C, int64_t ldc, RowMap cmap, const float* bias, bool accumulate, float* splitk_ws,
+               size_t splitk_ws_floats);
 void gemm_b1_tune(int tile_rows, int nsplit);       // 0 / 0: the launcher's time model decides (default)
 void gemm_x3_tune(int tile_rows, int nsplit);
 int split_planes(hipStream_t s, int nplanes, bool transpose, const float* in, int64_t ld, RowMap imap, int rows, int cols,

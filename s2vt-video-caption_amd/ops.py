@@ -49,8 +49,8 @@ def split_planes(x, nplanes=3, transpose=False):
     return out, ldo, kpad
 
 
-def gemm_planes_tt(pa, pb, M, N, K, bias=None, out=None, accumulate=False, splitk_ws=None):
-    """out[M,N] (+)= X_A^T X_B from the ROW plane images (split_planes(x, 3)) of X_A [K, M] and X_B [K, N]; K % 64 == 0."""
+def gemm_planes_tt(pa, pb, M, N, K, bias=None, out=None, accumulate=False, splitk_ws=None, nplanes=3):
+    """out[M,N] (+)= X_A^T X_B from the ROW plane images (split_planes(x, nplanes)) of X_A [K, M] and X_B [K, N]; K % 64 == 0."""
     lib = capi.load()
     (a, lda, _), (b, ldb, _) = pa, pb
     dev = a.device
@@ -58,7 +58,7 @@ def gemm_planes_tt(pa, pb, M, N, K, bias=None, out=None, accumulate=False, split
         if out is None:
             out = torch.zeros(M, N, dtype=torch.float32, device=dev) if accumulate else \
                 torch.empty(M, N, dtype=torch.float32, device=dev)
-        capi.check(lib.s2vt_gemm_bf16_tt(3, M, N, K, _ptr(a), lda, _ptr(b), ldb, _ptr(out), out.stride(0), _ptr(bias),
+        capi.check(lib.s2vt_gemm_bf16_tt(nplanes, M, N, K, _ptr(a), lda, _ptr(b), ldb, _ptr(out), out.stride(0), _ptr(bias),
                                          int(accumulate), _ptr(splitk_ws),
                                          ctypes.c_size_t(splitk_ws.numel() if splitk_ws is not None else 0), _stream(dev)),
                    "s2vt_gemm_bf16_tt")

@@ -103,6 +103,35 @@ def test_plain_bf16_gemm_rows(lib, M, N, K):
 
 
 
+def test_plain_bf16_gemm_transposed_reads(lib):
+    """gemm_b1_kernel<4, true>: C = X_A^T X_B from bf16 ROW images (what the bf16 recurrence kernels write), both read transposed:
+    integers exact, random operands against fp64 products of the bf16-rounded operands, ragged M / N, split-K, bias, accumulate, a
+    k range that starts 64 rows into the images."""
+    from s2vt_video_caption_amd import ops
+    for (K, M, N, ns) in ((192, 300, 77, 0), (1024, 4000, 1000, 4), (640, 1003, 517, 0), (128, 12000, 1000, 0)):
+        lib.s2vt_gemm_tune(1, 0, ns)
+        try:
+            g = torch.Generator().manual_seed(K + M)
+            xa = torch.randint(-4, 5, (K + 64, M), generator=g).float()
+            xb = torch.randint(-4, 5, (K + 64, N), generator=g).float()
+            bias = torch.randint(-8, 9, (N,), generator=g).float()
+            pa, pb = ops.split_planes(xa.to(DEV), 1), ops.split_planes(xb.to(DEV), 1)
+            ws = torch.empty(8 * M * N + 1, device=DEV)
+            got = ops.gemm_planes_tt(pa, pb, M, N, K, bias=bias.to(DEV), splitk_ws=ws, nplanes=1).cpu()
+            assert torch.equal(got, xa[:K].t() @ xb[:K] + bias), (K, M, N, ns)
+            pa1, pb1 = (pa[0][64:], pa[1], pa[2]), (pb[0][64:], pb[1], pb[2])
+            c0 = torch.randint(-8, 9, (M, N), generator=g).float()
+            out = c0.to(DEV).clone()
+            ops.gemm_planes_tt(pa1, pb1, M, N, K, out=out, accumulate=True, splitk_ws=ws, nplanes=1)
+            assert torch.equal(out.cpu(), xa[64:64 + K].t() @ xb[64:64 + K] + c0), (K, M, N, ns, "offset")
+            a, b = _r(K, M, seed=K), _r(K, N, seed=M)
+            ref = a.bfloat16().double().t() @ b.bfloat16().double()
+            got = ops.gemm_planes_tt(ops.split_planes(a.to(DEV), 1), ops.split_planes(b.to(DEV), 1), M, N, K, splitk_ws=ws, nplanes=1).cpu()
+            assert (got.double() - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-6, (K, M, N, ns)
+        finally:
+            lib.s2vt_gemm_tune(1, 0, 0)
+
+
 def test_split_precision_gemm_transposed_reads(lib):
     """gemm_x3_kernel<4, true>: C = X_A^T X_B with both operands read transposed from their ROW plane images (the weight-gradient
     form dW = dG^T h): integer operands exact (any wrong lane / row / chunk of the transposed fragment reads or of the gathered
