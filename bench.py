@@ -292,7 +292,7 @@ def main():
             dp.train_step(model, crit, opt, f2, c2, m2, reducer)
         sync_all()
         t0 = time.perf_counter()
-        n128 = 20
+        n128 = 50
         for _ in range(n128):
             dp.train_step(model, crit, opt, f2, c2, m2, reducer)
         sync_all()
@@ -347,7 +347,7 @@ def main():
             """(kernels, provenance) of the committed PMC traffic file of this workload; STATIC data: the file names the
             commit it was measured at, and a kernel changed since then carries a stale figure until the passes are re-run
             (tools/profile_round3.sh)."""
-            for rnd in ("round3", "round2"):
+            for rnd in ("round4", "round3", "round2"):
                 path = os.path.join(ROOT, "profiles", "%s_traffic_pmc_%s.json" % (rnd, tag))
                 try:
                     j = json.load(open(path))
@@ -355,7 +355,30 @@ def main():
                 except Exception:
                     continue
             return {}, None
+        def load_busy(tag):
+            """Matrix-pipe busy share and wave-state shares per kernel from the committed SQ counter passes (profiles/round4_pmc_<tag>.json,
+            tools/profile_round4.sh pmc): STATIC data like `traffic`, tagged with the commit it was measured at."""
+            path = os.path.join(ROOT, "profiles", "round4_pmc_%s.json" % tag)
+            try:
+                j = json.load(open(path))
+                return j["kernels"], {"static": "profiles/%s@%s" % (os.path.basename(path), j.get("commit", "unrecorded"))}
+            except Exception:
+                return {}, None
+
+        def busy_of(table, src, kernel):
+            """{mfma_busy (dispatch-weighted over the template instantiations), per-instantiation figures, provenance} for `kernel`."""
+            inst = {k: v for k, v in table.items() if k.split("<")[0] == kernel and "mfma_busy" in v}
+            if not inst:
+                return None
+            n = sum(v["dispatches"] for v in inst.values())
+            return {"mfma_busy": round(sum(v["mfma_busy"] * v["dispatches"] for v in inst.values()) / max(n, 1), 4),
+                    "by_instantiation": {k: {x: v.get(x) for x in ("mfma_busy", "wait_share", "issue_stall", "lds_conflict", "dispatches")}
+                                         for k, v in inst.items()},
+                    "source": src, "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) per dispatch"}
         pmc, pmc_src = ({}, None)
+        busy2, busy2_src = load_busy("c2")
+        busy3, busy3_src = load_busy("c3")
+        busyd, busyd_src = load_busy("dec")
         if B == 64 and not bf:
             pmc, pmc_src = load_pmc("c2")
         elif B == 256 and bf:
@@ -368,7 +391,7 @@ def main():
         BWD_KERNELS = {0: "lstm_step_bwd_kernel", 1: "lstm_seq_bwd_bf16_persist_kernel", 2: "lstm_seq_bwd_f32_persist_kernel",
                        3: "lstm_seq_bwd_x3_persist_kernel"}
 
-        def rooflines(pr, how, persist, B_=B, esz_=esz, bf_=bf, x3_=x3, pmc_=None, pmc_src_=None):
+        def rooflines(pr, how, persist, B_=B, esz_=esz, bf_=bf, x3_=x3, pmc_=None, pmc_src_=None, busy_=None):
             # persist: (forward kind, BPTT kind) as s2vt_recurrence_plan reports them, or False for launches per timestep
             pf, pb = persist if isinstance(persist, tuple) else ((1, 1) if (persist and bf_) else (2, 2) if persist else (0, 0))
             pmc_ = pmc if pmc_ is None else pmc_
@@ -407,7 +430,8 @@ def main():
                   "busy_ms_per_step": round(gemm_busy, 3), "sum_of_launch_ms": round(gemm_ms, 3),
                   "frac_by_sum_of_launch_ms": round(gflop_ / gemm_ms / gpeak, 4),
                   "algorithmic_bytes_or_flops_per_launch": round(gflop_ * 1e9 / max(gemm_n, 1)),
-                  "algorithmic_gflop_per_step": round(gflop_, 1), "timing": how, "note": gnote}
+                  "algorithmic_gflop_per_step": round(gflop_, 1), "timing": how, "note": gnote,
+                  "pipe_counters": busy_of(*busy_, gk) if busy_ else None}
             if pf:
                 fk = FWD_KERNELS[pf]
                 fnote = ("PERSISTENT-WEIGHTS kernel: one launch runs a block of timesteps of BOTH layers with every W_hh slice "
@@ -435,7 +459,8 @@ def main():
                         "hbm_gbs_measured": round(tr / (us * 1e-6) / 1e9, 1) if tr is not None else None,
                         "avg_launch_us": round(us, 3), "launches_per_step": 2 * T,
                         "ms_per_step": round(us * 2 * T / 1e3, 3),
-                        "algorithmic_bytes_per_launch": pair_ // 2, "timing": how, "note": note}
+                        "algorithmic_bytes_per_launch": pair_ // 2, "timing": how, "note": note,
+                        "pipe_counters": busy_of(*busy_, kernel) if busy_ else None}
             lane_note = ("; `frac` prices the average LAUNCH (two lanes' launches overlap and stretch each other), `frac_by_busy_time` the "
                          "wall time per layer timestep while the family runs (union of the lanes' brackets)")
             rs = step_rec(fk, step_gbs, step_us, fnote + lane_note, pr["step_fwd"][2])
@@ -450,7 +475,8 @@ def main():
         eff_blk = prev_blk           # api.hip balanced_block(): the persistent bf16 schedule evens the default 32 out over the L frames
         if plan[0] in (1, 3) and prev_blk == 32:
             eff_blk = -(-L // -(-L // 32))
-        roof_gemm, roof_step, roof_bstep = rooflines(live, "live, layers pipelined (block %d)" % eff_blk, plan)
+        busy_here = (busy3, busy3_src) if (B == 256 and bf) else (busy2, busy2_src) if (B == 64 and not bf) else None
+        roof_gemm, roof_step, roof_bstep = rooflines(live, "live, layers pipelined (block %d)" % eff_blk, plan, busy_=busy_here)
         if args.headline_only:
             alone = live
             roof_gemm_alone = roof_step_alone = roof_bstep_alone = None
@@ -529,6 +555,7 @@ def main():
                           "frac": round(am_gflop / (am_us * 1e-6) / 1e3 / am_peak, 4),
                           "avg_launch_us": round(am_us, 2), "launches_per_call": am_n,
                           "gflop_per_launch": round(am_gflop, 2), "traffic": None,
+                          "pipe_counters": busy_of(busyd, busyd_src, "logits_argmax_x3_kernel" if planes else "logits_argmax_kernel") if Bd == 128 else None,
                           "algorithmic_bytes_per_launch": am_bytes,
                           "hbm_frac_by_algorithmic_bytes": round(am_bytes / (am_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                           "note": ("fp32-equivalent FLOP/s of h W_o^T against the bf16 dense MFMA peak / 6 plane products (3 bf16 planes "
@@ -560,7 +587,7 @@ def main():
                     dp.train_step(model, crit, opt, b3[0], b3[1], b3[2], None)
                 torch.cuda.synchronize(dev)
                 t3 = time.perf_counter()
-                n3 = 20
+                n3 = 50
                 for _ in range(n3):
                     dp.train_step(model, crit, opt, b3[0], b3[1], b3[2], None)
                 torch.cuda.synchronize(dev)
@@ -570,7 +597,7 @@ def main():
                 pers = lib.s2vt_set_recurrence_mode(-1) >= 1
                 pmc3, pmc3_src = load_pmc("c3")
                 g3, f3, bw3 = rooflines(pr3, "live, persistent recurrence (block %d)" % (-(-L // -(-L // 32)) if prev_blk == 32 else prev_blk) if pers else "live", pers,
-                                        B_=256, esz_=2, bf_=True, x3_=False, pmc_=pmc3, pmc_src_=pmc3_src)
+                                        B_=256, esz_=2, bf_=True, x3_=False, pmc_=pmc3, pmc_src_=pmc3_src, busy_=(busy3, busy3_src))
                 config3 = {"workload": "BASELINE configs[2]: B=256, 80x4096 feats, hidden=embed=1000, vocab=12000, bf16 operands / "
                                        "fp32 accumulate, Adam", "dtype": "bf16", "value": round(256 * L / d3, 1), "unit": "frames/s",
                            "ms_per_step": round(d3 * 1e3, 3), "steps": n3,
