@@ -70,7 +70,7 @@ __device__ __forceinline__ void quad_transpose4(float& a0, float& a1, float& a2,
 // 256 contiguous bytes, conflict-free.  Same bytes staged, twice the (half-size) fragment reads, same MFMAs, same epilogue.
 template <int MI, bool TT>
 __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
-    static_assert(!TT || MI == 4, "the transposed-read variant is built for 256-row tiles (6 requests per wave and stage)");
+    // (TT: the tile's 2 MI + 8 column pairs x 3 planes are 6 requests for each of MI + 4 loader waves, as in the NN form)
     constexpr int NRA = MI, TMR = 64 * MI, X_STAGE = (NRA + 4) * X_REC;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[X_NS * X_STAGE];
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;   // LDS byte address
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
         if constexpr (TT) {
             // waves 0-3: the A image's columns m0.., waves 4-7: the B image's columns n0..; descriptor = the image from the k
             // range's first row block and the tile's first column chunk on
-            const bool isA = wave < 4;
+            const bool isA = wave < NRA;
             const unsigned short* base = isA ? p.A : p.B;
             const int64_t ld = isA ? p.lda : p.ldb;
             const int c0 = (isA ? m0 : n0) >> 4;
@@ -126,14 +126,15 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
                                                  nk * X_REC, 0x00020000);
     };
     const int vlane = TT ? ((lane >> 1) & 1) * X_REC + (lane & 1) * 1024 + (lane >> 2) * 16 : lane * 16;
-    const int64_t tt_ld2 = (wave < 4 ? p.lda : p.ldb) * 128;        // bytes between two 64-row blocks of this wave's image (TT)
+    const int64_t tt_ld2 = (wave < NRA ? p.lda : p.ldb) * 128;      // bytes between two 64-row blocks of this wave's image (TT)
+    const int tt_wq = wave < NRA ? wave : wave - NRA;                // TT: this wave's column pairs 2 wq, 2 wq + 1 of its operand
     // piece J of stage `st` (of the tile behind descriptor R) -> ring slot SLOT.  TT: request J of a wave = (column pair 2 (w & 3) +
     // J / 3, plane J % 3) of its operand: image offset = column pair x 2 records + plane x 2 KB + row quarter x 256 B + row block
 #define X3_REQ1(J, R, ST, SLOT)                                                                                           \
     if constexpr (TT) {                                                                                                   \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(R, (__attribute__((address_space(3))) void*)(smem + (SLOT) * X_STAGE + (wave >> 2) * (4 * X_REC) + \
-                                                     ((2 * (wave & 3) + (J) / 3) * 3 + (J) % 3) * 1024),                  \
-                                                 16, vlane, (int)(((ST) >> 2) * tt_ld2) + (2 * (wave & 3) + (J) / 3) * 2 * X_REC + ((J) % 3) * 2048 + ((ST) & 3) * 256, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(R, (__attribute__((address_space(3))) void*)(smem + (SLOT) * X_STAGE + (wave < NRA ? 0 : NRA * X_REC) + \
+                                                     ((2 * tt_wq + (J) / 3) * 3 + (J) % 3) * 1024),                       \
+                                                 16, vlane, (int)(((ST) >> 2) * tt_ld2) + (2 * tt_wq + (J) / 3) * 2 * X_REC + ((J) % 3) * 2048 + ((ST) & 3) * 256, 0, 0); \
     } else {                                                                                                              \
         __builtin_amdgcn_raw_ptr_buffer_load_lds(R, (__attribute__((address_space(3))) void*)(smem + (SLOT) * X_STAGE + wave * X_REC + (J) * 1024), \
                                                  16, vlane, (ST) * X_REC + (J) * 1024, 0, 0);                             \
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(512) void gemm_x3_kernel(GemmX3Args p) {
     // TT: lane (li, lh) of a 32-column tile: 16-lane group g = li / 16 (chunk parity), row q = (li % 16) / 4 of a 4-row block, 8-byte
     // part p = li % 4 of the group's 32 bytes; k rows 8 lh + 4 j + q (j = 0, 1: the two transposed reads of a fragment)
     const unsigned tt_lane = (unsigned)((8 * lh + ((li & 15) >> 2)) * 64 + (li >> 4) * 32 + (li & 3) * 8);
-    const unsigned lb_t = lbase + tt_lane + (unsigned)(4 * X_REC + wn * 2 * 3072);
+    const unsigned lb_t = lbase + tt_lane + (unsigned)(NRA * X_REC + wn * 2 * 3072);
     unsigned lat[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) lat[mi] = lbase + tt_lane + (unsigned)((wm * MI + mi) * 3072);
@@ -439,7 +440,7 @@ static int gemm_x3_impl(hipStream_t stream, bool tt, int M, int N, int K, const 
     static const int order[3] = {4, 3, 2};
     for (int oi = 0; oi < 3; ++oi) {
         const int mi = order[oi];
-        if (tt ? mi != 4 : (force_mi && force_mi != mi)) continue;
+        if (force_mi && force_mi != mi) continue;
         const int tiles = cdiv(M, 64 * mi) * ntn;
         for (int n = 1; n <= 16; ++n) {
             if (n > 1 && (!splitk_ws || K < 512 || K / n < 256 || (size_t)n * M * N > splitk_ws_floats)) break;
@@ -467,7 +468,11 @@ static int gemm_x3_impl(hipStream_t stream, bool tt, int M, int N, int K, const 
     p.slabs = (nsplit > 1) ? splitk_ws : nullptr;
     const dim3 grid(best_g, nsplit);
     if (tt) {
-        hipLaunchKernelGGL((gemm_x3_kernel<4, true>), grid, dim3(512), 0, stream, p);
+        switch (best_mi) {
+            case 2: hipLaunchKernelGGL((gemm_x3_kernel<2, true>), grid, dim3(512), 0, stream, p); break;
+            case 3: hipLaunchKernelGGL((gemm_x3_kernel<3, true>), grid, dim3(512), 0, stream, p); break;
+            default: hipLaunchKernelGGL((gemm_x3_kernel<4, true>), grid, dim3(512), 0, stream, p); break;
+        }
     } else {
         switch (best_mi) {
             case 2: hipLaunchKernelGGL((gemm_x3_kernel<2, false>), grid, dim3(512), 0, stream, p); break;

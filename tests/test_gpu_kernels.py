@@ -132,14 +132,15 @@ def test_plain_bf16_gemm_transposed_reads(lib):
             lib.s2vt_gemm_tune(1, 0, 0)
 
 
-def test_split_precision_gemm_transposed_reads(lib):
-    """gemm_x3_kernel<4, true>: C = X_A^T X_B with both operands read transposed from their ROW plane images (the weight-gradient
+@pytest.mark.parametrize("tile_rows", [0, 128, 192, 256])
+def test_split_precision_gemm_transposed_reads(lib, tile_rows):
+    """gemm_x3_kernel<MI, true> (every tile height; 0 = the launcher's choice): C = X_A^T X_B with both operands read transposed from their ROW plane images (the weight-gradient
     form dW = dG^T h): integer operands exact (any wrong lane / row / chunk of the transposed fragment reads or of the gathered
     LDS-DMA shows), random operands at the fp32-equivalent bound, ragged M / N (columns not multiples of 16 / 64 / 256), split-K,
     bias, accumulate, and a k range that starts at a later 64-row block of the images (dW_hh skips the first timestep)."""
     from s2vt_video_caption_amd import ops
     for (K, M, N, ns) in ((192, 300, 77, 0), (1024, 4000, 1000, 4), (640, 1003, 517, 0), (128, 12000, 1000, 0)):
-        lib.s2vt_gemm_tune(3, 0, ns)
+        lib.s2vt_gemm_tune(3, tile_rows, ns)
         try:
             g = torch.Generator().manual_seed(K + M)
             xa = torch.randint(-4, 5, (K + 64, M), generator=g).float()
