@@ -89,6 +89,8 @@ def beam_search(model, feats, params, beam_width=3, max_depth=30):
     max_rows = max(B * beam_width, B)
     if DEVICE_QUEUES and lib.s2vt_beam_queue_bytes(B, beam_width, max_depth) > 0:
         return _beam_search_device_queues(lib, model, feats, params, B, H, beam_width, max_depth, sos, eos, vid_h, vid_c, word_h, word_c)
+    global LAST_PATH
+    LAST_PATH = "host queues"
     queues = (BeamQueues if FAST_QUEUES else HeapQueues)(B, beam_width, sos, eos)
     pcs = tuple(p.contiguous() for p in (w_ih1, w_hh1, b_ih1, b_hh1, w_ih2, w_hh2, b_ih2, b_hh2, w_f, b_f, w_o, b_o, emb))
     d = _dims(feats, pcs)
@@ -139,6 +141,7 @@ DEVICE_QUEUES = True         # the queues on the device (csrc/beam_queue.hip): n
 
 
 PLANE_STEP = True            # s2vt_beam_step_cached: the depth's GEMMs on the plane path, from the decode cache of the same weights
+LAST_PATH = None             # which path the last beam_search call took (bench.py reports it beside the rate)
 
 
 def _beam_search_device_queues(lib, model, feats, params, B, H, beam_width, max_depth, sos, eos, vid_h, vid_c, word_h, word_c):
@@ -166,6 +169,8 @@ def _beam_search_device_queues(lib, model, feats, params, B, H, beam_width, max_
             cache, valid = functional.decode_cache_entry(model, params, d, dev, lib)
             if not valid:
                 cache = None
+    global LAST_PATH
+    LAST_PATH = "device queues + plane-path depth step (decode cache)" if cache is not None else "device queues + fp32-MFMA depth step"
     with torch.cuda.device(dev):
         nbytes = lib.s2vt_beam_workspace_bytes(ctypes.byref(d), R)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
