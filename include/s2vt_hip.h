@@ -378,6 +378,13 @@ int s2vt_set_gemm_mode(int32_t mode);
  * the L frames - 27 at L = 80 - because its launches pair a block of one layer with a block of the other); 0 runs everything
  * on the caller's stream (kernels then never overlap: used to time kernels in isolation).  Returns the previous value. */
 int s2vt_set_pipeline_block(int32_t steps);
+/* Schedule of the token-dependent decode steps of s2vt_greedy_decode[_cached] on the plane path (the loop of
+ * /root/reference/S2VTModel.py:98-107): 1 (default; env S2VT_DECODE_FUSED) = per step ONE launch that computes out_linear +
+ * argmax of step t and, as extra row blocks, h_t W_hh^T of step t+1 (which does not depend on the token), then a one-thread-
+ * per-cell launch that adds the token's gate-table row and updates the cell; 0 = a step kernel and an argmax kernel per step,
+ * the two batch halves as independent chains on two streams.  Same ids either way.  Returns the previous value; any other
+ * argument only queries. */
+int s2vt_set_decode_schedule(int32_t schedule);
 /* 1 if the internal side stream was verified to execute concurrently with the caller's stream (it is chosen by a
  * one-time calibration at the first pipelined call: HIP may map two streams onto one hardware queue), 0 if no
  * candidate overlapped (the drivers still run, serially), -1 before the first pipelined call. */

@@ -118,6 +118,7 @@ SIGNATURES = {
                                               c_void_p]),
     "s2vt_set_gemm_mode": (c_int32, [c_int32]),
     "s2vt_set_pipeline_block": (c_int32, [c_int32]),
+    "s2vt_set_decode_schedule": (c_int32, [c_int32]),
     "s2vt_pipeline_overlaps": (c_int32, []),
     "s2vt_test_occupy_cus": (c_int32, [c_int32, c_int32, c_int64, c_void_p]),
     "s2vt_set_graph_mode": (c_int32, [c_int32]),

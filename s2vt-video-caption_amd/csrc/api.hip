@@ -1474,6 +1474,7 @@ int s2vt_train_backward_dropout(const s2vt_dims* d, const s2vt_params* p, const 
 // ------------------------------------------------------------------ greedy decode
 struct DecodeWS {
     float *bsum1, *bsum2, *x1, *gx1, *h1, *c1, *gx2, *h2, *c2, *gws_a, *gws_b;
+    float* zbuf;                           // [B][4H]: h_t·W_hh^T, the recurrent half of the next decode step's gates
     size_t gws_floats;
     unsigned long long* packed;
     PB feats, px1, ph1;                    // packed planes of per-call activations (split-precision mode only)
@@ -1501,6 +1502,7 @@ static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
     w.gx2 = c.take<float>(T * B * 4 * H);
     w.h2 = c.take<float>(2 * B * H);
     w.c2 = c.take<float>(B * H);
+    w.zbuf = c.take<float>(B * 4 * H);
     w.packed = c.take<unsigned long long>((L - 1) * B);
     w.gws_floats = gemm_ws_floats(d);
     w.gws_a = c.take<float>(w.gws_floats);
@@ -1532,14 +1534,14 @@ static DecodeWS carve_decode(const s2vt_dims& d, void* base) {
 }
 // What a decode derives from the WEIGHTS alone (plane images of W_f, W_ih1, W_v, W_o and the per-token gate-input table):
 // carved from the tail of the call's workspace, or from a caller-kept cache that outlives the call (s2vt_greedy_decode_cached)
-struct DecodeConst { PB wf, wih1, wv, wo; float* gtab; unsigned short *xw1, *xw2; size_t bytes; };   // xw: W_hh planes [3][4H][Kp]
+struct DecodeConst { PB wf, wih1, wv, wo; float* gtab; unsigned short *xw1, *xw2; PB whh; size_t bytes; };   // xw: W_hh planes [3][4H][Kp]; whh: word_rnn's W_hh, blocked
 static DecodeConst carve_decode_const(const s2vt_dims& d, void* base) {
     const size_t F = d.F, H = d.H;
     Carver c{reinterpret_cast<char*>(base), 0, 0};
     DecodeConst k;
     k.gtab = nullptr;
     k.xw1 = k.xw2 = nullptr;
-    k.wf = k.wih1 = k.wv = k.wo = PB{nullptr, 0, 0};
+    k.wf = k.wih1 = k.wv = k.wo = k.whh = PB{nullptr, 0, 0};
     if (planes_ok(d)) {
         XP = 3;
         auto mk = [&](size_t rows, size_t kk) {
@@ -1554,6 +1556,7 @@ static DecodeConst carve_decode_const(const s2vt_dims& d, void* base) {
         const size_t xkp = (H <= 1024) ? (size_t)pad64((int)H) : 0;
         k.xw1 = c.take<unsigned short>(3 * 4 * H * xkp);
         k.xw2 = c.take<unsigned short>(3 * 4 * H * xkp);
+        k.whh = mk(4 * H, H);       // (last: the images in front keep their offsets)
     }
     k.bytes = align_up(c.off, 256);
     return k;
@@ -1711,6 +1714,18 @@ size_t s2vt_decode_cache_bytes(const s2vt_dims* d) {
 static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
                               void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, bool cache_valid,
                               void* stream);
+// schedule of the 79 token-dependent decode steps on the plane path: 1 = fused (the next step's recurrent GEMM inside the
+// argmax launch + a cell-update launch), 0 = a step kernel and an argmax kernel per step, batch halves as two chains
+static int g_decode_schedule = -1;
+static int decode_schedule() {
+    if (g_decode_schedule < 0) { const char* e = getenv("S2VT_DECODE_FUSED"); g_decode_schedule = (e && atoi(e) == 0) ? 0 : 1; }
+    return g_decode_schedule;
+}
+int s2vt_set_decode_schedule(int32_t schedule) {
+    const int prev = decode_schedule();
+    if (schedule == 0 || schedule == 1) g_decode_schedule = schedule;
+    return prev;
+}
 int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
                        void* workspace, size_t workspace_bytes, void* stream) {
     return greedy_decode_impl(d, p, feats, sos_ix, ids, workspace, workspace_bytes, nullptr, 0, false, stream);
@@ -1782,6 +1797,7 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
             if ((rc = pgemm(lb, V, 4 * H, E, w.embp, 0, 0, w.wep, 0, 0, kc.gtab, 4 * H, ID, nullptr, false))) return rc;
         }
         if (fill && (rc = psplit(lb, kc.wv, 0, p->word_w_ih + E, E + H, ID, 4 * H, H))) return rc;
+        if (fill && (rc = psplit(lb, kc.whh, 0, p->word_w_hh, H, ID, 4 * H, H))) return rc;
         if ((rc = psplit(la, w.feats, 0, feats, F, ID, B * L, F))) return rc;
         if (fill && (rc = psplit(la, kc.wf, 0, p->feat_w, F, ID, H, F))) return rc;
         if (fill && (rc = psplit(la, kc.wih1, 0, p->vid_w_ih, H, ID, 4 * H, H))) return rc;
@@ -1798,40 +1814,46 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
     // steps Emb[prev token] (:89-103)
     // (b0, nb): the batch rows [b0, b0 + nb) of the step - the whole batch, or one half of it when the decode runs as two
     // independent chains on two streams (b0 a multiple of 64: the plane images are blocked by 64 rows)
+    auto word_args = [&](int t, const float* hprev, const float* cprev, int b0, int nb) -> StepFwdArgs {
+        const int64_t o1 = (int64_t)b0 * H, o4 = 4 * o1;
+        StepFwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.B = nb; a.H = H;
+        a.h_prev = hprev ? hprev + o1 : nullptr; a.ldh = H;
+        a.w_hh = p->word_w_hh; a.ldw = H;
+        if (t >= L) {
+            if (use_tab) {
+                a.gx_tab = kc.gtab; a.ldtab = 4 * (int64_t)H;
+            } else {
+                a.x2 = p->emb_w; a.ldx2 = E; a.K2 = E;
+                a.w2 = p->word_w_ih; a.ldw2 = E + H;
+            }
+            a.tok_packed = (t > L) ? w.packed + (int64_t)(t - L - 1) * B + b0 : nullptr;
+            a.tok_const = sos_ix;
+            // the packed word is the previous step's argmax: a producer that left it unwritten would decode as token
+            // 0xFFFFFFFF - clamped and flagged (w.err[0], S2VT_ERR_INDEX) instead of read from beyond the table
+            a.tok_limit = V; a.tok_err = w.err;
+        }
+        a.gx = w.gx2 + t * B4H + o4; a.ldgx = 4 * (int64_t)H;
+        a.c_prev = cprev ? cprev + o1 : nullptr; a.ldc = H;
+        a.h_out = w.h2 + (t & 1) * BH + o1; a.ldho = H;
+        a.c_out = w.c2 + o1; a.ldco = H;
+        if (t >= L && ax3) { a.h_planes = w.ph2.p + (int64_t)b0 * w.ph2.ld; a.ldhp = w.ph2.ld; }
+        return a;
+    };
     auto word_step = [&](hipStream_t s, int t, const float* hprev, const float* cprev, int b0 = 0, int nb = -1) -> int {
         int r;
         if (nb < 0) nb = B;
-        const int64_t o1 = (int64_t)b0 * H, o4 = 4 * o1;
+        const int64_t o1 = (int64_t)b0 * H;
         {
             ProfScope ps(s, K_STEP_FWD, 1);
-            StepFwdArgs a;
-            memset(&a, 0, sizeof(a));
-            a.B = nb; a.H = H;
-            a.h_prev = hprev ? hprev + o1 : nullptr; a.ldh = H;
-            a.w_hh = p->word_w_hh; a.ldw = H;
-            if (t >= L) {
-                if (use_tab) {
-                    a.gx_tab = kc.gtab; a.ldtab = 4 * (int64_t)H;
-                } else {
-                    a.x2 = p->emb_w; a.ldx2 = E; a.K2 = E;
-                    a.w2 = p->word_w_ih; a.ldw2 = E + H;
-                }
-                a.tok_packed = (t > L) ? w.packed + (int64_t)(t - L - 1) * B + b0 : nullptr;
-                a.tok_const = sos_ix;
-                // the packed word is the previous step's argmax: a producer that left it unwritten would decode as token
-                // 0xFFFFFFFF - clamped and flagged (w.err[0], S2VT_ERR_INDEX) instead of read from beyond the table
-                a.tok_limit = V; a.tok_err = w.err;
-            }
-            a.gx = w.gx2 + t * B4H + o4; a.ldgx = 4 * (int64_t)H;
-            a.c_prev = cprev ? cprev + o1 : nullptr; a.ldc = H;
-            a.h_out = w.h2 + (t & 1) * BH + o1; a.ldho = H;
-            a.c_out = w.c2 + o1; a.ldco = H;
-            if (t >= L && ax3) { a.h_planes = w.ph2.p + (int64_t)b0 * w.ph2.ld; a.ldhp = w.ph2.ld; }
+            const StepFwdArgs a = word_args(t, hprev, cprev, b0, nb);
             if ((r = lstm_step_fwd(s, a))) return r;
         }
         if (t >= L && ax3) {  // out_linear + argmax (:95-96, :105-106) on the bf16 matrix cores (argmax_x3.hip); the
             ProfScope ps(s, K_ARGMAX, 1);       // step kernel above wrote h_t as planes (StepFwdArgs::h_planes)
             ArgmaxX3Args ax;
+            memset(&ax, 0, sizeof(ax));
             ax.B = nb; ax.V = V; ax.K = kc.wo.kpad;
             ax.W = kc.wo.p; ax.ldw = kc.wo.ld;
             ax.Hp = w.ph2.p + (int64_t)b0 * w.ph2.ld; ax.ldh = w.ph2.ld;
@@ -1890,6 +1912,42 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
         // each leave part of the chip idle (188 of 256 compute units in the argmax; launch gaps and tails between the two) and
         // batch rows never interact: at B % 128 == 0 the two halves of the batch run as two INDEPENDENT chains on the two
         // streams, so one half's step kernel fills the other half's gaps (S2VT_DECODE_HALVES=0: one chain)
+        // Fused schedule (s2vt_set_decode_schedule(1), the default; S2VT_DECODE_FUSED=0 selects the two-chain schedule below): h_t·W_hh^T of step t+1 does not depend on step t's token - only the
+        // per-token rows of the gate table do - so it is computed BESIDE step t's out_linear + argmax, by the same launch: W_hh's
+        // 4H rows are 63 more row blocks of the plane-path argmax kernel (188 + 63 workgroups: one wave of the 256 compute
+        // units), which write their products to w.zbuf instead of reducing them.  A one-thread-per-cell launch then finishes
+        // step t+1 (gates = z + gx + table row of the token, in the fused step's order).  Two launches per step on ONE stream,
+        // and the chain is argmax + cell update instead of argmax + recurrent GEMM + cell update.
+        if (decode_schedule() == 1 && ax3 && use_tab && kc.whh.p && kc.whh.kpad == kc.wo.kpad) {
+            auto pair = [&](int t, bool with_logits, bool with_z) -> int {     // logits + argmax of step t (h_t planes) | z of step t+1
+                ProfScope ps(st, K_ARGMAX, 1);
+                ArgmaxX3Args ax;
+                memset(&ax, 0, sizeof(ax));
+                ax.B = B; ax.V = V; ax.K = kc.wo.kpad;
+                ax.W = kc.wo.p; ax.ldw = kc.wo.ld;
+                ax.Hp = w.ph2.p; ax.ldh = w.ph2.ld;
+                ax.bias = p->out_b;
+                ax.packed = w.packed + (int64_t)(with_logits ? t - L : 0) * B;
+                if (with_z) { ax.W2 = kc.whh.p; ax.ldw2 = kc.whh.ld; ax.M2 = 4 * H; ax.z = w.zbuf; ax.ldz = 4 * (int64_t)H; }
+                ax.v_off = with_logits ? 0 : cdiv(V, 64);
+                return logits_argmax_x3(st, ax);
+            };
+            // h_{L-1} of the encode phase as blocked planes, then z(L) alone
+            if ((rc = handoff(sx, st, ev++))) return rc;
+            if ((rc = psplit(la, w.ph2, 0, w.h2_all + (int64_t)(L - 1) * BH, H, ID, B, H))) return rc;
+            if ((rc = pair(L, false, true))) return rc;
+            for (int t = L; t < T; ++t) {
+                StepFwdArgs a = word_args(t, nullptr, t == L ? w.c2_all + (int64_t)(L - 1) * BH : w.c2, 0, B);
+                a.z_out = w.zbuf; a.ldz = 4 * (int64_t)H;
+                {
+                    ProfScope ps(st, K_STEP_FWD, 1);
+                    if ((rc = lstm_cell_pointwise(st, a))) return rc;
+                }
+                if ((rc = pair(t, true, t + 1 < T))) return rc;
+            }
+            if ((rc = unpack_tokens(st, w.packed, L - 1, B, ids))) return rc;
+            return post_async_error(st, w.err);
+        }
         static const bool halves_off = getenv("S2VT_DECODE_HALVES") && atoi(getenv("S2VT_DECODE_HALVES")) == 0;
         const int nh = (!halves_off && ax3 && B % 128 == 0 && sx != st) ? 2 : 1;
         if (nh == 2 && (rc = handoff(st, sx, ev++))) return rc;
@@ -2548,6 +2606,7 @@ int s2vt_decode_step_argmax_x3(int32_t B, int32_t H, int32_t V, const float* h, 
     if ((rc = split_planes(st, 3, false, w_out, H, ID, V, H, wp, 3 * (int64_t)kp, kp, (int)rows64((size_t)V)))) return rc;
     if ((rc = split_planes(st, 3, false, h, H, ID, B, H, hp, 3 * (int64_t)kp, kp, (int)rows64((size_t)B)))) return rc;
     ArgmaxX3Args ax;
+    memset(&ax, 0, sizeof(ax));
     ax.B = B; ax.V = V; ax.K = kp;
     ax.W = wp; ax.ldw = 3 * (int64_t)kp;
     ax.Hp = hp; ax.ldh = 3 * (int64_t)kp;

@@ -61,7 +61,11 @@ __global__ __launch_bounds__(256) void logits_argmax_x3_kernel(ArgmaxX3Args p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int vb = blockIdx.x;                         // vocabulary row block (64 rows)
+    const int nvb = (p.V + 63) >> 6;
+    const int vb_all = (int)blockIdx.x + p.v_off;      // row block of the launch: vocabulary blocks first, then the second image's
+    const bool zrole = vb_all >= nvb;                  // (workgroup-uniform)
+    const int vb = zrole ? vb_all - nvb : vb_all;      // row block (64 rows) of this workgroup's weight image
+    const int mlim = zrole ? p.M2 : p.V;
     const int bt = blockIdx.y;                         // batch tile (64 * NB rows)
     const int nst = (AX_DBG(p) & 4) ? 4 : (p.K >> 5);      // k32 stages (K % 64 == 0: an even number >= 2)
     const int xrec = p.stamps ? (int)blockIdx.x : -1;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void logits_argmax_x3_kernel(ArgmaxX3Args p) {
     for (int q = 0; q < 4; ++q) {
         const int m = m_base + 8 * q;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bv[q][e] = *((p.bias && m + e < p.V) ? p.bias + m + e : g_zero4);
+        for (int e = 0; e < 4; ++e) bv[q][e] = *((!zrole && p.bias && m + e < p.V) ? p.bias + m + e : g_zero4);
     }
 
     // ---- loader role: piece q = wave + 4 j of a stage lies in segment q / 12 at byte (q % 12) * 1024
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(256) void logits_argmax_x3_kernel(ArgmaxX3Args p) {
             const int q = wave + 4 * j, seg = q / 12, off = (q % 12) * 1024;
             const unsigned short* base;
             if (seg == 0) {
-                base = p.W + (int64_t)vb * 64 * p.ldw;
+                base = zrole ? p.W2 + (int64_t)vb * 64 * p.ldw2 : p.W + (int64_t)vb * 64 * p.ldw;
             } else {
                 int hb = bt * NB + seg - 1;            // a batch block past the last one is clamped onto it (never stored)
                 hb = hb < nhb ? hb : nhb - 1;
@@ -223,6 +227,28 @@ __global__ __launch_bounds__(256) void logits_argmax_x3_kernel(ArgmaxX3Args p) {
     // Per column: running max in registers, the two k-row halves (lh) by one exchange, the two vocabulary halves of the
     // workgroup (wm) through LDS, then ONE atomicMax per column and workgroup (188 per address and launch at V = 12000;
     // one per wave doubled that and cost 3.5 us of a 35-us launch)
+    if (zrole) {
+        // second role: the products leave as they are.  Lane (li, lh) holds rows m_base + 8 q + (0..3) of batch column li:
+        // one 16-byte store per q, the two lh halves of a column side by side (32 contiguous bytes per batch row)
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) {
+            const int b = bt * 64 * NB + ((NB == 2) ? wn * 64 + ni * 32 : wn * 32) + li;
+            if (b >= p.B) continue;
+            float* zr = p.z + (int64_t)b * p.ldz;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = m_base + 8 * q;
+                if (m + 3 < mlim) {
+                    *reinterpret_cast<f32x4*>(zr + m) = f32x4{acc[ni][4 * q], acc[ni][4 * q + 1], acc[ni][4 * q + 2], acc[ni][4 * q + 3]};
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (m + e < mlim) zr[m + e] = acc[ni][4 * q + e];
+                }
+            }
+        }
+        return;
+    }
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);       // [2][64 * NB]
     __syncthreads();                                                               // the ring is dead: every wave is past its last reads
 #pragma unroll
@@ -258,7 +284,11 @@ int logits_argmax_x3(hipStream_t stream, const ArgmaxX3Args& a) {
     S2VT_REQUIRE(a.ldw >= 3 * (int64_t)a.K && a.ldh >= 3 * (int64_t)a.K && a.ldw % 8 == 0 && a.ldh % 8 == 0 &&
                      (reinterpret_cast<uintptr_t>(a.W) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.Hp) & 15) == 0,
                  "logits_argmax_x3: operands must be blocked 3-plane images (split.hip) with k padded to K");
-    const int vblocks = cdiv(a.V, 64);
+    S2VT_REQUIRE(a.M2 >= 0 && (a.M2 == 0 || (a.W2 && a.z && a.ldw2 >= 3 * (int64_t)a.K && a.ldw2 % 8 == 0 && a.ldz >= a.M2 && a.ldz % 4 == 0 &&
+                                              (reinterpret_cast<uintptr_t>(a.W2) & 15) == 0 && (reinterpret_cast<uintptr_t>(a.z) & 15) == 0)),
+                 "logits_argmax_x3: the second image must be a blocked 3-plane image of the same K, z 16-byte aligned rows");
+    S2VT_REQUIRE(a.v_off == 0 || (a.v_off == cdiv(a.V, 64) && a.M2 > 0), "logits_argmax_x3: v_off is 0 or every vocabulary block");
+    const int vblocks = cdiv(a.V, 64) - a.v_off + cdiv(a.M2, 64);
     static int dbg = -1;
     if (dbg < 0) { const char* e = getenv("S2VT_AX_DBG"); dbg = e ? atoi(e) : 0; }
     ArgmaxX3Args b = a;

@@ -82,8 +82,15 @@ struct StepFwdArgs {
     // producer bug (e.g. a packed argmax word that no workgroup wrote) then surfaces as an error code, not as a GPU fault.
     // tok_limit == 0: no token segment in use
     int tok_limit; int* tok_err;
+    // optional: CONTRACTION ONLY - z_out[b][g*H + u] = sum_k h_prev[b][k] W_hh[g*H + u][k] (the reduced partial sums, nothing
+    // added) and no cell update: the recurrent half of a decode step that does not depend on the previous step's token, so it
+    // runs beside that step's out_linear + argmax; lstm_cell_pointwise() finishes the step (same additions in the same order)
+    float* z_out; int64_t ldz;
 };
 int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a);
+// the cell update of a step whose contraction ran as its own launch (StepFwdArgs::z_out): the token segment (gx_tab + token
+// source + guard), gx, c_prev and every output of `a` are used; h_prev / w_hh are not read, a.z_out is the INPUT
+int lstm_cell_pointwise(hipStream_t stream, const StepFwdArgs& a);
 int lstm_step_fwd2(hipStream_t stream, const StepFwdArgs& a, const StepFwdArgs* b);   // two independent steps, one launch
 
 struct StepBwdArgs {
@@ -245,6 +252,13 @@ struct ArgmaxX3Args {
     const unsigned short* Hp; int64_t ldh;          // planes of h_t [rows64(B)][3K] (re-split every step)
     const float* bias;                              // b_o [V] (nullable)
     unsigned long long* packed;                     // [B] zero-initialised; atomicMax of (ordered logit << 32 | ~index)
+    // optional second role of the same launch: row blocks past the vocabulary's multiply the SAME h_t planes with a second
+    // weight image and write the products instead of reducing them - z[b][m] = h_t[b]·W2[m], m < M2 (the decode loop: W2 =
+    // W_hh of word_rnn, z = the recurrent half of step t+1's gates, which does not depend on step t's token).  M2 == 0: none.
+    // v_off = number of leading vocabulary row blocks the launch leaves out (cdiv(V, 64): the second role alone).
+    const unsigned short* W2; int64_t ldw2; int M2;
+    float* z; int64_t ldz;
+    int v_off;
     int dbg;                                        // timing experiments only (S2VT_AX_DBG): 0 in the product
     unsigned long long* stamps;                     // timing experiments only (experiment.h); null in the product
 };

@@ -204,6 +204,40 @@ __device__ __forceinline__ int64_t step_token(const StepFwdArgs& p, int b) {
     return tok;
 }
 
+// gates -> (c_t, h_t) and every optional output of a step, for one cell (shared by the fused epilogue and the stand-alone
+// cell kernel: one expression, one rounding sequence)
+__device__ __forceinline__ void step_cell_outputs(const StepFwdArgs& p, int b, int unit, const float (&pre)[4], float cpv) {
+    const float ig = sigmoidf_(pre[0]);
+    const float fg = sigmoidf_(pre[1]);
+    const float gg = tanhf_(pre[2]);
+    const float og = sigmoidf_(pre[3]);
+    const float c = fg * cpv + ig * gg;
+    const float h = og * tanhf_(c);
+    p.h_out[(int64_t)b * p.ldho + unit] = h;
+    if (p.h_out2) p.h_out2[(int64_t)b * p.ldho2 + unit] = h;
+    p.c_out[(int64_t)b * p.ldco + unit] = c;
+    if (p.stash) {
+        float* st = p.stash + (int64_t)b * p.ldst + unit;
+        st[0] = ig;
+        st[(int64_t)p.H] = fg;
+        st[(int64_t)2 * p.H] = gg;
+        st[(int64_t)3 * p.H] = og;
+    }
+    if (p.h_planes) {
+        // blocked plane layout (split.hip): element (row b, k = unit, plane pl) at
+        //   (b/64)*(64*ld) + (k/16)*3072 + (pl*2 + (k%16)/8)*512 + (b%64)*8 + k%8.
+        // The 8 threads of a row hold the 8 consecutive units u0..u0+7 (u0 % 8 == 0): their 2-byte stores fill one 16-byte
+        // slot, the rows of the tile consecutive slots of the same piece
+        unsigned short pl3[3];
+        split3_bits(h, pl3);
+        unsigned short* q = p.h_planes + (int64_t)(b >> 6) * (64 * p.ldhp) + (int64_t)(unit >> 4) * 3072 +
+                            ((unit >> 3) & 1) * 512 + (b & 63) * 8 + (unit & 7);
+        q[0] = pl3[0];
+        q[1024] = pl3[1];
+        q[2048] = pl3[2];
+    }
+}
+
 template <int MT, int NT, bool VEC>
 __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid) {
     constexpr int TM = 16 * MT, TN = 16 * NT, UN = TN / 4;
@@ -232,8 +266,8 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
     const int ebl = tid / UN, eu = tid % UN;
     const int eb = b0 + ebl, eunit = u0 + eu;
     const bool evalid = (tid < TM * UN) && (eb < p.B) && (eunit < p.H);
-    float gxv[4], cpv;
-    {
+    float gxv[4] = {0.f, 0.f, 0.f, 0.f}, cpv = 0.f;
+    if (!p.z_out) {
         const float* gsrc = p.gx ? p.gx + (int64_t)((p.gx_idx && evalid) ? p.gx_idx[eb] : eb) * p.ldgx : p.bias;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -244,7 +278,7 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
         cpv = *q;
     }
     float gtv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.gx_tab) {       // embedded-word half of the gate input from the per-token table (two dependent loads, behind the K loop)
+    if (p.gx_tab && !p.z_out) {       // embedded-word half of the gate input from the per-token table (two dependent loads, behind the K loop)
         const int64_t tok = evalid ? step_token(p, eb) : 0;
         const float* trow = p.gx_tab + tok * p.ldtab;
 #pragma unroll
@@ -266,7 +300,7 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
         }
         wave_gemm_nt<MT, NT, NA, VEC, NWAVE>(acc, p.h_prev, p.w_hh, arow, brow, p.H, sA, sB, wave, lane);
     }
-    if (p.x2) {
+    if (p.x2 && !p.z_out) {
         const float* arow[MT * LPT];
         const float* brow[NT * LPT];
 #pragma unroll
@@ -295,43 +329,48 @@ __device__ __forceinline__ void lstm_step_fwd_body(const StepFwdArgs& p, int bid
     write_partials<MT, NT, NA, RLD>(acc, red, wave, lane);
     __syncthreads();
 
+    if (evalid && p.z_out) {           // contraction only: the cell update is lstm_cell_pointwise's
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            p.z_out[(int64_t)eb * p.ldz + (int64_t)g * p.H + eunit] = read_sum<MT, NT, NWAVE, RLD>(red, ebl, g * UN + eu);
+        return;
+    }
     if (evalid) {
-        const int bl = ebl, u = eu, b = eb, unit = eunit;
         float pre[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) pre[g] = read_sum<MT, NT, NWAVE, RLD>(red, bl, g * UN + u) + gxv[g] + gtv[g];
-        const float ig = sigmoidf_(pre[0]);
-        const float fg = sigmoidf_(pre[1]);
-        const float gg = tanhf_(pre[2]);
-        const float og = sigmoidf_(pre[3]);
-        const float c = fg * cpv + ig * gg;
-        const float h = og * tanhf_(c);
-        p.h_out[(int64_t)b * p.ldho + unit] = h;
-        if (p.h_out2) p.h_out2[(int64_t)b * p.ldho2 + unit] = h;
-        p.c_out[(int64_t)b * p.ldco + unit] = c;
-        if (p.stash) {
-            float* st = p.stash + (int64_t)b * p.ldst + unit;
-            st[0] = ig;
-            st[(int64_t)p.H] = fg;
-            st[(int64_t)2 * p.H] = gg;
-            st[(int64_t)3 * p.H] = og;
-        }
-        if (p.h_planes) {
-            // blocked plane layout (split.hip): element (row b, k = unit, plane pl) at
-            //   (b/64)*(64*ld) + (k/16)*3072 + (pl*2 + (k%16)/8)*512 + (b%64)*8 + k%8.
-            // The 8 threads of a row hold the 8 consecutive units u0..u0+7 (u0 % 8 == 0): their 2-byte stores fill one 16-byte
-            // slot, the rows of the tile consecutive slots of the same piece
-            unsigned short pl3[3];
-            split3_bits(h, pl3);
-            unsigned short* q = p.h_planes + (int64_t)(b >> 6) * (64 * p.ldhp) + (int64_t)(unit >> 4) * 3072 +
-                                ((unit >> 3) & 1) * 512 + (b & 63) * 8 + (unit & 7);
-            q[0] = pl3[0];
-            q[1024] = pl3[1];
-            q[2048] = pl3[2];
-        }
+        for (int g = 0; g < 4; ++g) pre[g] = read_sum<MT, NT, NWAVE, RLD>(red, ebl, g * UN + eu) + gxv[g] + gtv[g];
+        step_cell_outputs(p, eb, eunit, pre, cpv);
     }
 }
 
+// The epilogue of lstm_step_fwd_body on a contraction that ran as its own launch (z_out): one thread per NU consecutive cells
+// of a batch row (NU = 4: 16-byte loads and stores, H % 4 == 0 and 16-byte aligned rows; NU = 1 otherwise).
+template <int NU>
+__global__ __launch_bounds__(256) void lstm_cell_pointwise_kernel(StepFwdArgs p) {
+    const int upr = p.H / NU;                          // threads per batch row
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= p.B * upr) return;
+    const int b = i / upr, unit = (i % upr) * NU;
+    typedef float vec __attribute__((ext_vector_type(NU)));
+    const float* gsrc = p.gx ? p.gx + (int64_t)(p.gx_idx ? p.gx_idx[b] : b) * p.ldgx : p.bias;
+    const float* zsrc = p.z_out + (int64_t)b * p.ldz + unit;
+    const float* trow = p.gx_tab ? p.gx_tab + step_token(p, b) * p.ldtab + unit : nullptr;
+    vec zv[4], gxv[4], gtv[4], cpv;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        zv[g] = *reinterpret_cast<const vec*>(zsrc + (int64_t)g * p.H);
+        gxv[g] = *reinterpret_cast<const vec*>(gsrc + (int64_t)g * p.H + unit);
+        gtv[g] = trow ? *reinterpret_cast<const vec*>(trow + (int64_t)g * p.H) : (vec)(0.f);
+    }
+    cpv = p.c_prev ? *reinterpret_cast<const vec*>(p.c_prev + (int64_t)b * p.ldc + unit) : (vec)(0.f);
+#pragma unroll
+    for (int e = 0; e < NU; ++e) {
+        float pre[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] = zv[g][e] + gxv[g][e] + gtv[g][e];
+        step_cell_outputs(p, b, unit + e, pre, cpv[e]);
+    }
+}
 
 static bool step_fwd_vec(const StepFwdArgs& a) {
     // vector path: 16-B aligned rows whose length is a multiple of 4 floats, for every operand in use
@@ -341,8 +380,9 @@ static bool step_fwd_vec(const StepFwdArgs& a) {
 
 // b == nullptr: one timestep; otherwise two independent timesteps of the same (B, H) in one launch
 int lstm_step_fwd2(hipStream_t stream, const StepFwdArgs& a, const StepFwdArgs* b) {
-    S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.h_out && a.c_out, "lstm_step_fwd: bad arguments");
-    S2VT_REQUIRE(a.gx || a.bias, "lstm_step_fwd: need gx or bias");
+    S2VT_REQUIRE(a.B > 0 && a.H > 0 && ((a.h_out && a.c_out) || a.z_out), "lstm_step_fwd: bad arguments");
+    S2VT_REQUIRE(a.gx || a.bias || a.z_out, "lstm_step_fwd: need gx or bias");
+    S2VT_REQUIRE(!a.z_out || (a.h_prev && !b && a.ldz >= 4 * (int64_t)a.H), "lstm_step_fwd: a contraction-only step needs h_prev and runs alone");
     S2VT_REQUIRE(!(a.x2 || a.gx_tab) || a.tok_limit > 0, "lstm_step_fwd: a token segment needs tok_limit (rows of the table)");
     S2VT_REQUIRE(!b || (b->B == a.B && b->H == a.H && b->h_out && b->c_out && (b->gx || b->bias)),
                  "lstm_step_fwd: paired steps must have the same batch and hidden size");
@@ -363,6 +403,19 @@ int lstm_step_fwd2(hipStream_t stream, const StepFwdArgs& a, const StepFwdArgs* 
     return 0;
 }
 int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a) { return lstm_step_fwd2(stream, a, nullptr); }
+
+int lstm_cell_pointwise(hipStream_t stream, const StepFwdArgs& a) {
+    S2VT_REQUIRE(a.B > 0 && a.H > 0 && a.h_out && a.c_out && a.z_out && a.ldz >= 4 * (int64_t)a.H, "lstm_cell_pointwise: bad arguments");
+    S2VT_REQUIRE(a.gx || a.bias, "lstm_cell_pointwise: need gx or bias");
+    S2VT_REQUIRE(!a.x2, "lstm_cell_pointwise: the token segment must be the per-token table (gx_tab), not a second K segment");
+    S2VT_REQUIRE(!a.gx_tab || a.tok_limit > 0, "lstm_cell_pointwise: a token segment needs tok_limit (rows of the table)");
+    const bool v4 = a.H % 4 == 0 && vec_ok(a.z_out, a.ldz) && (!a.gx || vec_ok(a.gx, a.ldgx)) && (!a.bias || vec_ok(a.bias, 4)) &&
+                    (!a.gx_tab || vec_ok(a.gx_tab, a.ldtab)) && (!a.c_prev || vec_ok(a.c_prev, a.ldc));
+    if (v4) hipLaunchKernelGGL(lstm_cell_pointwise_kernel<4>, dim3((unsigned)cdiv(a.B * (a.H / 4), 256)), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(lstm_cell_pointwise_kernel<1>, dim3((unsigned)cdiv(a.B * a.H, 256)), dim3(256), 0, stream, a);
+    S2VT_LAUNCH_CHECK("lstm_cell_pointwise_kernel");
+    return 0;
+}
 
 // ----------------------------------------------------------------------------- backward step
 template <int MT, int NT, bool VEC>

@@ -373,6 +373,36 @@ def test_c5_unscaled_greedy_batch_against_reference_golden(lib, golden):
     np.testing.assert_array_equal(ids[rows], g["greedy_ids"][rows])
 
 
+@pytest.mark.parametrize("B", [64, 128, 192])
+def test_decode_schedules_give_the_same_ids(lib, golden, B):
+    """s2vt_set_decode_schedule: the fused schedule (h_t W_hh^T of step t+1 as extra row blocks of step t's argmax launch, then a
+    cell-update launch - /root/reference/S2VTModel.py:98-107 reordered around the one data dependence the token has) and the
+    step-kernel + argmax-kernel schedule decode the same ids, and both are the reference's on the rows of the unscaled fixture
+    whose margins are resolvable (B <= 128: the first B samples of c5raw's batch)."""
+    g = golden("c5raw")
+    d = dict(synth.CONFIGS["c5"])
+    seed = int(g["seed"])
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed, out_scale=1.0)
+    feats128, _, _ = synth.make_batch(128, d["L"], d["F"], d["V"], seed=1234 + seed)
+    feats = feats128[:B] if B <= 128 else torch.cat([feats128, feats128[:B - 128].flip(1)], dim=0)
+    m = _model(d, sd).eval()
+    prev = lib.s2vt_set_decode_schedule(-1)
+    out = {}
+    try:
+        for sched in (1, 0):
+            lib.s2vt_set_decode_schedule(sched)
+            assert lib.s2vt_set_decode_schedule(-1) == sched
+            with torch.no_grad():
+                out[sched] = m(feats.to(DEV), mode="test").cpu().numpy()
+    finally:
+        lib.s2vt_set_decode_schedule(prev)
+    np.testing.assert_array_equal(out[0], out[1])
+    n = min(B, 128)
+    rows = np.nonzero(g["greedy_margin"][:n].min(axis=1) >= 1e-4)[0]
+    assert len(rows) >= n - 8
+    np.testing.assert_array_equal(out[1][rows], g["greedy_ids"][rows])
+
+
 def test_c3_full_size_bf16_against_reference_golden(lib, golden):
     """BASELINE configs[2] at its own size: B=256, L=80, F=4096, H=E=1000, V=12000 with s2vt_set_gemm_mode(1) (bf16
     operands for the batched GEMMs and the recurrence - k padded 1000 -> 1024, 4000 -> 4032 - fp32 accumulation, cell
