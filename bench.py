@@ -544,6 +544,12 @@ def main():
             am_bytes = 4 * V * H + 4 * V + 4 * Bd * H + 8 * Bd         # W_o + b_o + h + packed argmax words
             am_gflop = 2.0 * Bd * V * H / 1e9
             planes = (mode != 0) and Bd % 64 == 0                      # the plane-path kernel (csrc/argmax_x3.hip)
+            fused = planes and lib.s2vt_set_decode_schedule(-1) == 1 and am_n == L
+            if fused:
+                # fused schedule: L launches do the L-1 argmax steps AND the L-1 recurrent GEMMs h_t W_hh^T (4H more rows of the
+                # same kernel; the first launch has only those, the last only the vocabulary's): FLOPs and bytes averaged per launch
+                am_gflop = 2.0 * Bd * (V + 4 * H) * H * (L - 1) / L / 1e9
+                am_bytes = int((4 * (V + 4 * H) * H + 4 * V + 4 * Bd * H + 8 * Bd + 16 * Bd * H) * (L - 1) / L)
             am_peak = (MFMA_BF16_PEAK_TF / 6.0) if planes else MFMA_F32_PEAK_TF
             decode = {"metric": "greedy-decode captions/sec", "value": round(Bd / ddt, 1), "unit": "captions/s",
                       "batch": Bd, "ms_per_call": round(ddt * 1e3, 2), "n_gpus": 1, "calls_timed": nd,
@@ -558,8 +564,9 @@ def main():
                           "pipe_counters": busy_of(busyd, busyd_src, "logits_argmax_x3_kernel" if planes else "logits_argmax_kernel") if Bd == 128 else None,
                           "algorithmic_bytes_per_launch": am_bytes,
                           "hbm_frac_by_algorithmic_bytes": round(am_bytes / (am_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                          "note": ("fp32-equivalent FLOP/s of h W_o^T against the bf16 dense MFMA peak / 6 plane products (3 bf16 planes "
-                                   "per operand); W_o planes are written once per decode call, h_t planes by the decode step kernel"
+                          "schedule": "fused (argmax of step t + h_t W_hh^T of step t+1 in one launch)" if fused else "step kernel + argmax kernel",
+                          "note": ("fp32-equivalent FLOP/s of h [W_o; W_hh]^T against the bf16 dense MFMA peak / 6 plane products (3 bf16 planes "
+                                   "per operand); the weight planes are written once per weight version, h_t planes by the cell-update kernel"
                                    if planes else "fp32-input MFMA kernel (batches that are not multiples of 64)")}}
             # ---- beam search (BASELINE configs[4]: B=128, beam_size 5, depth 30)
             # The interpreter's cyclic collector is run before the leg: a generation-2 pass over what the training leg left
