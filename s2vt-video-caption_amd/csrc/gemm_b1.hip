@@ -208,7 +208,8 @@ __global__ __launch_bounds__(512) void gemm_b1_kernel(GemmB1Args p) {
         bf16x8 ax[MI], bx[2], ay[MI], by[2];
         // request set k of the next stage: waves 0-3 issue it BEHIND product group k, waves 4-7 (their SIMD partners) IN FRONT of
         // it - while one wave of a SIMD spends ~100-150 cycles per request at the issue port, its partner feeds the matrix pipe
-        // (all eight waves behind the group: every shape of the config-3 step 4-6 % slower, profiles/round4_gemm_b1_shapes.txt)
+        // (all eight waves behind the group measured 4-6 % slower on every shape of the config-3 step when this schedule was built;
+        // the shipped kernel's per-shape table: profiles/round4_gemm_b1_shapes.txt)
         const bool early = more && wave >= 4, late = more && wave < 4;
 #define B1_REQS(K) { B1_REQ(K, ra, rb, koff, ns) B1_REQ((K) + 4, ra, rb, koff, ns) if constexpr ((K) == 0) { B1_REQ(8, ra, rb, koff, ns) } }
         B1_FENCE

@@ -403,6 +403,35 @@ def test_decode_schedules_give_the_same_ids(lib, golden, B):
     np.testing.assert_array_equal(out[1][rows], g["greedy_ids"][rows])
 
 
+@pytest.mark.parametrize("dims", [(64, 5, 70, 44, 28, 61), (128, 4, 36, 100, 52, 333), (192, 7, 24, 72, 40, 130), (256, 12, 24, 16, 8, 12)])
+def test_decode_schedules_on_ragged_shapes_against_the_oracle(lib, dims):
+    """The fused decode schedule at shapes where nothing is a multiple of a tile: 4H = 176 / 400 / 288 / 64 rows of W_hh planes (a
+    partial last 64-row block, or exactly one), V = 61 / 333 / 130 / 12 vocabulary rows, H = 44 (k padded 44 -> 64).  Both
+    schedules give the same ids, and on every row whose weakest top-2 margin in the oracle is >= 1e-4 they are the oracle's
+    (oracle/s2vt_oracle.py::greedy_decode, the restatement of /root/reference/S2VTModel.py:82-110)."""
+    B, L, Fd, H, E, V = dims
+    sd = synth.make_state_dict(V, Fd, H, E, seed=11)
+    feats, _, _ = synth.make_batch(B, L, Fd, V, seed=12)
+    import S2VTModel
+    m = S2VTModel.S2VT(V, Fd, L, dim_hid=H, dim_embed=E)
+    m.load_state_dict(sd)
+    m.to(DEV).eval()
+    prev = lib.s2vt_set_decode_schedule(-1)
+    out = {}
+    try:
+        for sched in (1, 0):
+            lib.s2vt_set_decode_schedule(sched)
+            with torch.no_grad():
+                out[sched] = m(feats.to(DEV), mode="test").cpu()
+    finally:
+        lib.s2vt_set_decode_schedule(prev)
+    assert torch.equal(out[0], out[1])
+    oids, marg = orc.greedy_decode(sd, feats, return_margins=True)
+    rows = (marg.reshape(B, -1).min(dim=1).values >= 1e-4).nonzero().flatten()
+    assert len(rows) >= B // 2, len(rows)
+    assert torch.equal(out[1][rows], oids[rows])
+
+
 def test_c3_full_size_bf16_against_reference_golden(lib, golden):
     """BASELINE configs[2] at its own size: B=256, L=80, F=4096, H=E=1000, V=12000 with s2vt_set_gemm_mode(1) (bf16
     operands for the batched GEMMs and the recurrence - k padded 1000 -> 1024, 4000 -> 4032 - fp32 accumulation, cell
