@@ -503,5 +503,7 @@ if __name__ == "__main__":
         gen_c5full(*C5FULL_CHOICE)
     if "c5raw" in which:
         gen_c5raw(C5FULL_CHOICE[0])
+    if "c5rawbeam" in which:     # the UNSCALED beam fixture: the reference's 128 beam searches with the recipe's weights as they are
+        gen_c5full(C5FULL_CHOICE[0], 1.0, name="c5rawbeam")
     if "c5beam" in which:
         gen_beam_only("c5beam", "c5", seed=C5_CHOICE[0], beam_b=4, beam_width=5, out_scale=C5_CHOICE[1])

@@ -83,13 +83,18 @@ __device__ __forceinline__ void bq_pop(float* hk, int* hc, int S, int lane, int&
     bq_siftdown(hk, hc, S, lane, 0, pos);
 }
 
-__global__ void beam_queue_kernel(BeamQ q) {
-    extern __shared__ unsigned char bq_smem[];
-    const int S = blockDim.x, lane = threadIdx.x;
-    const int b = blockIdx.x * S + lane;
-    float* hk = reinterpret_cast<float*>(bq_smem);
-    int* hc = reinterpret_cast<int*>(bq_smem + (size_t)q.NC * S * sizeof(float));
-    if (b >= q.B) return;
+// One WAVE per sample.  The pushes of a depth are laid out in push order (ck / cc); what the reference's heap then yields is
+//   (a) its root after the push phase (the entry :231 would pop) and (b) the first beam_width pops.
+// A binary heap pops in ascending key order whatever its layout as long as the keys involved are DISTINCT, so the wave selects the
+// smallest remaining key beam_width times (butterfly min + a ballot count of the candidates that hold it); the moment two
+// candidates share the smallest remaining key - the only case in which the heap's internal layout decides - lane 0 replays
+// heapq's own _siftdown / _siftup over the same push sequence instead (the single-lane replay took 86 us per depth for every
+// sample; the selection takes ~5).
+constexpr int BQ_MAXC = BQ_MAXBW * BQ_FAN + BQ_MAXBW;     // candidates of one depth
+__global__ __launch_bounds__(64) void beam_queue_kernel(BeamQ q) {
+    __shared__ float ck[BQ_MAXC], hk[BQ_MAXC], selk[BQ_MAXBW];
+    __shared__ int cc[BQ_MAXC], hc[BQ_MAXC], selc[BQ_MAXBW];
+    const int b = blockIdx.x, lane = threadIdx.x;
     const int bw = q.bw;
     float* bkey = q.beam_key + b * bw;
     int* bnid = q.beam_nid + b * bw;
@@ -97,53 +102,97 @@ __global__ void beam_queue_kernel(BeamQ q) {
     int* bflag = q.beam_flag + b * bw;
     int* ntok = q.node_tok + (int64_t)b * q.NN;
     int* nprev = q.node_prev + (int64_t)b * q.NN;
-    int n = 0;
+    int n = 0;                                 // pushes of this depth (wave-uniform)
     if (q.depth == 1) {        // the root: BeamSearchNode(hidden, None, <sos>, 0, 1), key -0.0 (:186-188)
-        q.n_nodes[b] = 1;
-        ntok[0] = q.sos; nprev[0] = -1;
-        q.done[b] = 0;
-        q.best_tok[b] = q.sos; q.best_node[b] = -1;
-        for (int j = 0; j < bw; ++j) {
-            q.row_b[b * bw + j] = b;
-            bflag[j] = 0;
+        if (lane == 0) {
+            q.n_nodes[b] = 1;
+            ntok[0] = q.sos; nprev[0] = -1;
+            q.done[b] = 0;
+            q.best_tok[b] = q.sos; q.best_node[b] = -1;
+            for (int j = 0; j < bw; ++j) {
+                q.row_b[b * bw + j] = b;
+                bflag[j] = 0;
+            }
+            ck[0] = -0.0f; cc[0] = -1;
         }
-        bq_push(hk, hc, S, lane, n, -0.0f, -1);
+        n = 1;
     } else {
         if (q.done[b]) return;             // frozen: its beam slots were cleared when it stopped
         // ---- push phase of the depth that was just stepped, in beam (= pop) order (:198-223)
         for (int j = 0; j < bw; ++j) {
             const int flag = bflag[j];
             if (flag == 2) {
-                bq_push(hk, hc, S, lane, n, bkey[j], j * 32 + BQ_FIN);
+                if (lane == 0) { ck[n] = bkey[j]; cc[n] = j * 32 + BQ_FIN; }
+                n += 1;
             } else if (flag == 1) {
-                const float div = q.pow07[blen[j] + 1];
-                const float* lp = q.top_lp + (int64_t)(b * bw + j) * BQ_FAN;
-                for (int f = 0; f < BQ_FAN; ++f) bq_push(hk, hc, S, lane, n, -(lp[f] / div), j * 32 + f);
+                if (lane < BQ_FAN) {
+                    const float div = q.pow07[blen[j] + 1];
+                    ck[n + lane] = -(q.top_lp[(int64_t)(b * bw + j) * BQ_FAN + lane] / div);
+                    cc[n + lane] = j * 32 + lane;
+                }
+                n += BQ_FAN;
             }
         }
+    }
+    __syncthreads();
+    // ---- selection: the root, and (unless the sample stops here or this is the final push) the first beam_width pops
+    const bool stops = q.depth != 1 && n <= bw;                        // (:227-228)
+    const int m = (q.depth == 0 || stops) ? 1 : (n < bw ? n : bw);
+    constexpr int CPL = (BQ_MAXC + 63) / 64;                            // candidates per lane
+    float myk[CPL];
+    bool live[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+        const int pidx = lane + 64 * c;
+        live[c] = pidx < n;
+        myk[c] = live[c] ? ck[pidx] : INFINITY;
+    }
+    bool tie = false;
+    for (int r = 0; r < m && !tie; ++r) {
+        float mn = INFINITY;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) mn = (live[c] && myk[c] < mn) ? myk[c] : mn;
+        for (int o = 32; o; o >>= 1) { const float ov = __shfl_xor(mn, o); mn = ov < mn ? ov : mn; }
+        int holders = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) holders += __popcll(__ballot(live[c] && myk[c] == mn));
+        if (holders != 1) { tie = true; break; }                        // (also: no live candidate compares equal - a NaN key)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+            if (live[c] && myk[c] == mn) { selk[r] = mn; selc[r] = cc[lane + 64 * c]; live[c] = false; }
+    }
+    __syncthreads();
+    if (lane != 0) return;
+    int rootc;
+    if (tie) {                              // exact replay of the reference's heap
+        int hn = 0;
+        for (int i = 0; i < n; ++i) bq_push(hk, hc, 1, 0, hn, ck[i], cc[i]);
+        rootc = hc[0];
+        if (!(q.depth == 0 || stops))
+            for (int j = 0; j < m; ++j) bq_pop(hk, hc, 1, 0, hn, selk[j], selc[j]);
+    } else {
+        rootc = selc[0];
+    }
+    if (q.depth != 1) {
         // ---- the entry the reference would pop at the end (:231): the heap's root after this push phase
-        {
-            const int code = hc[lane], j = code >> 5, f = code & 31;
-            if (f == BQ_FIN) { q.best_tok[b] = q.eos; q.best_node[b] = nprev[bnid[j]]; }
-            else { q.best_tok[b] = q.top_ix[(int64_t)(b * bw + j) * BQ_FAN + f]; q.best_node[b] = bnid[j]; }
-        }
-        if (n <= bw) {                     // (:227-228)
+        const int j = rootc >> 5, f = rootc & 31;
+        if (f == BQ_FIN) { q.best_tok[b] = q.eos; q.best_node[b] = nprev[bnid[j]]; }
+        else { q.best_tok[b] = q.top_ix[(int64_t)(b * bw + j) * BQ_FAN + f]; q.best_node[b] = bnid[j]; }
+        if (stops) {
             q.done[b] = 1;
             atomicAdd(q.done_count, 1);
-            for (int j = 0; j < bw; ++j) { bflag[j] = 0; q.row_state[b * bw + j] = 0; q.row_tok[b * bw + j] = 0; }
+            for (int jj = 0; jj < bw; ++jj) { bflag[jj] = 0; q.row_state[b * bw + jj] = 0; q.row_tok[b * bw + jj] = 0; }
             return;
         }
     }
     if (q.depth == 0) return;              // final push: nothing is popped any more
     // ---- pop phase: up to beam_width entries, queue cleared (:190-194); a popped candidate becomes a node now
-    const int m = n < bw ? n : bw;
     float pk[BQ_MAXBW];
     int ptok[BQ_MAXBW], pnid[BQ_MAXBW], plen[BQ_MAXBW], prow[BQ_MAXBW];
     int nn = q.n_nodes[b];
     for (int j = 0; j < m; ++j) {
-        float key;
-        int code;
-        bq_pop(hk, hc, S, lane, n, key, code);
+        const float key = selk[j];
+        const int code = selc[j];
         pk[j] = key;
         if (code < 0) {                    // the root
             ptok[j] = q.sos; pnid[j] = 0; plen[j] = 1; prow[j] = b;
@@ -248,17 +297,7 @@ int s2vt_beam_queue_step(int32_t B, int32_t beam_width, int32_t max_depth, int32
         S2VT_HIP(hipStreamSynchronize(st));                  // (the table leaves scope; once per search)
         S2VT_HIP(hipMemsetAsync(q.done_count, 0, sizeof(int), st));
     }
-    // one lane per sample, the heaps of a workgroup's samples side by side in LDS (8 bytes per entry)
-    int S = 64;
-    while (S > 8 && (size_t)S * q.NC * 8 > 150 * 1024) S >>= 1;
-    const size_t lds = (size_t)S * q.NC * 8;
-    S2VT_REQUIRE(lds <= 160 * 1024, "s2vt_beam_queue_step: beam_width %d needs %zu bytes of LDS per 8 samples", beam_width, lds);
-    static bool attr_set = false;
-    if (!attr_set) {
-        S2VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&beam_queue_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(beam_queue_kernel, dim3(cdiv(B, S)), dim3(S), lds, st, q);
+    hipLaunchKernelGGL(beam_queue_kernel, dim3(B), dim3(64), 0, st, q);
     S2VT_LAUNCH_CHECK("beam_queue_kernel");
     return 0;
 }

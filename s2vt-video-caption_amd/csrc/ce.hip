@@ -2,6 +2,8 @@
 // 'mean' reduction over all B*(L-1) rows against target[:, 1:]) and its gradient.
 // One 256-thread workgroup per logits row: 16-B vector loads, wave shuffles + LDS for the row max and
 // the exp-sum; per-row losses are then summed in a fixed order by a single workgroup (deterministic).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -225,9 +227,97 @@ __global__ __launch_bounds__(256) void top20_logprob_kernel(const float* logits,
     }
 }
 
+// The same selection with the row in REGISTERS (VPT elements per thread, element i = tid + 256 j): the owner's rescan after an
+// extraction is VPT register compares instead of VPT dependent LDS reads (the LDS form spent 1.4 of its 4.7 us per extraction
+// there: 95 us per launch at V = 12000, 640 rows; this one ~25).  Same arithmetic in the same order: max, then the sum of
+// expf(x - max) per thread in ascending i, wave butterflies, (w0 + w1) + (w2 + w3); ties -> the lower token id.
+template <int VPT>
+__global__ __launch_bounds__(256) void top20_logprob_reg_kernel(const float* logits, int64_t ld, int V, int32_t* top_ix,
+                                                                float* top_lp) {
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    __shared__ float sel_v[TOPK_N];
+    __shared__ int sel_i[TOPK_N];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = logits + (int64_t)blockIdx.x * ld;
+    float vals[VPT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+        const int i = tid + 256 * j;
+        vals[j] = (i < V) ? src[i] : -INFINITY;
+        mx = fmaxf(mx, vals[j]);
+    }
+    for (int o = 32; o; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red_v[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_v[0], red_v[1]), fmaxf(red_v[2], red_v[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j)
+        if (tid + 256 * j < V) sum += expf(vals[j] - mx);
+    for (int o = 32; o; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red_v[wave] = sum;
+    __syncthreads();
+    const float lse = mx + logf((red_v[0] + red_v[1]) + (red_v[2] + red_v[3]));
+    __syncthreads();
+    float bv;
+    int bj;
+    auto rescan = [&]() {
+        bv = -INFINITY; bj = -1;
+#pragma unroll
+        for (int j = 0; j < VPT; ++j)
+            if (vals[j] > bv) { bv = vals[j]; bj = j; }      // ascending i: the first (lowest id) of equal values is kept
+    };
+    rescan();
+    for (int k = 0; k < TOPK_N; ++k) {
+        float v = bv;
+        int ix = bj >= 0 ? tid + 256 * bj : 0x7fffffff;
+        for (int o = 32; o; o >>= 1) {
+            const float ov = __shfl_xor(v, o);
+            const int oi = __shfl_xor(ix, o);
+            if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+        }
+        if (lane == 0) { red_v[wave] = v; red_i[wave] = ix; }
+        __syncthreads();
+        v = red_v[0]; ix = red_i[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (red_v[w] > v || (red_v[w] == v && red_i[w] < ix)) { v = red_v[w]; ix = red_i[w]; }
+        if (tid == 0) { sel_v[k] = v; sel_i[k] = ix; }
+        if ((ix & 255) == tid && ix < V) {           // owner: remove it and find the next best of its elements
+            const int jj = ix >> 8;
+#pragma unroll
+            for (int j = 0; j < VPT; ++j)
+                if (j == jj) vals[j] = -INFINITY;
+            rescan();
+        }
+        __syncthreads();
+    }
+    if (tid < TOPK_N) {                              // rank by token id (ids are distinct)
+        const int my = sel_i[tid];
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < TOPK_N; ++j) rank += (sel_i[j] < my);
+        top_ix[(int64_t)blockIdx.x * TOPK_N + rank] = my;
+        top_lp[(int64_t)blockIdx.x * TOPK_N + rank] = sel_v[tid] - lse;
+    }
+}
+
 int top20_logprob(hipStream_t s, const float* logits, int64_t ld, int64_t rows, int V, int32_t* top_ix, float* top_lp) {
     if (rows <= 0) return 0;
     S2VT_REQUIRE(V >= TOPK_N && (size_t)V * sizeof(float) <= 150 * 1024, "top20_logprob: 20 <= vocab_size <= 38400");
+    static const bool lds_form = getenv("S2VT_TOP20_LDS") && atoi(getenv("S2VT_TOP20_LDS")) != 0;      // A/B switch
+    if (!lds_form && V <= 256 * 64) {
+        const dim3 grid((unsigned)rows), block(256);
+        if (V <= 256 * 16) hipLaunchKernelGGL(top20_logprob_reg_kernel<16>, grid, block, 0, s, logits, ld, V, top_ix, top_lp);
+        else if (V <= 256 * 32) hipLaunchKernelGGL(top20_logprob_reg_kernel<32>, grid, block, 0, s, logits, ld, V, top_ix, top_lp);
+        else if (V <= 256 * 48) hipLaunchKernelGGL(top20_logprob_reg_kernel<48>, grid, block, 0, s, logits, ld, V, top_ix, top_lp);
+        else hipLaunchKernelGGL(top20_logprob_reg_kernel<64>, grid, block, 0, s, logits, ld, V, top_ix, top_lp);
+        S2VT_LAUNCH_CHECK("top20_logprob_reg_kernel");
+        return 0;
+    }
     if ((size_t)V * sizeof(float) > 48 * 1024)
         S2VT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(top20_logprob_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)V * sizeof(float))));

@@ -197,9 +197,12 @@ def decode_cache_entry(owner, raw_params, d, dev, lib):
            str(dev), torch.cuda.current_stream(dev).cuda_stream)
     entry = _DECODE_CACHES.get(owner)
     cbytes = lib.s2vt_decode_cache_bytes(ctypes.byref(d))
-    valid = entry is not None and entry[0] == key and entry[1].numel() >= cbytes
-    if not valid:
-        entry = (key, torch.empty(cbytes, dtype=torch.uint8, device=dev))
+    # entry = [key, tensor, filled]: "the images are there" is recorded by the call that WROTE them (greedy_decode below), not
+    # inferred from the entry's existence - a lookup that only allocates (the beam search asks before it decides to fill) must
+    # not make the next lookup believe the fresh tensor holds anything
+    valid = entry is not None and entry[0] == key and entry[1].numel() >= cbytes and entry[2]
+    if entry is None or entry[0] != key or entry[1].numel() < cbytes:
+        entry = [key, torch.empty(cbytes, dtype=torch.uint8, device=dev), False]
         _DECODE_CACHES[owner] = entry
     return entry[1], valid
 
@@ -224,6 +227,9 @@ def greedy_decode(feats, params, sos_ix, owner=None):
             capi.check(lib.s2vt_greedy_decode_cached(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), int(sos_ix), _ptr(ids),
                                                      _ptr(ws), nbytes, _ptr(cache), cache.numel(), 1 if valid else 0,
                                                      _stream(dev)), "s2vt_greedy_decode_cached")
+            entry = _DECODE_CACHES.get(owner)
+            if entry is not None and entry[1] is cache:
+                entry[2] = True                     # (stream-ordered: later calls on this stream see the filled images)
         else:
             capi.check(lib.s2vt_greedy_decode(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), int(sos_ix), _ptr(ids),
                                               _ptr(ws), nbytes, _stream(dev)), "s2vt_greedy_decode")

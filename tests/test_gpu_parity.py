@@ -373,6 +373,37 @@ def test_c5_unscaled_greedy_batch_against_reference_golden(lib, golden):
     np.testing.assert_array_equal(ids[rows], g["greedy_ids"][rows])
 
 
+def test_c5_unscaled_beam_batch_against_reference_golden(lib, golden):
+    """The UNSCALED companion of c5full's beam half (tests/golden/c5rawbeam.npz, oracle/make_golden.py c5rawbeam: the reference's
+    128 beam searches - beam 5, depth 30, S2VTModel.py:149-240 - with the recipe's weights as they are).  With out_scale 1 the
+    log-probs of a step lie within ~1e-3 of each other, so the 31 non-cumulative score decisions of a search are close calls by
+    construction: the fixture's weakest decision gap is below 1e-4 for ALL 128 samples and below 1e-6 (two fp32 ulps of a score
+    of 3) for 42 - which is why c5full scales the logits.  What this fixture pins: every sample whose weakest gap is >= GATE (one
+    part in 3e6 of a score) must come out bit-exact, the number of samples compared is asserted, and at most 8 of the excused ones
+    may differ (measured: all 128 identical, on the device-queue + plane-path default as on the host-queue / fp32-step paths).
+    The model is fresh: the beam search is its FIRST call, so the plane path has to fill the weight-image cache itself (a lookup
+    that only allocated the cache once made the filling call believe it was filled: every caption came out as one token)."""
+    g = golden("c5rawbeam")
+    d = dict(synth.CONFIGS["c5"])
+    seed = int(g["seed"])
+    assert float(g["out_scale"]) == 1.0 and int(g["dims"][0]) == d["B"] == 128
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=seed, out_scale=1.0)
+    feats, _, _ = synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=1234 + seed)
+    m = _model(d, sd).eval()
+    with torch.no_grad():
+        out = m(feats.to(DEV), mode="beam_search", beam_width=int(g["beam_width"]), max_beam_depth=30)
+    GATE = 1e-6
+    gap = g["beam_gap"]
+    compared = np.nonzero(gap >= GATE)[0]
+    assert len(compared) >= 85, len(compared)
+    same = np.array([[int(t.item()) for t in s] == [int(x) for x in g["beam_ids"][b] if x >= 0] for b, s in enumerate(out)])
+    print("c5rawbeam: identical rows %d/128; differing gaps %s" % (int(same.sum()), np.sort(gap[~same])[-5:]))
+    assert same[compared].all(), [(int(b), float(gap[b])) for b in compared if not same[b]]
+    assert int(same.sum()) >= 120, int(same.sum())
+    from s2vt_video_caption_amd import beam as _beam
+    assert _beam.LAST_PATH.startswith("device queues + plane-path"), _beam.LAST_PATH
+
+
 @pytest.mark.parametrize("B", [64, 128, 192])
 def test_decode_schedules_give_the_same_ids(lib, golden, B):
     """s2vt_set_decode_schedule: the fused schedule (h_t W_hh^T of step t+1 as extra row blocks of step t's argmax launch, then a
