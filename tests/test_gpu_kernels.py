@@ -475,8 +475,9 @@ def test_feat_proj_fwd_bwd(lib):
 
 
 
+@pytest.mark.parametrize("bw", [5, 3, 8])
 @pytest.mark.parametrize("ties", [False, True])
-def test_device_beam_queues_match_reference_heap(lib, ties):
+def test_device_beam_queues_match_reference_heap(lib, ties, bw):
     """csrc/beam_queue.hip against the literal heap bookkeeping of S2VTModel.py:186-236 (beam.HeapQueues): the same synthetic
     top-20 tables (ascending token ids, random log-probs - small integers in the `ties` case, where WHICH entries pop first
     depends on the binary heap's internal layout) are fed to both, depth by depth; popped tokens, the set of frozen samples at
@@ -485,7 +486,7 @@ def test_device_beam_queues_match_reference_heap(lib, ties):
     import ctypes
     from s2vt_video_caption_amd import beam
     from s2vt_video_caption_amd.functional import _ptr, _stream
-    B, bw, D, V, sos, eos = 37, 5, 12, 23, 1, 2
+    B, D, V, sos, eos = 37, 12, 23, 1, 2            # (bw = 8: the kernel's widest beam, 168 candidates per depth = 3 per lane)
     R = B * bw
     for seed in range(4):
         rng = np.random.default_rng(seed + (100 if ties else 0))
