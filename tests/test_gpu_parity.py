@@ -404,6 +404,46 @@ def test_c5_unscaled_beam_batch_against_reference_golden(lib, golden):
     assert _beam.LAST_PATH.startswith("device queues + plane-path"), _beam.LAST_PATH
 
 
+@pytest.mark.parametrize("B", [64, 192])
+def test_beam_plane_path_fills_and_follows_the_weight_cache(lib, B):
+    """The plane-path depth step (s2vt_beam_step_cached) reads weight images that mode='test' normally leaves behind.  Scenarios in
+    which nobody has: the beam search is a fresh model's first call; the weights moved in place since the last decode (an optimiser
+    step: version counters); a second model with other weights decodes in between.  In each the default path must give what the
+    path that reads the fp32 parameters directly gives (beam.PLANE_STEP = False: s2vt_beam_step; >= 95 % of the captions identical -
+    the two round differently, so a 1-ulp score tie may fall the other way) - stale or unfilled images give 0 %."""
+    from s2vt_video_caption_amd import beam
+    d = dict(synth.CONFIGS["c5"])
+    feats = synth.make_batch(B, d["L"], d["F"], d["V"], seed=77)[0].to(DEV)
+
+    def captions(m, plane):
+        keep = beam.PLANE_STEP
+        beam.PLANE_STEP = plane
+        try:
+            with torch.no_grad():
+                out = m(feats, mode="beam_search", beam_width=5, max_beam_depth=12)
+        finally:
+            beam.PLANE_STEP = keep
+        assert ("plane-path" in beam.LAST_PATH) == plane, beam.LAST_PATH
+        return [[int(t.item()) for t in s] for s in out]
+
+    def agree(a, b):
+        return sum(x == y for x, y in zip(a, b)) / len(a)
+    ma = _model(d, synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=21)).eval()
+    mb = _model(d, synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=22)).eval()
+    a1 = captions(ma, True)                                    # first call of a fresh model
+    assert agree(a1, captions(ma, False)) >= 0.95
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    with torch.no_grad():
+        for p_ in ma.parameters():                             # what an optimiser step does: in place, version counters move
+            p_.add_(0.02 * p_.abs().mean() * torch.randn(p_.shape, generator=gen).to(DEV))
+    b1 = captions(mb, True)                                    # another model's images in between
+    a2 = captions(ma, True)
+    assert agree(a2, captions(ma, False)) >= 0.95
+    assert agree(a2, a1) < 0.5                                 # (the weights did move)
+    assert agree(b1, captions(mb, False)) >= 0.95
+    assert captions(ma, True) == a2                            # and the cached images serve the next call
+
+
 @pytest.mark.parametrize("B", [64, 128, 192])
 def test_decode_schedules_give_the_same_ids(lib, golden, B):
     """s2vt_set_decode_schedule: the fused schedule (h_t W_hh^T of step t+1 as extra row blocks of step t's argmax launch, then a
