@@ -180,18 +180,19 @@ def _c2_body(g, d, sd, feats, caps, mask, greedy=True):
 
 
 @pytest.mark.parametrize("name,cfg,gemm_mode,bound", [("c1long", "c1", 3, 1e-4), ("mid64long", "mid64", 3, 1e-4),
-                                                      ("mid64long", "mid64", 0, 1e-4), ("mid64long", "mid64", 1, 5e-2),
-                                                      ("c3long", "c3", 1, 2e-2), ("c2long", "c2", 3, 1e-4)])
+                                                      ("mid64long", "mid64", 0, 1e-4), ("mid64long", "mid64", 1, 5e-3),
+                                                      ("c3long", "c3", 1, 5e-3), ("c2long", "c2", 3, 1e-4)])
 def test_long_loss_trajectory_against_reference(lib, golden, name, cfg, gemm_mode, bound):
     """FORTY Adam steps on one fixed batch at ten times train.py's learning rate (the reference's loss falls from 4.6 to
     0.007 at c1 dims, from 7.0 to 2.1 at B=64): every step runs on weights that carry the rounding history of all earlier
     steps, Adam's division included.  north_star's bound - training loss within 1e-4 - must hold at EVERY step for the
     fp32 paths (measured 5e-7: B=4 takes the fp32-MFMA driver, B=64 the split-precision two-stream driver, mode 0 its
-    fp32-MFMA twin); the bf16 configuration (mode 1, persistent recurrence kernels) stays within 5e-2 of the same fp32
-    trajectory.  Final parameter norms within 1e-4 (fp32) / 2e-2 (bf16) relative.
+    fp32-MFMA twin); the bf16 configuration (mode 1, persistent recurrence kernels) stays within 5e-3 of the same fp32
+    trajectory (measured 1.2e-3).  Final parameter norms within 1e-4 (fp32) / 2e-3 (bf16; measured 4e-4) relative.
     c3long: BASELINE configs[2] AT ITS OWN SIZE (B=256, H=E=1000, V=12000): TEN fp32 Adam steps of the reference (lr 1e-3,
     one batch; train.py:116-127) against the bf16 configuration - persistent recurrence, bf16 batched GEMMs - step by step:
-    |loss - reference| < 2e-2 at every step while the reference's loss moves by far more than that, final norms within 2 %.
+    |loss - reference| < 5e-3 at every step (measured 1.5e-3, round 4; the reference's loss falls from 9.53 to 1.46), final norms
+    within 0.2 % (measured 0.04 %).
     c2long: BASELINE configs[1] - the headline workload - AT ITS OWN SIZE (B=64, H=E=1000, V=12000): ten fp32 Adam steps of the
     reference against the timed configuration (split-precision GEMMs, split-precision persistent forward recurrence, two-lane
     BPTT): north_star's 1e-4 on the loss at every step, final parameter norms within 1e-4."""
@@ -220,7 +221,7 @@ def test_long_loss_trajectory_against_reference(lib, golden, name, cfg, gemm_mod
         lib.s2vt_set_gemm_mode(prev)
     diff = np.abs(np.array(losses) - g["losses"])
     assert diff.max() < bound, (int(diff.argmax()), float(diff.max()))
-    rel = 1e-4 if gemm_mode != 1 else 2e-2
+    rel = 1e-4 if gemm_mode != 1 else 2e-3
     for k, v in m.state_dict().items():
         ref = float(g["finalnorm/" + k])
         assert abs(float(v.double().norm()) - ref) <= rel * ref + 1e-9, k
@@ -507,9 +508,10 @@ def test_c3_full_size_bf16_against_reference_golden(lib, golden):
     """BASELINE configs[2] at its own size: B=256, L=80, F=4096, H=E=1000, V=12000 with s2vt_set_gemm_mode(1) (bf16
     operands for the batched GEMMs and the recurrence - k padded 1000 -> 1024, 4000 -> 4032 - fp32 accumulation, cell
     state and gradients), against ONE fp32 train step of the reference on the same seeded inputs (tests/golden/c3.npz).
-    Stated bf16 bounds: loss within 2e-3 (measured ~1e-4: the mean over 20 224 rows averages the rounding out), logits
-    slice within 2e-2 of the largest logit, every gradient's norm within 2 %, its first 32 entries within 8 % of their
-    largest.  Plus the size-independent properties: finite, deterministic (bitwise), batch-independent rows, and the
+    Stated bf16 bounds (round 4: three times what was measured): loss within 1e-3 (measured 2.7e-4: the mean over 20 224 rows
+    averages the rounding out), logits slice within 2e-2 of the largest logit (6e-3), every gradient's norm within 0.6 % (0.21 %),
+    its first 32 entries within 4 % of their largest (1.4 %), and every FULL gradient within 1.5 % (relative L2; 0.48 %) and
+    cosine 0.9999 (1 - 1e-5) of the fp32-equivalent arithmetic's, which is itself held to the reference at fp32 bounds.  Plus the size-independent properties: finite, deterministic (bitwise), batch-independent rows, and the
     persistent recurrence schedule equal to the launch-per-timestep one within bf16 re-rounding."""
     import utils
     g = golden("c3")
@@ -525,17 +527,17 @@ def test_c3_full_size_bf16_against_reference_golden(lib, golden):
         loss.backward()
         torch.cuda.synchronize()
         assert torch.isfinite(logits).all()
-        assert abs(float(loss) - float(g["losses"][0])) < 2e-3, (float(loss), float(g["losses"][0]))
+        assert abs(float(loss) - float(g["losses"][0])) < 1e-3, (float(loss), float(g["losses"][0]))
         ref_rows = g["logits_rows"]
         assert np.abs(logits.detach()[:, ::13, :64].cpu().numpy() - ref_rows).max() < 2e-2 * np.abs(ref_rows).max()
         for key, p in m.named_parameters():
             gn = float(g["gradnorm/" + key])
             assert torch.isfinite(p.grad).all(), key
-            assert abs(float(p.grad.double().norm()) - gn) <= 2e-2 * gn, (key, float(p.grad.double().norm()), gn)
+            assert abs(float(p.grad.double().norm()) - gn) <= 6e-3 * gn, (key, float(p.grad.double().norm()), gn)
             ref = g["gradhead/" + key]
-            assert np.abs(p.grad.reshape(-1)[:32].cpu().numpy() - ref).max() <= 8e-2 * np.abs(ref).max() + 1e-9, key
+            assert np.abs(p.grad.reshape(-1)[:32].cpu().numpy() - ref).max() <= 4e-2 * np.abs(ref).max() + 1e-9, key
         # DIRECTION of every full gradient (a dropped plane, a mis-scaled tile or a skipped k range of one GEMM moves a norm by
-        # less than the 2 % above): the same step in the fp32-equivalent arithmetic (gemm mode 3) - itself held to the
+        # less than the 0.6 % above): the same step in the fp32-equivalent arithmetic (gemm mode 3) - itself held to the
         # reference's norms and leading entries at fp32 bounds here - and the cosine between the two, per parameter
         bf_grads = {key: p.grad.detach().clone() for key, p in m.named_parameters()}
         lib.s2vt_set_gemm_mode(3)
@@ -549,7 +551,8 @@ def test_c3_full_size_bf16_against_reference_golden(lib, golden):
             assert np.abs(p.grad.reshape(-1)[:32].cpu().numpy() - ref).max() <= 2e-6 + 5e-4 * np.abs(ref).max(), key
             a, b = bf_grads[key].double().reshape(-1), p.grad.double().reshape(-1)
             cos = float((a @ b) / (a.norm() * b.norm()))
-            assert cos >= 0.999, (key, cos)
+            assert cos >= 0.9999, (key, cos)
+            assert float((a - b).norm() / b.norm()) <= 1.5e-2, (key, float((a - b).norm() / b.norm()))
         del m3, bf_grads
         lib.s2vt_set_gemm_mode(1)
         with torch.no_grad():
