@@ -385,6 +385,23 @@ int s2vt_set_pipeline_block(int32_t steps);
  * the two batch halves as independent chains on two streams.  Same ids either way.  Returns the previous value; any other
  * argument only queries. */
 int s2vt_set_decode_schedule(int32_t schedule);
+/* The encode phase of a decode alone - /root/reference/S2VTModel.py:56-60 (mode='beam_search': vid_rnn over the L frames, word_rnn
+ * over the padded vid_out) - on the plane path, with the weight-derived images in the caller's cache as in
+ * s2vt_greedy_decode_cached (cache_valid == 0: filled here, every image a decode or a beam search of these weights reads).
+ * workspace: s2vt_decode_workspace_bytes(d).  Out: vid_h, vid_c, word_h, word_c [B, H], the states after frame L-1 that
+ * S2VT.beam_search (:149) starts from.  Shapes the persistent split-precision recurrence does not take (B % 64, H > 1024,
+ * fp32-MFMA mode) return S2VT_ERR_ARG. */
+int s2vt_decode_encode_cached(const s2vt_dims* d, const s2vt_params* p, const float* feats, void* workspace, size_t workspace_bytes,
+                              void* cache, size_t cache_bytes, int32_t cache_valid, float* vid_h, float* vid_c, float* word_h,
+                              float* word_c, float* gx_dec, int32_t depth, void* stream);
+/* gx_dec (nullable) [depth][B][4H], depth <= L-1: vid_rnn's decode-phase steps take no input and see no token
+ * (/root/reference/S2VTModel.py:208-210 runs one per depth inside the search loop), so the first `depth` of them run here in one
+ * persistent launch and their half of word_rnn's gate input (h1_t W_v^T + both biases) comes out of one GEMM.
+ * s2vt_beam_step_gx is s2vt_beam_step_cached for a depth whose slice gx_dec[depth - 1] replaces the vid_rnn state arguments. */
+int s2vt_beam_step_gx(const s2vt_dims* d, const s2vt_params* p, int32_t R, const int32_t* row_b, const int32_t* row_state,
+                      const int32_t* tok, const float* gx_vid, const float* word_h_in, const float* word_c_in, float* word_h_out,
+                      float* word_c_out, int32_t* top_ix, float* top_lp, void* workspace, size_t workspace_bytes, void* cache,
+                      size_t cache_bytes, void* stream);
 /* 1 if the internal side stream was verified to execute concurrently with the caller's stream (it is chosen by a
  * one-time calibration at the first pipelined call: HIP may map two streams onto one hardware queue), 0 if no
  * candidate overlapped (the drivers still run, serially), -1 before the first pipelined call. */

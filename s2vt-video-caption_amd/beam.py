@@ -49,6 +49,8 @@ class BeamSearchNode(object):
 
 
 PERSISTENT_ENCODER = True        # A/B switch: encoder recurrences on the persistent split-precision kernels
+PLANE_ENCODER = True             # A/B switch: the whole encode phase by the library (s2vt_decode_encode_cached), GEMMs on the plane path
+VID_PRECOMPUTE = True            # A/B switch: vid_rnn's token-independent decode steps and their gate-input GEMM once, in front of the depth loop
 
 
 @torch.no_grad()
@@ -66,6 +68,14 @@ def beam_search(model, feats, params, beam_width=3, max_depth=30):
     w_e = w_ih2[:, :E]
 
     # ---- encoder: vid_rnn over the L real frames only, word_rnn with a zero embedding (S2VTModel.py:57-60)
+    lib0 = capi.load()
+    if (DEVICE_QUEUES and PLANE_STEP and PLANE_ENCODER and lib0.s2vt_beam_queue_bytes(B, beam_width, max_depth) > 0):
+        # the library's own encode phase (what mode='test' runs: plane-path GEMMs, paired persistent recurrence launches); it
+        # fills the weight-image cache the plane-path depth step reads
+        from . import functional
+        enc = functional.decode_encode(feats, params, model, depth=max_depth if VID_PRECOMPUTE else 0)
+        if enc is not None:
+            return _beam_search_device_queues(lib0, model, feats, params, B, H, beam_width, max_depth, sos, eos, *enc)
     x1 = ops.feat_proj_fwd(feats.contiguous(), w_f, b_f)                       # [L*B, H] time-major
     gx1 = _gemm_strided(x1, w_ih1, bsum1)
     # (the persistent split-precision recurrence, lstm_persist_x3.hip, where the shape is supported; else launches per timestep)
@@ -144,7 +154,8 @@ PLANE_STEP = True            # s2vt_beam_step_cached: the depth's GEMMs on the p
 LAST_PATH = None             # which path the last beam_search call took (bench.py reports it beside the rate)
 
 
-def _beam_search_device_queues(lib, model, feats, params, B, H, beam_width, max_depth, sos, eos, vid_h, vid_c, word_h, word_c):
+def _beam_search_device_queues(lib, model, feats, params, B, H, beam_width, max_depth, sos, eos, vid_h, vid_c, word_h, word_c,
+                               gx_dec=None):
     """The depth loop with the queue bookkeeping on the device: per depth ONE s2vt_beam_queue_step (push the children of the
     depth before, freeze finished samples, pop the next beam with heapq's own sift order, write the rows of the step) and ONE
     s2vt_beam_step over the fixed rows r = b * beam_width + slot; nothing crosses PCIe until the back-traced sequences at the
@@ -170,7 +181,10 @@ def _beam_search_device_queues(lib, model, feats, params, B, H, beam_width, max_
             if not valid:
                 cache = None
     global LAST_PATH
-    LAST_PATH = "device queues + plane-path depth step (decode cache)" if cache is not None else "device queues + fp32-MFMA depth step"
+    if cache is None:
+        gx_dec = None
+    LAST_PATH = ("device queues + plane-path depth step (decode cache)" + (", vid_rnn steps precomputed" if gx_dec is not None else "")) \
+        if cache is not None else "device queues + fp32-MFMA depth step"
     with torch.cuda.device(dev):
         nbytes = lib.s2vt_beam_workspace_bytes(ctypes.byref(d), R)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
@@ -204,7 +218,12 @@ def _beam_search_device_queues(lib, model, feats, params, B, H, beam_width, max_
             events.append(ev)
             (vh_in, vc_in), (vh_out, vc_out) = vid[(depth - 1) & 1], vid[depth & 1]
             (wh_in, wc_in), (wh_out, wc_out) = tab[(depth - 1) & 1], tab[depth & 1]
-            if cache is not None:
+            if gx_dec is not None:
+                capi.check(lib.s2vt_beam_step_gx(ctypes.byref(d), ctypes.byref(ps), R, _ptr(rows[0]), _ptr(rows[1]), _ptr(rows[2]),
+                                                 _ptr(gx_dec[depth - 1]), _ptr(wh_in), _ptr(wc_in), _ptr(wh_out), _ptr(wc_out),
+                                                 _ptr(top_ix), _ptr(top_lp), _ptr(ws), nbytes, _ptr(cache), cache.numel(), st),
+                           "s2vt_beam_step_gx")
+            elif cache is not None:
                 capi.check(lib.s2vt_beam_step_cached(ctypes.byref(d), ctypes.byref(ps), R, _ptr(rows[0]), _ptr(rows[1]), _ptr(rows[2]),
                                                      _ptr(vh_in), _ptr(vc_in), _ptr(vh_out), _ptr(vc_out), _ptr(wh_in), _ptr(wc_in),
                                                      _ptr(wh_out), _ptr(wc_out), _ptr(top_ix), _ptr(top_lp), _ptr(ws), nbytes,

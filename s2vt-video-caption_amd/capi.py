@@ -119,6 +119,10 @@ SIGNATURES = {
     "s2vt_set_gemm_mode": (c_int32, [c_int32]),
     "s2vt_set_pipeline_block": (c_int32, [c_int32]),
     "s2vt_set_decode_schedule": (c_int32, [c_int32]),
+    "s2vt_decode_encode_cached": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_int32,
+                                            c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+    "s2vt_beam_step_gx": (c_int32, [POINTER(Dims), POINTER(Params), c_int32] + [c_void_p] * 10 + [c_void_p, c_size_t, c_void_p, c_size_t,
+                                                                                                  c_void_p]),
     "s2vt_pipeline_overlaps": (c_int32, []),
     "s2vt_test_occupy_cus": (c_int32, [c_int32, c_int32, c_int64, c_void_p]),
     "s2vt_set_graph_mode": (c_int32, [c_int32]),

@@ -1601,7 +1601,17 @@ size_t s2vt_beam_workspace_bytes(const s2vt_dims* d, int32_t max_rows) {
 static int beam_step_impl(const s2vt_dims* d, const s2vt_params* p, int32_t R, const int32_t* row_b, const int32_t* row_state,
                           const int32_t* tok, const float* vid_h_in, const float* vid_c_in, float* vid_h_out, float* vid_c_out,
                           const float* word_h_in, const float* word_c_in, float* word_h_out, float* word_c_out, int32_t* top_ix,
-                          float* top_lp, void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, void* stream);
+                          float* top_lp, void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, void* stream,
+                          const float* gx_vid = nullptr);
+// the depth step with vid_rnn's part precomputed (s2vt_decode_encode_cached, gx_dec[depth - 1]): word step, out_linear, fan-out
+int s2vt_beam_step_gx(const s2vt_dims* d, const s2vt_params* p, int32_t R, const int32_t* row_b, const int32_t* row_state,
+                      const int32_t* tok, const float* gx_vid, const float* word_h_in, const float* word_c_in, float* word_h_out,
+                      float* word_c_out, int32_t* top_ix, float* top_lp, void* workspace, size_t workspace_bytes, void* cache,
+                      size_t cache_bytes, void* stream) {
+    S2VT_REQUIRE(cache && gx_vid, "s2vt_beam_step_gx: null cache / gx_vid");
+    return beam_step_impl(d, p, R, row_b, row_state, tok, nullptr, nullptr, nullptr, nullptr, word_h_in, word_c_in, word_h_out,
+                          word_c_out, top_ix, top_lp, workspace, workspace_bytes, cache, cache_bytes, stream, gx_vid);
+}
 int s2vt_beam_step(const s2vt_dims* d, const s2vt_params* p, int32_t R, const int32_t* row_b, const int32_t* row_state,
                    const int32_t* tok, const float* vid_h_in, const float* vid_c_in, float* vid_h_out, float* vid_c_out,
                    const float* word_h_in, const float* word_c_in, float* word_h_out, float* word_c_out, int32_t* top_ix,
@@ -1620,8 +1630,9 @@ int s2vt_beam_step_cached(const s2vt_dims* d, const s2vt_params* p, int32_t R, c
 static int beam_step_impl(const s2vt_dims* d, const s2vt_params* p, int32_t R, const int32_t* row_b, const int32_t* row_state,
                           const int32_t* tok, const float* vid_h_in, const float* vid_c_in, float* vid_h_out, float* vid_c_out,
                           const float* word_h_in, const float* word_c_in, float* word_h_out, float* word_c_out, int32_t* top_ix,
-                          float* top_lp, void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, void* stream) {
-    S2VT_REQUIRE(d && p && vid_h_in && vid_c_in && vid_h_out && vid_c_out && workspace, "s2vt_beam_step: null argument");
+                          float* top_lp, void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, void* stream,
+                          const float* gx_vid) {
+    S2VT_REQUIRE(d && p && workspace && (gx_vid || (vid_h_in && vid_c_in && vid_h_out && vid_c_out)), "s2vt_beam_step: null argument");
     S2VT_REQUIRE(R >= 0 && (R == 0 || (row_b && row_state && tok && word_h_in && word_c_in && word_h_out && word_c_out &&
                                         top_ix && top_lp)),
                  "s2vt_beam_step: null row argument");
@@ -1630,9 +1641,9 @@ static int beam_step_impl(const s2vt_dims* d, const s2vt_params* p, int32_t R, c
     const BeamWS w = carve_beam(*d, R > 0 ? R : 1, workspace);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if ((rc = add_vectors(st, p->vid_b_ih, p->vid_b_hh, w.bsum1, 4 * H))) return rc;
-    if ((rc = add_vectors(st, p->word_b_ih, p->word_b_hh, w.bsum2, 4 * H))) return rc;
-    {   // one zero-input vid_rnn step for the whole batch (S2VTModel.py:208-210)
+    if (!gx_vid && (rc = add_vectors(st, p->vid_b_ih, p->vid_b_hh, w.bsum1, 4 * H))) return rc;
+    if (!gx_vid && (rc = add_vectors(st, p->word_b_ih, p->word_b_hh, w.bsum2, 4 * H))) return rc;
+    if (!gx_vid) {   // one zero-input vid_rnn step for the whole batch (S2VTModel.py:208-210)
         StepFwdArgs a = {};
         a.B = B; a.H = H;
         a.h_prev = vid_h_in; a.ldh = H; a.w_hh = p->vid_w_hh; a.ldw = H;
@@ -1655,8 +1666,10 @@ static int beam_step_impl(const s2vt_dims* d, const s2vt_params* p, int32_t R, c
         XP = 3;
         S2VT_REQUIRE(cache_bytes >= carve_decode_const(*d, nullptr).bytes, "s2vt_beam_step_cached: cache too small");
         const DecodeConst kc = carve_decode_const(*d, cache);
-        if ((rc = psplit(ln, w.pvid, 0, vid_h_out, H, ID, B, H))) return rc;
-        if ((rc = pgemm(ln, B, 4 * H, H, w.pvid, 0, 0, kc.wv, 0, 0, w.gx, 4 * H, ID, w.bsum2, false))) return rc;
+        if (!gx_vid) {
+            if ((rc = psplit(ln, w.pvid, 0, vid_h_out, H, ID, B, H))) return rc;
+            if ((rc = pgemm(ln, B, 4 * H, H, w.pvid, 0, 0, kc.wv, 0, 0, w.gx, 4 * H, ID, w.bsum2, false))) return rc;
+        }
         if ((rc = fill_zero(st, w.pword.p, rows64((size_t)R) * (size_t)w.pword.ld * sizeof(unsigned short)))) return rc;
         {
             StepFwdArgs a = {};
@@ -1664,7 +1677,7 @@ static int beam_step_impl(const s2vt_dims* d, const s2vt_params* p, int32_t R, c
             a.h_prev = w.ph; a.ldh = H; a.w_hh = p->word_w_hh; a.ldw = H;
             a.gx_tab = kc.gtab; a.ldtab = 4 * (int64_t)H; a.tok_idx = tok;
             a.tok_limit = V; a.tok_err = w.err;
-            a.gx = w.gx; a.ldgx = 4 * H; a.gx_idx = row_b;
+            a.gx = gx_vid ? gx_vid : w.gx; a.ldgx = 4 * H; a.gx_idx = row_b;
             a.c_prev = w.pc; a.ldc = H;
             a.h_out = word_h_out; a.ldho = H; a.c_out = word_c_out; a.ldco = H;
             a.h_planes = w.pword.p; a.ldhp = w.pword.ld;
@@ -1675,6 +1688,7 @@ static int beam_step_impl(const s2vt_dims* d, const s2vt_params* p, int32_t R, c
         if ((rc = top20_logprob(st, w.logits, V, R, V, top_ix, top_lp))) return rc;
         return post_async_error(st, w.err);
     }
+    S2VT_REQUIRE(!gx_vid, "s2vt_beam_step_gx: the precomputed vid_rnn half needs the plane path (B % 64 == 0, H <= 1024)");
     if ((rc = lgemm(ln, true, true, R, 4 * H, H, vid_h_out, H, gather(row_b), p->word_w_ih + E, E + H, ID, w.gx, 4 * H, ID,
                     w.bsum2, false)))
         return rc;
@@ -1711,9 +1725,11 @@ size_t s2vt_decode_cache_bytes(const s2vt_dims* d) {
     return carve_decode_const(*d, nullptr).bytes;
 }
 
+struct EncodeOut { float *vid_h, *vid_c, *word_h, *word_c; float* gx_dec; int depth; };      // states [B, H] after the L encode steps;
+                                     // optional: word_rnn's vid_out gate input (+ biases) of the first `depth` decode steps [depth][B][4H]
 static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
                               void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, bool cache_valid,
-                              void* stream);
+                              void* stream, const EncodeOut* enc = nullptr);
 // schedule of the 79 token-dependent decode steps on the plane path: 1 = fused (the next step's recurrent GEMM inside the
 // argmax launch + a cell-update launch), 0 = a step kernel and an argmax kernel per step, batch halves as two chains
 static int g_decode_schedule = -1;
@@ -1736,10 +1752,22 @@ int s2vt_greedy_decode_cached(const s2vt_dims* d, const s2vt_params* p, const fl
     S2VT_REQUIRE(cache, "s2vt_greedy_decode_cached: null cache");
     return greedy_decode_impl(d, p, feats, sos_ix, ids, workspace, workspace_bytes, cache, cache_bytes, cache_valid != 0, stream);
 }
+// The ENCODE phase of the decode alone (S2VTModel.py:56-60 for mode='beam_search', the same computation as :64-86 of mode='test'):
+// feature projection, both layers over the L frames on the plane path, the weight images in the caller's cache (filled here when
+// cache_valid == 0 - every image a decode or a beam search of these weights reads).  Out: the four [B, H] states a beam search
+// starts from.  Shapes the persistent split-precision recurrence does not take return S2VT_ERR_ARG (the caller keeps its own encoder).
+int s2vt_decode_encode_cached(const s2vt_dims* d, const s2vt_params* p, const float* feats, void* workspace, size_t workspace_bytes,
+                              void* cache, size_t cache_bytes, int32_t cache_valid, float* vid_h, float* vid_c, float* word_h,
+                              float* word_c, float* gx_dec, int32_t depth, void* stream) {
+    S2VT_REQUIRE(cache && vid_h && vid_c && word_h && word_c, "s2vt_decode_encode_cached: null argument");
+    S2VT_REQUIRE(!gx_dec || (d && depth > 0 && depth <= d->L - 1), "s2vt_decode_encode_cached: depth must be in [1, L-1]");
+    const EncodeOut enc{vid_h, vid_c, word_h, word_c, gx_dec, gx_dec ? depth : 0};
+    return greedy_decode_impl(d, p, feats, 0, nullptr, workspace, workspace_bytes, cache, cache_bytes, cache_valid != 0, stream, &enc);
+}
 static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
                               void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, bool cache_valid,
-                              void* stream) {
-    S2VT_REQUIRE(dims_ok(d) && p && feats && ids && workspace, "s2vt_greedy_decode: null/invalid argument");
+                              void* stream, const EncodeOut* enc) {
+    S2VT_REQUIRE(dims_ok(d) && p && feats && (ids || enc) && workspace, "s2vt_greedy_decode: null/invalid argument");
     S2VT_REQUIRE(sos_ix >= 0 && sos_ix < d->V, "s2vt_greedy_decode: sos_ix %d outside vocabulary %d", sos_ix, d->V);
     const DecodeWS w = carve_decode(*d, workspace);
     const size_t kbytes = carve_decode_const(*d, nullptr).bytes;
@@ -1901,6 +1929,27 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
             }
             if (hv && (rc = gx2_block(be[k], be[k + 1]))) return rc;
         }
+        if (enc) {       // the encode phase was what was asked for: the states after step L - 1
+            const size_t nb_ = (size_t)BH * sizeof(float);
+            S2VT_HIP(hipMemcpyAsync(enc->vid_h, w.h1 + (int64_t)(L - 1) * BH, nb_, hipMemcpyDeviceToDevice, st));
+            S2VT_HIP(hipMemcpyAsync(enc->vid_c, w.c1_all + (int64_t)(L - 1) * BH, nb_, hipMemcpyDeviceToDevice, st));
+            S2VT_HIP(hipMemcpyAsync(enc->word_h, w.h2_all + (int64_t)(L - 1) * BH, nb_, hipMemcpyDeviceToDevice, st));
+            S2VT_HIP(hipMemcpyAsync(enc->word_c, w.c2_all + (int64_t)(L - 1) * BH, nb_, hipMemcpyDeviceToDevice, st));
+            if (enc->depth > 0) {
+                // vid_rnn's decode-phase steps take no input and see no token (S2VTModel.py:208-210 inside the depth loop): the
+                // first `depth` of them in one launch, their half of word_rnn's gate input in one GEMM
+                const int Td = L + enc->depth;
+                SeqFwdX3Args av = persist_fwd_x3_args(L, Td, B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
+                av.no_stash = 1;
+                {
+                    ProfScope ps(st, K_STEP_FWD, Td - L);
+                    if ((rc = lstm_seq_fwd_x3_persist2(st, av, nullptr))) return rc;
+                }
+                if ((rc = gx2_block(L, Td))) return rc;
+                S2VT_HIP(hipMemcpyAsync(enc->gx_dec, w.gx2 + (int64_t)L * B4H, (size_t)enc->depth * B4H * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
+            return post_async_error(st, w.err);
+        }
         {   // vid_rnn over the L - 1 decode steps (no input: bias only): one launch that may use the whole device
             SeqFwdX3Args av = persist_fwd_x3_args(L, T, B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
             av.no_stash = 1;
@@ -1960,6 +2009,7 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
         if ((rc = unpack_tokens(st, w.packed, L - 1, B, ids))) return rc;
         return post_async_error(st, w.err);                   // (a timed-out hand-off surfaces like the train path's)
     }
+    S2VT_REQUIRE(!enc, "s2vt_decode_encode_cached: this shape / mode does not take the persistent split-precision encode phase");
     const std::vector<int> bd = pipe_bounds(T, L, blk);
     for (size_t k = 0; k + 1 < bd.size(); ++k) {
         const int t0 = bd[k], t1 = bd[k + 1];

@@ -236,6 +236,41 @@ def greedy_decode(feats, params, sos_ix, owner=None):
     return ids
 
 
+@torch.no_grad()
+def decode_encode(feats, params, owner, depth=0):
+    """The encode phase of a decode on the plane path (s2vt_decode_encode_cached): (vid_h, vid_c, word_h, word_c, gx_dec), the
+    states [B, H] S2VT.beam_search starts from and - for 0 < depth <= L-1, else None - vid_rnn's half of word_rnn's gate input for
+    the first `depth` decode steps [depth, B, 4H]; fills `owner`'s weight-image cache when the weights moved.  None where the cache
+    or the persistent split-precision recurrence does not apply (the caller runs its own encoder)."""
+    lib = capi.load()
+    feats = _f32c(feats, "feats")
+    raw = params
+    params = tuple(_f32c(p.detach(), "parameter") for p in params)
+    d = _dims(feats, params)
+    dev = feats.device
+    if lib.s2vt_lstm_seq_x3_workspace_bytes(d.L, d.B, d.H) == 0 or lib.s2vt_set_recurrence_mode(-1) == 0:
+        return None
+    with torch.cuda.device(dev):
+        cache, valid = decode_cache_entry(owner, raw, d, dev, lib)
+        if cache is None:
+            return None
+        nbytes = lib.s2vt_decode_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        out = torch.empty(4, d.B, d.H, dtype=torch.float32, device=dev)
+        depth = int(depth) if 0 < int(depth) <= d.L - 1 else 0
+        gx_dec = torch.empty(depth, d.B, 4 * d.H, dtype=torch.float32, device=dev) if depth else None
+        ps = _params_struct(capi.Params, params)
+        rc = lib.s2vt_decode_encode_cached(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), _ptr(ws), nbytes, _ptr(cache), cache.numel(),
+                                           1 if valid else 0, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(gx_dec),
+                                           depth, _stream(dev))
+        if rc != 0:
+            return None                              # (a shape the library's own predicate refused: capi.last_error() says why)
+        entry = _DECODE_CACHES.get(owner)
+        if entry is not None and entry[1] is cache:
+            entry[2] = True
+    return out[0], out[1], out[2], out[3], gx_dec
+
+
 class _MeanCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target):
