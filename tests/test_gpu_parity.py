@@ -445,6 +445,61 @@ def test_beam_plane_path_fills_and_follows_the_weight_cache(lib, B):
     assert captions(ma, True) == a2                            # and the cached images serve the next call
 
 
+def test_library_encode_phase_is_the_beam_searchs_python_encoder(lib):
+    """s2vt_decode_encode_cached (the encode phase of mode='test' handed out for the beam search, plus vid_rnn's token-independent
+    decode steps): its four states and its per-depth gate inputs against the per-op encoder beam.py used before (s2vt_feat_proj_fwd,
+    s2vt_gemm_f32, the sequence kernels) and an explicit vid_rnn roll-out in torch, to fp32-rounding bounds; and the beam search
+    gives the same captions with the switches on and off (/root/reference/S2VTModel.py:56-60, 208-212)."""
+    from s2vt_video_caption_amd import beam, functional, ops
+    d = dict(synth.CONFIGS["c5"]); B = 64
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=31)
+    feats = synth.make_batch(B, d["L"], d["F"], d["V"], seed=32)[0].to(DEV)
+    m = _model(d, sd).eval()
+    with torch.no_grad():
+        caps_on = [[int(t.item()) for t in s] for s in m(feats, mode="beam_search", beam_width=5, max_beam_depth=10)]
+        assert "precomputed" in beam.LAST_PATH
+        keep = beam.PLANE_ENCODER
+        beam.PLANE_ENCODER = False
+        try:
+            caps_off = [[int(t.item()) for t in s] for s in m(feats, mode="beam_search", beam_width=5, max_beam_depth=10)]
+            assert "precomputed" not in beam.LAST_PATH
+        finally:
+            beam.PLANE_ENCODER = keep
+    assert sum(a == b for a, b in zip(caps_on, caps_off)) >= int(0.95 * B)
+    # states and gate inputs against torch fp64 on the same weights
+    p64 = {k: v.double().to(DEV) for k, v in sd.items()}
+    H, E, L = d["H"], d["E"], d["L"]
+    x1 = feats.double() @ p64["feat_linear.weight"].T + p64["feat_linear.bias"]                      # [B, L, H]
+
+    def run(x, wi, wh, bi, bh, h, c):
+        hs = []
+        for t in range(x.shape[1]):
+            g = x[:, t] @ wi.T + h @ wh.T + bi + bh
+            i, f, gg, o = g.chunk(4, dim=1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            hs.append(h)
+        return torch.stack(hs, 1), h, c
+    z = torch.zeros(B, H, dtype=torch.float64, device=DEV)
+    h1s, h1, c1 = run(x1, p64["vid_rnn.weight_ih_l0"], p64["vid_rnn.weight_hh_l0"], p64["vid_rnn.bias_ih_l0"], p64["vid_rnn.bias_hh_l0"], z, z)
+    x2 = torch.cat([torch.zeros(B, L, E, dtype=torch.float64, device=DEV), h1s], dim=2)
+    _, h2, c2 = run(x2, p64["word_rnn.weight_ih_l0"], p64["word_rnn.weight_hh_l0"], p64["word_rnn.bias_ih_l0"], p64["word_rnn.bias_hh_l0"], z, z)
+    depth = 6
+    pad = torch.zeros(B, depth, H, dtype=torch.float64, device=DEV)
+    hd, _, _ = run(pad, p64["vid_rnn.weight_ih_l0"], p64["vid_rnn.weight_hh_l0"], p64["vid_rnn.bias_ih_l0"], p64["vid_rnn.bias_hh_l0"], h1, c1)
+    gx_ref = hd @ p64["word_rnn.weight_ih_l0"][:, E:].T + p64["word_rnn.bias_ih_l0"] + p64["word_rnn.bias_hh_l0"]   # [B, depth, 4H]
+    plist = tuple(m.state_dict()[k] for k in ("vid_rnn.weight_ih_l0", "vid_rnn.weight_hh_l0", "vid_rnn.bias_ih_l0", "vid_rnn.bias_hh_l0",
+                                              "word_rnn.weight_ih_l0", "word_rnn.weight_hh_l0", "word_rnn.bias_ih_l0", "word_rnn.bias_hh_l0",
+                                              "feat_linear.weight", "feat_linear.bias", "out_linear.weight", "out_linear.bias",
+                                              "embedding.weight"))
+    out = functional.decode_encode(feats, plist, m, depth=depth)
+    assert out is not None
+    vh, vc, wh, wc, gx = out
+    for got, ref in ((vh, h1), (vc, c1), (wh, h2), (wc, c2)):
+        assert (got.double() - ref).abs().max().item() < 2e-6
+    assert (gx.double() - gx_ref.transpose(0, 1)).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize("B", [64, 128, 192])
 def test_decode_schedules_give_the_same_ids(lib, golden, B):
     """s2vt_set_decode_schedule: the fused schedule (h_t W_hh^T of step t+1 as extra row blocks of step t's argmax launch, then a
