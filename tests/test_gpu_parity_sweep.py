@@ -1,0 +1,65 @@
+"""Parity over fresh seeds (no fixture involved): per seed new weights and inputs at a mid-size shape (B=64: the split-precision two-lane
+train drivers, persistent forward, fused decode schedule, device beam queues with the plane-path depth step), compared with the CPU
+oracle (oracle/s2vt_oracle.py - the restatement of /root/reference/S2VTModel.py pinned by tests/golden) run in the same process:
+  train step : |loss - oracle| and the worst relative error of the 13 gradients (max |g - g_oracle| / max |g_oracle|)
+  greedy     : ids of every row whose weakest top-2 margin in the oracle is >= 1e-4 (rows compared / rows equal)
+  beam 5     : captions of the first 6 samples whose weakest decision gap in the oracle is >= 1e-5 (compared / equal)
+8 seeds by default; S2VT_SWEEP_SEEDS=64 python -m pytest tests/test_gpu_parity_sweep.py -s wrote profiles/round4_parity_sweep.txt."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import s2vt_oracle as orc
+from s2vt_video_caption_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_fresh_seeds_against_the_oracle():
+    import S2VTModel, utils
+    capi.load()
+    N = int(os.environ.get("S2VT_SWEEP_SEEDS", "8"))
+    B, L, F, H, E, V = 64, 20, 256, 128, 96, 600
+    dev = "cuda:0"
+    worst = {"loss": 0.0, "grad": 0.0}
+    tot = {"g_rows": 0, "g_eq": 0, "b_rows": 0, "b_eq": 0}
+    t0 = time.time()
+    for seed in range(1000, 1000 + N):
+        sd = synth.make_state_dict(V, F, H, E, seed=seed)
+        feats, caps, mask = synth.make_batch(B, L, F, V, seed=seed + 7)
+        m = S2VTModel.S2VT(V, F, L, dim_hid=H, dim_embed=E)
+        m.load_state_dict(sd)
+        m.to(dev)
+        loss = utils.MaskCriterion()(m(feats.to(dev), targets=caps[:, :-1].to(dev), mode="train"), caps.to(dev), mask.to(dev))
+        loss.backward()
+        om = orc.OracleModel(sd)
+        oloss = orc.mask_criterion(om(feats, caps[:, :-1]), caps, mask)
+        oloss.backward()
+        dl = abs(float(loss.detach()) - float(oloss.detach()))
+        dg = max(float((p.grad.cpu() - q.grad).abs().max() / q.grad.abs().max())
+                 for (_, p), (_, q) in zip(m.named_parameters(), om.as_dict().items()))
+        with torch.no_grad():
+            ids = m.eval()(feats.to(dev), mode="test").cpu()
+            out = m(feats[:6].to(dev).repeat(11, 1, 1)[:64], mode="beam_search", beam_width=5, max_beam_depth=12)
+            beams = [[int(t.item()) for t in s] for s in out][:6]
+        oids, marg = orc.greedy_decode(sd, feats, return_margins=True)
+        rows = (marg.min(dim=1).values >= 1e-4).nonzero().flatten()
+        geq = int((ids[rows] == oids[rows]).all(dim=1).sum())
+        obeam, gaps = orc.beam_search(sd, feats[:6], beam_width=5, max_depth=12, return_gap="per_sample")
+        brow = [i for i in range(6) if gaps[i] >= 1e-5]
+        beq = sum(beams[i] == obeam[i] for i in brow)
+        worst["loss"] = max(worst["loss"], dl)
+        worst["grad"] = max(worst["grad"], dg)
+        tot["g_rows"] += len(rows); tot["g_eq"] += geq; tot["b_rows"] += len(brow); tot["b_eq"] += beq
+        print("seed %d: |loss - oracle| %.2e  worst gradient error %.2e  greedy %d/%d rows  beam %d/%d samples" %
+              (seed, dl, dg, geq, len(rows), beq, len(brow)), flush=True)
+    capi.check_async_error()
+    print("%d seeds in %.0f s: worst |loss - oracle| %.2e, worst gradient error %.2e; greedy rows equal %d of %d compared; beam "
+          "captions equal %d of %d compared" % (N, time.time() - t0, worst["loss"], worst["grad"], tot["g_eq"], tot["g_rows"], tot["b_eq"],
+                                                tot["b_rows"]))
+    assert worst["loss"] < 1e-4 and worst["grad"] < 1e-4
+    assert tot["g_eq"] == tot["g_rows"] and tot["g_rows"] >= 40 * N
+    assert tot["b_eq"] == tot["b_rows"] and tot["b_rows"] >= 4 * N
