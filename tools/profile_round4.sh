@@ -2,7 +2,7 @@
 #   usage (gpurun command): S2VT_COMMIT=<sha> bash tools/profile_round4.sh [stats] [pmc] [traffic]
 # stats:   rocprofv3 --kernel-trace --stats of the bench command for config 2 / config 3 and of one greedy decode
 # pmc:     SQ / GRBM counter passes (matrix-pipe busy, wait / issue-stall shares, LDS conflicts, instruction mix) over
-#          tools/prof_path.py c2 (+ decode at B = 64), c3 and c5 --decode (B = 128): counters only, program directly after --
+#          tools/prof_path.py c2 (+ decode at B = 64), c3, c5 --decode (B = 128) and tools/prof_beam_device.py: counters only, program directly after --
 # traffic: FETCH_SIZE / WRITE_SIZE / L2 passes (tools/pmc_traffic.py)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && export OUT=${OUT:-prof_r4} && mkdir -p gpurun_out/$OUT && . tools/gpu/run_steps.sh
 WHAT="${*:-stats pmc traffic}"
@@ -16,12 +16,13 @@ case " $WHAT " in *" stats "*)
   run_step dec_stats 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/$OUT -o dec -- python3 tools/prof_path.py c5 0 --decode
 ;; esac
 case " $WHAT " in *" pmc "*)
-  for cfg in c2 c3 dec; do
+  for cfg in c2 c3 dec beam; do
     mkdir -p gpurun_out/$OUT/sq_$cfg
     case $cfg in
       c2) unset S2VT_GEMM_MODE; P="python3 tools/prof_path.py c2 2 --decode";;
       c3) export S2VT_GEMM_MODE=1; P="python3 tools/prof_path.py c3 2";;
       dec) unset S2VT_GEMM_MODE; P="python3 tools/prof_path.py c5 0 --decode";;
+      beam) unset S2VT_GEMM_MODE; P="python3 tools/prof_beam_device.py";;
     esac
     run_step sq1_$cfg 300 rocprofv3 --pmc $SQ1 --output-format csv -d gpurun_out/$OUT/sq_$cfg -o p1 -- $P
     run_step sq2_$cfg 300 rocprofv3 --pmc $SQ2 --output-format csv -d gpurun_out/$OUT/sq_$cfg -o p2 -- $P
