@@ -1032,7 +1032,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = handoff(st, sx, ev++))) return rc;
     if ((rc = pgemm(la, R, H, V, q.dlog, 0, 0, q.woT, 0, 0, w.dh2dec, H, perm(L - 1, B), nullptr, false))) return rc;
     if (out_mask && (rc = mul_vectors(st, w.dh2dec, out_mask, w.dh2dec, (int64_t)R * H))) return rc;      // autograd of out_drop
-    if ((rc = transpose_f32(st, p->word_w_hh, 4 * H, H, w.wt2))) return rc;
+    if (!bf && (rc = transpose_f32(st, p->word_w_hh, 4 * H, H, w.wt2))) return rc;       // (the bf16 BPTT reads the W_hh^T planes instead)
     // lane B meanwhile: out_linear weight/bias gradients (k = batch-major row index) and W_hh1^T
     {
         const float* h2dec = w.h2 + L * BH;
@@ -1050,7 +1050,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     }
     if ((rc = colsum_finish(sx, w.colsum_c, cdiv(R, 64), V, g->out_b, false))) return rc;
     if ((rc = grads_ready(0, sx))) return rc;
-    if ((rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
+    if (!bf && (rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     const bool pbf_bwd = bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad;
     const bool px3_any = !bf && XP == 3 && blk > 0 && w.xnslots > 0 && persist_x3_bwd_on() && lstm_seq_bwd_x3_persist_supported(B, H) &&
                          w.xnslots > (blk < T ? blk : T);

@@ -65,37 +65,40 @@ __global__ void colsum_partial_kernel(const float* x, int64_t rows, int cols, in
     for (int64_t r = r0; r < r1; ++r) s += x[r * ld + c];
     partial[(int64_t)blockIdx.y * cols + c] = s;
 }
-// 64 columns per workgroup; the chunk loop is dealt over 4 thread rows with 4 independent accumulators each (the sum
-// is a dependent chain of loads otherwise: 159 chunks took 80 us), combined in a fixed order -> deterministic.
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* partial, int nchunks, int cols, float* out,
-                                                           int accumulate) {
-    __shared__ float red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + tx;
+// 16 columns per workgroup; the chunk loop is dealt over 16 thread rows with 4 independent accumulators each (the sum is a
+// dependent chain of loads otherwise: 159 chunks took 80 us in one chain; 4 rows x 64 columns left 63 workgroups with 40
+// dependent rounds at B = 256 - 27 us per bias gradient), combined in a fixed order -> deterministic.
+constexpr int CF_COLS = 16, CF_ROWS = 16;
+__global__ __launch_bounds__(CF_COLS * CF_ROWS) void colsum_final_kernel(const float* partial, int nchunks, int cols, float* out,
+                                                                         int accumulate) {
+    __shared__ float red[CF_ROWS][CF_COLS + 1];
+    const int tx = threadIdx.x % CF_COLS, ty = threadIdx.x / CF_COLS;
+    const int c = blockIdx.x * CF_COLS + tx;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < cols) {
         const float* q = partial + c;
         int k = ty;
-        for (; k + 12 < nchunks; k += 16) {
+        for (; k + 3 * CF_ROWS < nchunks; k += 4 * CF_ROWS) {
             s0 += q[(int64_t)k * cols];
-            s1 += q[(int64_t)(k + 4) * cols];
-            s2 += q[(int64_t)(k + 8) * cols];
-            s3 += q[(int64_t)(k + 12) * cols];
+            s1 += q[(int64_t)(k + CF_ROWS) * cols];
+            s2 += q[(int64_t)(k + 2 * CF_ROWS) * cols];
+            s3 += q[(int64_t)(k + 3 * CF_ROWS) * cols];
         }
-        for (; k < nchunks; k += 4) s0 += q[(int64_t)k * cols];
+        for (; k < nchunks; k += CF_ROWS) s0 += q[(int64_t)k * cols];
     }
     red[ty][tx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (ty == 0 && c < cols) {
         float s = accumulate ? out[c] : 0.f;
-        s += red[0][tx]; s += red[1][tx]; s += red[2][tx]; s += red[3][tx];
+#pragma unroll
+        for (int r = 0; r < CF_ROWS; ++r) s += red[r][tx];
         out[c] = s;
     }
 }
 // fixed-order sum of `nchunks` partial rows (written by colsum_partial_kernel or split_dual_kernel)
 int colsum_finish(hipStream_t s, const float* partial, int nchunks, int cols, float* out, bool accumulate) {
     if (cols <= 0) return 0;
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, s, partial, nchunks, cols, out,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, CF_COLS)), dim3(CF_COLS * CF_ROWS), 0, s, partial, nchunks, cols, out,
                        accumulate ? 1 : 0);
     S2VT_LAUNCH_CHECK("colsum_final_kernel");
     return 0;
@@ -110,7 +113,7 @@ int colsum_f32(hipStream_t s, const float* x, int64_t rows, int cols, int64_t ld
                            partial);
         S2VT_LAUNCH_CHECK("colsum_partial_kernel");
     }
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, s, partial, nchunks, cols, out,
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(cols, CF_COLS)), dim3(CF_COLS * CF_ROWS), 0, s, partial, nchunks, cols, out,
                        accumulate ? 1 : 0);
     S2VT_LAUNCH_CHECK("colsum_final_kernel");
     return 0;
@@ -220,10 +223,13 @@ __global__ __launch_bounds__(EG_HT) void emb_grad_heavy_kernel(const float* d_ro
     __shared__ int list[EG_HLIST + EG_HT];
     __shared__ int wave_cnt[EG_HT / 64];
     __shared__ float part[EG_HT / 16][17];
-    if ((int)blockIdx.y >= *n_heavy) return;
-    const int v = heavy[blockIdx.y], tid = threadIdx.x;
+    // gridDim.y is a small constant, not the worst-case number of heavy tokens (rows / 64 + 2 = 318 at B = 256: 20 000 workgroups of
+    // 1024 threads that found nothing to do were most of this launch's 130 us); a workgroup takes every gridDim.y-th heavy token
+    const int nh = *n_heavy, tid = threadIdx.x;
     const int rl = tid >> 4, c = blockIdx.x * 16 + (tid & 15);
     constexpr int NRL = EG_HT / 16;
+    for (int hv = blockIdx.y; hv < nh; hv += gridDim.y) {
+    const int v = heavy[hv];
     float total = 0.f;
     int base = 0;
     while (base < rows) {
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(EG_HT) void emb_grad_heavy_kernel(const float* d_ro
         __syncthreads();
     }
     if (rl == 0 && c < E) d_emb[(int64_t)v * E + c] = total;
+    }
 }
 size_t embedding_grad_ws_ints(int64_t rows, int V) { return (size_t)(rows / EG_CAP + 2) + 1 + (size_t)V; }
 // ws: embedding_grad_ws_ints(rows, V) ints of scratch (heavy-token list, its counter, per-token counts)
@@ -277,8 +284,8 @@ int embedding_grad(hipStream_t s, const float* d_rows, int64_t rows, int E, cons
     S2VT_LAUNCH_CHECK("emb_count_kernel");
     hipLaunchKernelGGL(emb_grad_kernel, dim3((unsigned)V), dim3(256), 0, s, d_rows, (int)rows, E, tok, d_emb, ws, n_heavy, count);
     S2VT_LAUNCH_CHECK("emb_grad_kernel");
-    hipLaunchKernelGGL(emb_grad_heavy_kernel, dim3(cdiv(E, 16), max_heavy), dim3(EG_HT), 0, s, d_rows, (int)rows, E, tok, d_emb,
-                       ws, n_heavy);
+    hipLaunchKernelGGL(emb_grad_heavy_kernel, dim3(cdiv(E, 16), max_heavy < 4 ? max_heavy : 4), dim3(EG_HT), 0, s, d_rows, (int)rows, E,
+                       tok, d_emb, ws, n_heavy);
     S2VT_LAUNCH_CHECK("emb_grad_heavy_kernel");
     return 0;
 }
