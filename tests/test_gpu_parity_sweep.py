@@ -8,7 +8,6 @@ oracle (oracle/s2vt_oracle.py - the restatement of /root/reference/S2VTModel.py 
 import os
 import time
 
-import numpy as np
 import pytest
 import torch
 

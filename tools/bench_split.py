@@ -3,7 +3,6 @@ bytes = fp32 read + three bf16 planes written.  usage: python tools/bench_split.
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import ctypes
 import torch
 from s2vt_video_caption_amd import capi
 from s2vt_video_caption_amd.functional import _ptr, _stream
