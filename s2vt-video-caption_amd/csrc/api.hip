@@ -250,6 +250,7 @@ struct Carver {
 struct TrainWS {
     float *bsum1, *bsum2, *x1, *s1, *h1, *c1, *s2, *h2, *c2;
     float *wt1, *wt2, *dh1, *dh2dec, *dx1, *de, *dc1, *dc2, *colsum_a, *colsum_b, *colsum_c, *gws_a, *gws_b;
+    float* ce_alpha;         // [1] mantissa of the mean-CE scale (bf16 mode, fused criterion backward: CeGradArgs::alpha_out)
     size_t gws_floats;
     int32_t* tok;
     int* embws;              // embedding_grad scratch (heavy-token list)
@@ -319,6 +320,7 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     w.de = c.take<float>((L - 1) * B * E);
     w.dc1 = c.take<float>(B * H);
     w.dc2 = c.take<float>(B * H);
+    w.ce_alpha = c.take<float>(64);
     size_t cs = colsum_partial_floats((int64_t)T * B, (int)(4 * H));
     size_t cs2 = colsum_partial_floats((int64_t)(L - 1) * B, (int)V);
     size_t cs3 = colsum_partial_floats((int64_t)L * B, (int)H);
@@ -1031,6 +1033,10 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if (!dlog_ready && (rc = pdual(la, dlogits, V, ID, R, V, &q.dlog, 0, tt ? nullptr : &q.dlogT, 0, w.colsum_c))) return rc;
     if ((rc = handoff(st, sx, ev++))) return rc;
     if ((rc = pgemm(la, R, H, V, q.dlog, 0, 0, q.woT, 0, 0, w.dh2dec, H, perm(L - 1, B), nullptr, false))) return rc;
+    // bf16 mode with the fused criterion backward: the dlogits planes carry the power of two of gout / rows only (split.hip); the
+    // mantissa multiplies the two fp32 products of those planes - here and dW_o below (the bias gradient already has it)
+    const bool ce_pow2 = dlog_ready && bf;
+    if (ce_pow2 && (rc = scale_by_device_scalar(st, w.dh2dec, (int64_t)R * H, w.ce_alpha))) return rc;
     if (out_mask && (rc = mul_vectors(st, w.dh2dec, out_mask, w.dh2dec, (int64_t)R * H))) return rc;      // autograd of out_drop
     if (!bf && (rc = transpose_f32(st, p->word_w_hh, 4 * H, H, w.wt2))) return rc;       // (the bf16 BPTT reads the W_hh^T planes instead)
     // lane B meanwhile: out_linear weight/bias gradients (k = batch-major row index) and W_hh1^T
@@ -1047,6 +1053,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
             if ((rc = psplitT(lb, q.h2decT, 0, h2dec, H, perm(L - 1, B), R, H))) return rc;
             if ((rc = pgemm(lb, V, H, R, q.dlogT, 0, 0, q.h2decT, 0, 0, g->out_w, H, ID, nullptr, false))) return rc;
         }
+        if (ce_pow2 && (rc = scale_by_device_scalar(sx, g->out_w, (int64_t)V * H, w.ce_alpha))) return rc;
     }
     if ((rc = colsum_finish(sx, w.colsum_c, cdiv(R, 64), V, g->out_b, false))) return rc;
     if ((rc = grads_ready(0, sx))) return rc;
@@ -2096,6 +2103,7 @@ int s2vt_mean_ce_backward_fused(const s2vt_dims* d, const float* logits, const i
     const int R = (d->L - 1) * d->B, V = d->V;
     CeGradArgs ce;
     ce.lse = lse; ce.target = target; ce.gout = gout; ce.Lm1 = d->L - 1; ce.ldt = target_ld;
+    ce.alpha_out = (XP == 1) ? w.ce_alpha : nullptr;       // bf16 operands: power-of-two scale in the planes, mantissa downstream
     hipStream_t st = (hipStream_t)stream;
     int rc;
     {

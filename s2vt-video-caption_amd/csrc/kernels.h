@@ -41,11 +41,17 @@ struct CeGradArgs {
     const int64_t* target;       // [B][ldt]: row r = b*Lm1 + j reads target[b*ldt + j + 1]
     const float* gout;           // device scalar
     int Lm1; int64_t ldt;
+    // optional (bf16 operands): the scale gout / rows is applied as its POWER OF TWO only - the one-hot entries (p - 1) * scale are
+    // the same number for every row, and bf16's rounding of that constant (1 / 20224 -> x 0.99808) would scale the whole gradient;
+    // the mantissa f = scale / 2^e in [1, 2) is written here for the fp32 consumers of the planes' products to multiply by (the
+    // partial column sums of this pass already carry it)
+    float* alpha_out;
 };
 int split_planes_dual(hipStream_t s, int nplanes, const float* in, int64_t ld, RowMap imap, int rows, int cols,
                       unsigned short* out_r, int64_t ldo_r, int kpad_r, unsigned short* out_t, int64_t ldo_t, int kpad_t,
                       float* colpart, const CeGradArgs* ce = nullptr);
 int colsum_finish(hipStream_t s, const float* partial, int nchunks, int cols, float* out, bool accumulate);
+int scale_by_device_scalar(hipStream_t s, float* x, int64_t n, const float* alpha);      // x *= *alpha (misc.hip)
 
 // ---- lstm.hip
 struct StepFwdArgs {

@@ -51,6 +51,27 @@ int transpose_f32(hipStream_t s, const float* in, int rows, int cols, float* out
     return 0;
 }
 
+// x[i] *= *alpha (alpha on the device: the mantissa of the mean-CE scale, CeGradArgs::alpha_out)
+__global__ __launch_bounds__(256) void scale_by_kernel(float* x, int64_t n4, int64_t n, const float* alpha) {
+    const float a = *alpha;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) {
+        f32x4 v = reinterpret_cast<f32x4*>(x)[i];
+        v[0] *= a; v[1] *= a; v[2] *= a; v[3] *= a;
+        reinterpret_cast<f32x4*>(x)[i] = v;
+    } else if (i == n4) {
+        for (int64_t j = 4 * n4; j < n; ++j) x[j] *= a;
+    }
+}
+int scale_by_device_scalar(hipStream_t s, float* x, int64_t n, const float* alpha) {
+    if (n <= 0) return 0;
+    S2VT_REQUIRE(x && alpha && (reinterpret_cast<uintptr_t>(x) & 15) == 0, "scale_by_device_scalar: bad arguments");
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(scale_by_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, s, x, n4, n, alpha);
+    S2VT_LAUNCH_CHECK("scale_by_kernel");
+    return 0;
+}
+
 // Deterministic column sum in two passes: partial[chunk][col] over CS_ROWS-row chunks, then a fixed-
 // order sum over chunks (bias gradients must not depend on atomics' arrival order).
 constexpr int CS_ROWS = 64;   // = the row-tile of split_dual_kernel, which can produce the same partials

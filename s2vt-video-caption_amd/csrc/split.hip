@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void split_dual_kernel(const float* in, int64_
     __shared__ int row_tgt[64];            // integer divisions: per ELEMENT they cost more than the split itself)
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    float ce_scale = 0.f;
+    float ce_scale = 0.f, ce_alpha = 1.f;
     if (CE) {
         if (threadIdx.x < 64) {
             const int r = r0 + (int)threadIdx.x;
@@ -166,6 +166,12 @@ __global__ __launch_bounds__(256) void split_dual_kernel(const float* in, int64_
             row_lse[threadIdx.x] = l;
         }
         ce_scale = ce.gout[0] / (float)rows;
+        if (ce.alpha_out) {         // sign and exponent of the scale only (see CeGradArgs::alpha_out)
+            const float s2 = __uint_as_float(__float_as_uint(ce_scale) & 0xFF800000u);
+            ce_alpha = (s2 != 0.f) ? ce_scale / s2 : 0.f;
+            ce_scale = s2;
+            if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *ce.alpha_out = ce_alpha;
+        }
         __syncthreads();
     }
     // 16 bytes per lane and load (a wave covers 4 rows x 256 B): 4-byte loads cannot keep HBM busy
@@ -197,7 +203,7 @@ __global__ __launch_bounds__(256) void split_dual_kernel(const float* in, int64_
         float sum = 0.f;
 #pragma unroll 8
         for (int i = 0; i < 64; ++i) sum += tile[i][(int)threadIdx.x ^ TSW(i)];
-        colpart[(int64_t)blockIdx.y * cols + c0 + threadIdx.x] = sum;
+        colpart[(int64_t)blockIdx.y * cols + c0 + threadIdx.x] = CE ? sum * ce_alpha : sum;
     }
     for (int s = threadIdx.x; s < 64 * 8; s += 256) {
         // a: line index, bq: start of an 8-element run.  Blocked layout: a wave writes one 1-KB piece (64 lines x 16 B)
@@ -257,7 +263,7 @@ int split_planes_dual(hipStream_t s, int nplanes, const float* in, int64_t ld, R
     S2VT_REQUIRE(!out_t || (kpad_t % 64 == 0 && kpad_t >= rows && kpad_t <= 64 * cdiv(rows, 64) && ldo_t >= (int64_t)nplanes * kpad_t),
                  "split_planes_dual: bad transposed-plane geometry");
     const dim3 grid(cdiv(cols, 64), cdiv(rows, 64));
-    CeGradArgs none = {nullptr, nullptr, nullptr, 1, 0};
+    CeGradArgs none = {nullptr, nullptr, nullptr, 1, 0, nullptr};
     if (ce) {
         S2VT_REQUIRE(ce->lse && ce->target && ce->gout && ce->Lm1 > 0 && imap.idx == nullptr && imap.inner == 0,
                      "split_planes_dual: bad CE-gradient arguments");

@@ -566,8 +566,9 @@ def test_c3_full_size_bf16_against_reference_golden(lib, golden):
     operands for the batched GEMMs and the recurrence - k padded 1000 -> 1024, 4000 -> 4032 - fp32 accumulation, cell
     state and gradients), against ONE fp32 train step of the reference on the same seeded inputs (tests/golden/c3.npz).
     Stated bf16 bounds (round 4: three times what was measured): loss within 1e-3 (measured 2.7e-4: the mean over 20 224 rows
-    averages the rounding out), logits slice within 2e-2 of the largest logit (6e-3), every gradient's norm within 0.6 % (0.21 %),
-    its first 32 entries within 4 % of their largest (1.4 %), and every FULL gradient within 1.5 % (relative L2; 0.48 %) and
+    averages the rounding out), logits slice within 2e-2 of the largest logit (6e-3), every gradient's norm within 0.06 % (0.02 % since the
+    mean-CE scale's mantissa stays out of the bf16 planes: CeGradArgs::alpha_out; 0.21 % before), its first 32 entries within 2.5 % of
+    their largest (0.7 %), and every FULL gradient within 1.5 % (relative L2; 0.48 %) and
     cosine 0.9999 (1 - 1e-5) of the fp32-equivalent arithmetic's, which is itself held to the reference at fp32 bounds.  Plus the size-independent properties: finite, deterministic (bitwise), batch-independent rows, and the
     persistent recurrence schedule equal to the launch-per-timestep one within bf16 re-rounding."""
     import utils
@@ -590,11 +591,11 @@ def test_c3_full_size_bf16_against_reference_golden(lib, golden):
         for key, p in m.named_parameters():
             gn = float(g["gradnorm/" + key])
             assert torch.isfinite(p.grad).all(), key
-            assert abs(float(p.grad.double().norm()) - gn) <= 6e-3 * gn, (key, float(p.grad.double().norm()), gn)
+            assert abs(float(p.grad.double().norm()) - gn) <= 6e-4 * gn, (key, float(p.grad.double().norm()), gn)
             ref = g["gradhead/" + key]
-            assert np.abs(p.grad.reshape(-1)[:32].cpu().numpy() - ref).max() <= 4e-2 * np.abs(ref).max() + 1e-9, key
+            assert np.abs(p.grad.reshape(-1)[:32].cpu().numpy() - ref).max() <= 2.5e-2 * np.abs(ref).max() + 1e-9, key
         # DIRECTION of every full gradient (a dropped plane, a mis-scaled tile or a skipped k range of one GEMM moves a norm by
-        # less than the 0.6 % above): the same step in the fp32-equivalent arithmetic (gemm mode 3) - itself held to the
+        # less than a per cent): the same step in the fp32-equivalent arithmetic (gemm mode 3) - itself held to the
         # reference's norms and leading entries at fp32 bounds here - and the cosine between the two, per parameter
         bf_grads = {key: p.grad.detach().clone() for key, p in m.named_parameters()}
         lib.s2vt_set_gemm_mode(3)
@@ -867,8 +868,8 @@ def _dp_overlapped_body(lib, cfg, B):
 def test_fused_criterion_backward_is_bitwise_the_unfused_one(lib, cfg, gemm_mode):
     """MaskCriterion's backward fused into the model's (s2vt_mean_ce_backward_fused: the mean-CE gradient is evaluated from the
     logits inside the plane-split pass of the train workspace, no fp32 dlogits tensor; utils.py:22 under train.py:124) against the
-    two-kernel route (functional.FUSE_CE = False): loss and all 13 gradients of two Adam steps bit for bit, in the split-precision
-    and in the bf16 configuration.  And the guard: a second consumer of the logits is refused, not silently dropped."""
+    two-kernel route (functional.FUSE_CE = False): loss and all 13 gradients of two Adam steps bit for bit in the split-precision
+    configuration; in the bf16 configuration equal up to the one systematic difference described below.  And the guard: a second consumer of the logits is refused, not silently dropped."""
     import utils
     from s2vt_video_caption_amd import capi, functional
     d = synth.CONFIGS[cfg]
@@ -894,9 +895,24 @@ def test_fused_criterion_backward_is_bitwise_the_unfused_one(lib, cfg, gemm_mode
             return out
         ref, got = run(False), run(True)
         for (l0, g0), (l1, g1) in zip(ref, got):
-            assert l0 == l1
-            for n in g0:
-                assert torch.equal(g0[n], g1[n]), n
+            if gemm_mode != 1:
+                assert l0 == l1
+                for n in g0:
+                    assert torch.equal(g0[n], g1[n]), n
+            else:
+                # bf16 operands: the fused route keeps the mantissa of gout / rows OUT of the bf16 planes (power-of-two scale in
+                # dlogits, the mantissa as an fp32 factor on dh2 / dW_o: CeGradArgs::alpha_out), the two-kernel route rounds
+                # (p - y) * gout / rows as a whole - for the one-hot entries that is one constant whose bf16 rounding scales the whole
+                # gradient (up to 2^-9).  Same gradients up to that scale and bf16 rounding noise; out_linear.bias (fp32 sums) exact.
+                assert abs(l0 - l1) <= 2e-3 * abs(l0)
+                for n in g0:
+                    a, b = g0[n].double().reshape(-1), g1[n].double().reshape(-1)
+                    if n == "out_linear.bias":
+                        assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()), n
+                        continue
+                    cos = float((a @ b) / (a.norm() * b.norm()))
+                    assert cos >= 0.9999, (n, cos)
+                    assert abs(float(b.norm() / a.norm()) - 1.0) <= 5e-3, (n, float(b.norm() / a.norm()))
         functional.FUSE_CE = True
         m = _model(d, sd)
         logits = m(feats, targets=caps[:, :-1], mode="train")
