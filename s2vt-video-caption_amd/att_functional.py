@@ -1,5 +1,6 @@
 """Autograd glue for the reference's second network, `Att_Baseline` (attention_baseline.py:9-105), over the per-op C-ABI entry
-points of libs2vt_hip.so: every GEMM is s2vt_gemm_f32, every recurrence s2vt_lstm_seq_fwd / s2vt_lstm_seq_bwd (the fused
+points of libs2vt_hip.so: the projections and their gradients are the split-precision plane GEMMs of the S2VT path (s2vt_split_planes +
+s2vt_gemm_bf16_nt / _tt; s2vt_gemm_f32 outside gemm mode 3), every recurrence s2vt_lstm_seq_fwd / s2vt_lstm_seq_bwd (the fused
 timestep kernels of the S2VT path), the greedy loop s2vt_lstm_step_fwd + s2vt_decode_step_argmax.  PyTorch only holds the
 tensors and wires the autograd graph (the callers / model variants either side of the hot path).
 
@@ -14,23 +15,61 @@ import torch
 from . import capi, ops
 
 
+PLANE_GEMMS = True       # A/B switch: the projections on the split-precision plane path (fp32-equivalent, bf16 matrix cores)
+
+
+def _plane_mode():
+    """The library's batched-GEMM arithmetic is split precision (s2vt_set_gemm_mode 3: three bf16 planes per operand, six plane
+    products, fp32-equivalent); modes 0 (exact-fp32 MFMA) and 1 (bf16 operands) keep s2vt_gemm_f32 here."""
+    return PLANE_GEMMS and capi.load().s2vt_set_gemm_mode(-1) == 3
+
+
+def _dw_planes(dy, x_planes, N, K):
+    """dW [N, K] = dy^T x from the ROW plane images of dy [M, N] and x [M, K] (transposed fragment reads: no transposed copy);
+    M is padded to the images' 64-row blocks, whose padding rows are zero."""
+    pdy = ops.split_planes(dy)
+    mpad = pdy[0].shape[0]
+    return ops.gemm_planes_tt(pdy, x_planes, N, K, mpad), pdy
+
+
 class _Affine(torch.autograd.Function):
-    """y = x W^T (+ b) with x [M, K], W [N, K]: forward and both gradients on s2vt_gemm_f32 (exact-fp32 MFMA GEMM)."""
+    """y = x W^T (+ b) with x [M, K], W [N, K]: forward and both gradients on the split-precision plane GEMMs of the S2VT path
+    (gemm_x3.hip: fp32-equivalent) when the library is in that mode, else on s2vt_gemm_f32 (exact-fp32 MFMA GEMM)."""
 
     @staticmethod
     def forward(ctx, x, w, b):
         x, w = x.contiguous(), w.contiguous()
-        ctx.save_for_backward(x, w)
         ctx.has_bias = b is not None
+        ctx.planes = _plane_mode()
+        if ctx.planes:
+            px = ops.split_planes(x)
+            y = ops.gemm_planes(px, ops.split_planes(w), x.shape[0], w.shape[0], bias=b.contiguous() if b is not None else None)
+            ctx.save_for_backward(w, px[0])
+            ctx.px_meta, ctx.xshape = px[1:], tuple(x.shape)
+            return y
+        ctx.save_for_backward(x, w)
         return ops.gemm(x, w, bias=b.contiguous() if b is not None else None)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
         dy = dy.contiguous()
+        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        if ctx.planes:
+            w, px0 = ctx.saved_tensors
+            (M, K), N = ctx.xshape, w.shape[0]
+            px = (px0,) + tuple(ctx.px_meta)
+            pdy = None
+            dw = None
+            if ctx.needs_input_grad[1]:
+                dw, pdy = _dw_planes(dy, px, N, K)
+            dx = None
+            if ctx.needs_input_grad[0]:
+                pdy = pdy if pdy is not None else ops.split_planes(dy)
+                dx = ops.gemm_planes(pdy, ops.split_planes(w, transpose=True), M, K)            # [M,N]·[N,K]
+            return dx, dw, db
+        x, w = ctx.saved_tensors
         dx = ops.gemm(dy, w, b_kmajor=False) if ctx.needs_input_grad[0] else None            # [M,N]·[N,K]
         dw = ops.gemm(dy, x, a_kmajor=False, b_kmajor=False) if ctx.needs_input_grad[1] else None   # [N,M]·[M,K]
-        db = dy.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
 
