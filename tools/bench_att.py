@@ -1,5 +1,5 @@
 """Train step and greedy decode of the drop-in attention_baseline.Att_Baseline at the reference's default
-widths on synthetic data: the per-op C-ABI composition (fp32-MFMA GEMMs, launch-per-timestep recurrences), not a tuned path.
+widths on synthetic data: the per-op C-ABI composition (split-precision plane GEMMs, launch-per-timestep recurrences).
 usage: python tools/bench_att.py [B]   (GPU box)"""
 import os
 import sys
