@@ -1917,11 +1917,17 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
         };
         const std::vector<int> be = pipe_bounds(L, L, balanced_block(L, blk));     // blocks over the L encode steps
         const int nb = (int)be.size() - 1;
+        // vid_rnn's blocks: the encode blocks and ONE block of its decode-phase steps (no input, no token) - the partner of word_rnn's
+        // last encode block, which used to run alone on half of the device
+        const int Tend = enc ? L + enc->depth : T;
+        std::vector<int> bv(be);
+        if (Tend > L) bv.push_back(L + (be[nb] - be[nb - 1]) < Tend ? L + (be[nb] - be[nb - 1]) : Tend);
+        const int nbv = (int)bv.size() - 1;
         for (int k = 0; k <= nb; ++k) {          // stage k: vid_rnn block k next to word_rnn block k-1 (as in s2vt_train_forward)
-            const bool hv = k < nb, hw = k >= 1;
+            const bool hv = k < nbv, hw = k >= 1;
             SeqFwdX3Args av, aw;
             if (hv) {
-                av = persist_fwd_x3_args(be[k], be[k + 1], B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
+                av = persist_fwd_x3_args(bv[k], bv[k + 1], B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
                 av.no_stash = 1;
             }
             if (hw) {
@@ -1929,13 +1935,14 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
                 aw.no_stash = 1;
             }
             {
-                ProfScope ps(st, K_STEP_FWD, (hv ? be[k + 1] - be[k] : 0) + (hw ? be[k] - be[k - 1] : 0));
+                ProfScope ps(st, K_STEP_FWD, (hv ? bv[k + 1] - bv[k] : 0) + (hw ? be[k] - be[k - 1] : 0));
                 if (hv && hw) rc = lstm_seq_fwd_x3_persist2(st, av, &aw);
                 else rc = lstm_seq_fwd_x3_persist2(st, hv ? av : aw, nullptr);
                 if (rc) return rc;
             }
-            if (hv && (rc = gx2_block(be[k], be[k + 1]))) return rc;
+            if (hv && (rc = gx2_block(bv[k], bv[k + 1]))) return rc;
         }
+        const int tv = bv.back();                // vid_rnn steps done so far (>= L)
         if (enc) {       // the encode phase was what was asked for: the states after step L - 1
             const size_t nb_ = (size_t)BH * sizeof(float);
             S2VT_HIP(hipMemcpyAsync(enc->vid_h, w.h1 + (int64_t)(L - 1) * BH, nb_, hipMemcpyDeviceToDevice, st));
@@ -1946,24 +1953,28 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
                 // vid_rnn's decode-phase steps take no input and see no token (S2VTModel.py:208-210 inside the depth loop): the
                 // first `depth` of them in one launch, their half of word_rnn's gate input in one GEMM
                 const int Td = L + enc->depth;
-                SeqFwdX3Args av = persist_fwd_x3_args(L, Td, B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
-                av.no_stash = 1;
-                {
-                    ProfScope ps(st, K_STEP_FWD, Td - L);
-                    if ((rc = lstm_seq_fwd_x3_persist2(st, av, nullptr))) return rc;
+                if (tv < Td) {
+                    SeqFwdX3Args av = persist_fwd_x3_args(tv, Td, B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
+                    av.no_stash = 1;
+                    {
+                        ProfScope ps(st, K_STEP_FWD, Td - tv);
+                        if ((rc = lstm_seq_fwd_x3_persist2(st, av, nullptr))) return rc;
+                    }
+                    if ((rc = gx2_block(tv, Td))) return rc;
                 }
-                if ((rc = gx2_block(L, Td))) return rc;
                 S2VT_HIP(hipMemcpyAsync(enc->gx_dec, w.gx2 + (int64_t)L * B4H, (size_t)enc->depth * B4H * sizeof(float), hipMemcpyDeviceToDevice, st));
             }
             return post_async_error(st, w.err);
         }
-        {   // vid_rnn over the L - 1 decode steps (no input: bias only): one launch that may use the whole device
-            SeqFwdX3Args av = persist_fwd_x3_args(L, T, B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
+        if (tv < T) {   // the rest of vid_rnn's decode steps (no input: bias only): one launch that may use the whole device
+            SeqFwdX3Args av = persist_fwd_x3_args(tv, T, B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
             av.no_stash = 1;
-            ProfScope ps(st, K_STEP_FWD, T - L);
-            if ((rc = lstm_seq_fwd_x3_persist2(st, av, nullptr))) return rc;
+            {
+                ProfScope ps(st, K_STEP_FWD, T - tv);
+                if ((rc = lstm_seq_fwd_x3_persist2(st, av, nullptr))) return rc;
+            }
+            if ((rc = gx2_block(tv, T))) return rc;
         }
-        if ((rc = gx2_block(L, T))) return rc;
         // The 79 token-dependent steps.  A decode step is two dependent launches (word_rnn step, out_linear + argmax) that
         // each leave part of the chip idle (188 of 256 compute units in the argmax; launch gaps and tails between the two) and
         // batch rows never interact: at B % 128 == 0 the two halves of the batch run as two INDEPENDENT chains on the two
