@@ -425,6 +425,12 @@ static int gemm_x3_impl(hipStream_t stream, bool tt, int M, int N, int K, const 
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
         (void)hipGetLastError();
+        // S2VT_CU_RESERVE=n: plan the persistent grids for n compute units fewer.  A launch is sized to ONE workgroup per compute unit
+        // with a static share of the tiles each; a long-lived foreign kernel on some of the units (a communication kernel of a
+        // data-parallel run) makes the workgroups that find no unit wait for a whole share.  Default 0.
+        const char* e = getenv("S2VT_CU_RESERVE");
+        const int reserve = e ? atoi(e) : 0;
+        if (reserve > 0 && reserve < n - 8) n -= reserve;
         ncu = n / 8 * 8;
     }
     // S2VT_X3_MI=2..4 / S2VT_X3_NSPLIT=n or s2vt_gemm_tune(3, ...): overrides of the time model
