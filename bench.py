@@ -251,9 +251,12 @@ def main():
         mine_comm = reducer.read_timing()
         gathered = [None] * world
         dist.all_gather_object(gathered, mine_comm)
-        comm = dict(gathered[0])
-        comm["exposed_after_backward_ms_by_rank"] = [g["exposed_after_backward_ms"] for g in gathered]
-        comm["group_ms_by_rank"] = [g["group_ms"] for g in gathered]
+        # (a rank that took the bucketed path reports {"path", "host_ms", ...}, one whose all_reduce returned early reports None:
+        # the record is emitted as it stands, with its path label - nothing here may take the line down after the timed region)
+        comm = dict(gathered[0]) if isinstance(gathered[0], dict) else {"path": "no timing record on rank 0"}
+        comm["exposed_after_backward_ms_by_rank"] = [g.get("exposed_after_backward_ms") if isinstance(g, dict) else None for g in gathered]
+        comm["group_ms_by_rank"] = [g.get("group_ms") if isinstance(g, dict) else None for g in gathered]
+        comm["path_by_rank"] = [g.get("path") if isinstance(g, dict) else None for g in gathered]
         comm["note"] = ("events on the communication stream, mean of 3 steps after the timed region; group 0 out_linear, 1 word_rnn + "
                         "embedding, 2 vid_rnn + feat_linear; a group's start < 0 = issued while the backward was still running")
     # Host-side cost of ENQUEUING one step: the phases of a step timed separately with the queues drained before each (a
@@ -386,14 +389,12 @@ def main():
 
         plan = capi.recurrence_plan(B, H)          # (forward, BPTT) recurrence kernels of the timed configuration (s2vt_hip.h)
         persist_bf16 = plan[0] == 1
-        FWD_KERNELS = {0: "lstm_step_fwd_kernel", 1: "lstm_seq_fwd_bf16_persist_kernel", 2: "lstm_seq_fwd_f32_persist_kernel",
-                       3: "lstm_seq_fwd_x3_persist_kernel"}
-        BWD_KERNELS = {0: "lstm_step_bwd_kernel", 1: "lstm_seq_bwd_bf16_persist_kernel", 2: "lstm_seq_bwd_f32_persist_kernel",
-                       3: "lstm_seq_bwd_x3_persist_kernel"}
+        FWD_KERNELS = {0: "lstm_step_fwd_kernel", 1: "lstm_seq_fwd_bf16_persist_kernel", 3: "lstm_seq_fwd_x3_persist_kernel"}
+        BWD_KERNELS = {0: "lstm_step_bwd_kernel", 1: "lstm_seq_bwd_bf16_persist_kernel", 3: "lstm_seq_bwd_x3_persist_kernel"}
 
         def rooflines(pr, how, persist, B_=B, esz_=esz, bf_=bf, x3_=x3, pmc_=None, pmc_src_=None, busy_=None):
             # persist: (forward kind, BPTT kind) as s2vt_recurrence_plan reports them, or False for launches per timestep
-            pf, pb = persist if isinstance(persist, tuple) else ((1, 1) if (persist and bf_) else (2, 2) if persist else (0, 0))
+            pf, pb = persist if isinstance(persist, tuple) else ((1, 1) if (persist and bf_) else (0, 0))
             pmc_ = pmc if pmc_ is None else pmc_
             pmc_src_ = pmc_src if pmc_src_ is None else pmc_src_
 
@@ -664,7 +665,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf else "f32",
             "data": "synthetic",
             "arithmetic": ("fp32 storage and accumulation; batched GEMM products as 3 bf16 planes x 6 plane products on the bf16 "
-                           "matrix cores (fp32-equivalent, ~2^-23 relative), recurrent GEMMs on the fp32-input MFMA"
+                           "matrix cores (fp32-equivalent, ~2^-23 relative) - the batched GEMMs and every persistent recurrence kernel "
+                           "of s2vt_recurrence_plan (kind 3); launch-per-timestep recurrences (kind 0) on the exact fp32-input MFMA"
                            if x3 else ("bf16 operands (weights, activations) on the bf16 matrix cores for batched and recurrent "
                                        "GEMMs; fp32 accumulation, cell state, gate stash, gradients, master weights and Adam"
                                        if bf else "fp32 storage, fp32-input MFMA, fp32 accumulation")),
@@ -686,6 +688,8 @@ def main():
             "kernel_busy_ms_per_step": {"gemm": round(live["gemm"][2], 3), "step_fwd": round(live["step_fwd"][2], 3),
                                         "step_bwd": round(live["step_bwd"][2], 3), "ce": round(live["ce"][2], 3)},
             "kernel_ms_per_step_isolated": {k: round(v, 3) for k, v in fam_alone.items()} if fam_alone else None,
+            "recurrence_plan": {"forward": plan[0], "bptt": plan[1], "kinds": "0 launch per timestep, 1 persistent bf16, 3 persistent split precision"},
+            "options": {lib.s2vt_option_name(i).decode(): int(lib.s2vt_set_option(lib.s2vt_option_name(i), -1)) for i in range(lib.s2vt_option_count())},
             "decode": decode,
             "beam": beam,
             "cpu_baseline": cpu,

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define S2VT_ABI_VERSION 8
+#define S2VT_ABI_VERSION 9
 
 /* negative return codes (positive ones are hipError_t values) */
 #define S2VT_ERR_ARG (-1)      /* bad argument */
@@ -183,6 +183,15 @@ int s2vt_mean_ce_forward(int32_t B, int32_t Lm1, int32_t V, const float* logits,
 int s2vt_mean_ce_backward(int32_t B, int32_t Lm1, int32_t V, const float* logits, const int64_t* target,
                           int64_t target_ld, const float* lse, const float* gout, float* dlogits, void* stream);
 
+/* MaskCriterion.forward as a whole (utils.py:13-26; called at train.py:122,143): the mean CE above, then
+ * `loss = sum(mean_ce * w) / sum(w)` with w = mask[:, 1:] (mask fp32 [B, L], row stride mask_ld), product by product as the
+ * reference evaluates it (NaN for an all-zero mask).  out3 = {loss, mean_ce, sum(w)} (three device floats). */
+int s2vt_mask_criterion_forward(int32_t B, int32_t Lm1, int32_t V, const float* logits, const int64_t* target, int64_t target_ld,
+                                const float* mask, int64_t mask_ld, float* lse, float* rowloss, float* out3, void* stream);
+/* autograd of those lines: g_ce[0] = sum_i (gout[0] / out3[2]) * w_i, the `gout` of s2vt_mean_ce_backward / _fused. */
+int s2vt_mask_criterion_backward(int32_t B, int32_t Lm1, const float* mask, int64_t mask_ld, const float* out3, const float* gout,
+                                 float* g_ce, void* stream);
+
 /* The same gradient handed to s2vt_train_backward WITHOUT an fp32 dlogits tensor (utils.py:22 under loss.backward(), train.py:124):
  * evaluates (softmax(logits) - onehot(target)) * gout[0] / (B*(L-1)) inside the plane-split pass of the TRAIN workspace the
  * logits came from - the operand planes and bias-gradient partial sums the backward's first kernel would otherwise produce from
@@ -306,33 +315,24 @@ int s2vt_lstm_seq_bwd_bf16_pair(int32_t T, int32_t B, int32_t H, const float* w_
                                 const float* dh_out1, int32_t dh_first, const float* c_all0, const float* c_all1,
                                 float* stash_dg0, float* stash_dg1, void* workspace, size_t workspace_bytes, int32_t block,
                                 void* stream);
-/* Recurrence schedule inside the whole-path train drivers: 0 = one launch per timestep; 1 (default) = persistent
- * kernels where the shape allows for the bf16 configuration (gemm mode 1: forward and BPTT) and for the FORWARD of the
- * fp32-equivalent configuration (gemm mode 3: the split-precision kernel of lstm_persist_x3.hip; its BPTT stays one launch per
- * timestep; env S2VT_PERSIST_X3_FWD=0 turns that forward off); 2 = the exact-fp32 persistent kernels as well (BPTT of gemm
- * mode 3; measured slower end to end at B = 64, see lstm_persist_f32.hip).  Negative: query.  Returns the previous mode. */
+/* Recurrence schedule inside the whole-path train drivers (option "persist"): 0 = one launch per timestep everywhere (a card
+ * shared with another process); 1 (default) = persistent kernels where the shape allows: forward and BPTT of the bf16
+ * configuration (gemm mode 1, lstm_persist.hip), forward of the fp32-equivalent configuration (gemm mode 3, the split-precision
+ * kernel of lstm_persist_x3.hip; option "persist_x3_fwd") and, with option "persist_x3_bwd", its BPTT.  Negative: query.
+ * Returns the previous mode. */
 int s2vt_set_recurrence_mode(int32_t mode);
 /* Which recurrence kernels s2vt_train_forward / s2vt_train_backward would run for (B, H) in the current modes:
- * *fwd, *bwd = 0 one launch per timestep, 1 persistent bf16, 2 persistent exact-fp32 MFMA, 3 persistent split precision. */
+ * *fwd, *bwd = 0 one launch per timestep, 1 persistent bf16, 3 persistent split precision. */
 int s2vt_recurrence_plan(int32_t B, int32_t H, int32_t* fwd, int32_t* bwd);
 
-/* fp32 persistent recurrence (lstm_persist_f32.hip): the same computation as s2vt_lstm_seq_fwd / s2vt_lstm_seq_bwd (exact
- * fp32 products on the matrix cores) with ONE launch per `block` timesteps (0 = all T) and each compute unit's slice of
- * W_hh / W_hh^T resident in registers.  Layer 1 pointers may all be null (one layer); otherwise both layers share every
- * launch.  gx_stash: gate input in, activated gates out (in place); stash_dg: activated gates in, dG out (in place).
- * workspace (s2vt_lstm_persist_workspace_bytes): word 0 (int32) is set to 1 if a hand-off wait timed out. */
-size_t s2vt_lstm_persist_workspace_bytes(void);
-int s2vt_lstm_seq_fwd_persist(int32_t T, int32_t B, int32_t H, float* gx_stash0, float* gx_stash1, int32_t n_gx,
-                              const float* bias0, const float* bias1, const float* w_hh0, const float* w_hh1, float* h_all0,
-                              float* h_all1, float* c_all0, float* c_all1, int32_t block, void* workspace,
-                              size_t workspace_bytes, void* stream);
-/* The same forward in split precision (lstm_persist_x3.hip): both operands of h_{t-1} . W_hh^T as three bf16 planes, six plane
- * products on the bf16 matrix cores, fp32 accumulate - fp32-equivalent like gemm mode 3, at 6/16 of the exact-fp32 MFMA's
- * cycles; one workgroup per compute unit keeps its W_hh planes in 384 registers per lane.  H <= 1024, B % 32 == 0.  Same
- * arguments as s2vt_lstm_seq_fwd_persist; workspace from s2vt_lstm_seq_x3_workspace_bytes (0 = shape not supported on this
- * device; word 0 of the workspace: hand-off time-out flag).
- * Whole-path use: env S2VT_PERSIST_X3_FWD=1 routes the forward recurrences of s2vt_train_forward (gemm mode 3) through it
- * (S2VTModel.py:67,77). */
+/* Persistent forward recurrence in split precision (lstm_persist_x3.hip): the same computation as s2vt_lstm_seq_fwd with ONE launch
+ * per `block` timesteps (0 = all T) and each compute unit's slice of W_hh resident in registers: both operands of
+ * h_{t-1} . W_hh^T as three bf16 planes, six plane products on the bf16 matrix cores, fp32 accumulate - fp32-equivalent like gemm
+ * mode 3; one workgroup per compute unit keeps its W_hh planes in 384 registers per lane.  H <= 1024, B % 32 == 0.  Layer 1
+ * pointers may all be null (one layer); otherwise both layers share every launch.  gx_stash: gate input in, activated gates
+ * out (in place).  workspace from s2vt_lstm_seq_x3_workspace_bytes (0 = shape not supported on this device; word 0 of the
+ * workspace: hand-off time-out flag).  Whole-path use: the forward recurrences of s2vt_train_forward in gemm mode 3
+ * (S2VTModel.py:67,77; option "persist_x3_fwd"). */
 size_t s2vt_lstm_seq_x3_workspace_bytes(int32_t T, int32_t B, int32_t H);
 int s2vt_lstm_seq_fwd_x3_persist(int32_t T, int32_t B, int32_t H, float* gx_stash0, float* gx_stash1, int32_t n_gx,
                               const float* bias0, const float* bias1, const float* w_hh0, const float* w_hh1, float* h_all0,
@@ -343,18 +343,12 @@ int s2vt_lstm_seq_fwd_x3_persist(int32_t T, int32_t B, int32_t H, float* gx_stas
  * of W_hh (planes resident in registers) for all H outputs, scatters the fp32 partial sums per consumer and gathers the ones
  * addressed to it (fixed summation order).  Same arithmetic contract as s2vt_lstm_seq_bwd (fp32-equivalent); stash_dg: activated
  * gates in, dG out (in place).  Layer 1 pointers may all be null.  block: timesteps per launch (0 = all T).
- * Whole-path use: env S2VT_PERSIST_X3_BWD=1 routes the BPTT of s2vt_train_backward (gemm mode 3) through it (one stream, both
- * layers per launch); =2 runs each layer's blocks as their own persistent launches on the two lanes of the default schedule
- * (an experiment: same step time). */
+ * Whole-path use: option "persist_x3_bwd" routes the BPTT of s2vt_train_backward (gemm mode 3) through it (one stream, both
+ * layers per launch). */
 size_t s2vt_lstm_seq_bwd_x3_workspace_bytes(int32_t T, int32_t B, int32_t H, int32_t block);
 int s2vt_lstm_seq_bwd_x3_persist(int32_t T, int32_t B, int32_t H, const float* w_hh0, const float* w_hh1, const float* dh_out0,
                                  const float* dh_out1, int32_t dh_first, const float* c_all0, const float* c_all1, float* stash_dg0,
                                  float* stash_dg1, int32_t block, void* workspace, size_t workspace_bytes, void* stream);
-int s2vt_lstm_seq_bwd_persist(int32_t T, int32_t B, int32_t H, const float* w_hh0, const float* w_hh1, const float* dh_out0,
-                              const float* dh_out1, int32_t dh_first, const float* c_all0, const float* c_all1, float* stash_dg0,
-                              float* stash_dg1, float* w_hh_t0, float* w_hh_t1, float* dc0, float* dc1, int32_t block,
-                              void* workspace, size_t workspace_bytes, void* stream);
-
 /* One greedy decode step's out_linear + argmax (S2VTModel.py:95-96,105-106): packed[b] (zeroed by the caller)
  * receives max over v of (ordered(logit) << 32 | (0xFFFFFFFF - v)); token = 0xFFFFFFFF - low 32 bits. */
 int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, const float* w_out, const float* b_out,
@@ -366,6 +360,25 @@ int s2vt_decode_step_argmax(int32_t B, int32_t H, int32_t V, const float* h, con
 size_t s2vt_decode_step_argmax_x3_workspace_bytes(int32_t B, int32_t H, int32_t V);
 int s2vt_decode_step_argmax_x3(int32_t B, int32_t H, int32_t V, const float* h, const float* w_out, const float* b_out,
                                unsigned long long* packed, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------- run-time options
+ * ONE table holds every switch of the library (csrc/options.hip).  The first read of an option takes S2VT_<NAME> (upper case)
+ * from the environment when it is set; s2vt_set_option changes it afterwards and returns the previous value (a negative value
+ * only queries; INT32_MIN: unknown name).  The typed setters below are views of the same table.
+ *   gemm_mode       3 | 1 | 0   arithmetic of the batched GEMMs (s2vt_set_gemm_mode)
+ *   persist         1 | 0       persistent recurrence kernels (s2vt_set_recurrence_mode)
+ *   persist_x3_fwd  1 | 0       split-precision persistent forward of gemm mode 3
+ *   persist_x3_bwd  0 | 1       split-precision persistent BPTT of gemm mode 3 (both layers per launch, one stream)
+ *   pipe_block      32          timesteps per pipeline block (s2vt_set_pipeline_block)
+ *   graph           0 | 1       hipGraph replay of the train launch sequences (s2vt_set_graph_mode)
+ *   decode_fused    1 | 0       schedule of the greedy decode's token steps (s2vt_set_decode_schedule)
+ *   cu_reserve      0..128      the persistent GEMMs plan their grids for this many compute units fewer (data-parallel runs
+ *                               whose communication kernels hold compute units beside the backward's GEMMs)
+ *   bptt_units      0 | 16 | 32 hidden units per workgroup of the persistent bf16 BPTT (0: 32 where two layers fit the device)
+ * Do not change gemm_mode / persist / pipe_block between a forward and its backward (the backward refuses). */
+int32_t s2vt_set_option(const char* name, int32_t value);
+int32_t s2vt_option_count(void);
+const char* s2vt_option_name(int32_t index);
 
 /* Arithmetic of the batched GEMMs inside the whole-path train drivers: 0 = fp32-input MFMA (exact fp32 products),
  * 3 = split precision (3 bf16 planes per operand, six plane products on the bf16 matrix cores: fp32-equivalent to

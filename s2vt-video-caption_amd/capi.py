@@ -34,7 +34,7 @@ class Grads(ctypes.Structure):
 
 
 # name -> (restype, argtypes): every symbol include/s2vt_hip.h declares
-ABI_VERSION = 8          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
+ABI_VERSION = 9          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding was written against
 
 SIGNATURES = {
     "s2vt_abi_version": (c_int32, []),
@@ -64,6 +64,9 @@ SIGNATURES = {
                                        c_void_p, c_void_p]),
     "s2vt_mean_ce_backward": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
+    "s2vt_mask_criterion_forward": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p,
+                                              c_void_p, c_void_p, c_void_p]),
+    "s2vt_mask_criterion_backward": (c_int32, [c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "s2vt_gemm_f32": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64,
                                 c_void_p, c_int64, c_void_p, c_int32, c_void_p]),
     "s2vt_gemm_f32_splitk": (c_int32, [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_int64,
@@ -98,17 +101,12 @@ SIGNATURES = {
                                          c_size_t, c_int32, c_int32, c_void_p]),
     "s2vt_lstm_seq_bwd_bf16_pair": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
-    "s2vt_lstm_persist_workspace_bytes": (c_size_t, []),
-    "s2vt_lstm_seq_fwd_persist": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 8 +
-                                  [c_int32, c_void_p, c_size_t, c_void_p]),
     "s2vt_lstm_seq_x3_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32]),
     "s2vt_lstm_seq_fwd_x3_persist": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int32] + [c_void_p] * 8 +
                                   [c_int32, c_void_p, c_size_t, c_void_p]),
     "s2vt_lstm_seq_bwd_x3_workspace_bytes": (c_size_t, [c_int32, c_int32, c_int32, c_int32]),
     "s2vt_lstm_seq_bwd_x3_persist": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32] +
                                      [c_void_p] * 4 + [c_int32, c_void_p, c_size_t, c_void_p]),
-    "s2vt_lstm_seq_bwd_persist": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int32] +
-                                  [c_void_p] * 8 + [c_int32, c_void_p, c_size_t, c_void_p]),
     "s2vt_set_recurrence_mode": (c_int32, [c_int32]),
     "s2vt_recurrence_plan": (c_int32, [c_int32, c_int32, POINTER(c_int32), POINTER(c_int32)]),
     "s2vt_decode_step_argmax": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5),
@@ -116,6 +114,9 @@ SIGNATURES = {
     "s2vt_decode_step_argmax_x3": (c_int32, [c_int32, c_int32, c_int32] + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "s2vt_mean_ce_backward_fused": (c_int32, [POINTER(Dims), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t,
                                               c_void_p]),
+    "s2vt_set_option": (c_int32, [c_char_p, c_int32]),
+    "s2vt_option_count": (c_int32, []),
+    "s2vt_option_name": (c_char_p, [c_int32]),
     "s2vt_set_gemm_mode": (c_int32, [c_int32]),
     "s2vt_set_pipeline_block": (c_int32, [c_int32]),
     "s2vt_set_decode_schedule": (c_int32, [c_int32]),

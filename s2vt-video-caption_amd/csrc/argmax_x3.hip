@@ -289,10 +289,7 @@ int logits_argmax_x3(hipStream_t stream, const ArgmaxX3Args& a) {
                  "logits_argmax_x3: the second image must be a blocked 3-plane image of the same K, z 16-byte aligned rows");
     S2VT_REQUIRE(a.v_off == 0 || (a.v_off == cdiv(a.V, 64) && a.M2 > 0), "logits_argmax_x3: v_off is 0 or every vocabulary block");
     const int vblocks = cdiv(a.V, 64) - a.v_off + cdiv(a.M2, 64);
-    static int dbg = -1;
-    if (dbg < 0) { const char* e = getenv("S2VT_AX_DBG"); dbg = e ? atoi(e) : 0; }
     ArgmaxX3Args b = a;
-    b.dbg = dbg;
     if (a.B > 64) {
         hipLaunchKernelGGL(logits_argmax_x3_kernel<2>, dim3(vblocks, cdiv(a.B, 128)), dim3(256), 0, stream, b);
     } else {

@@ -291,10 +291,19 @@ int s2vt_beam_queue_step(int32_t B, int32_t beam_width, int32_t max_depth, int32
     hipStream_t st = (hipStream_t)stream;
     if (depth == 1) {
         // score divisor len ** 0.7 exactly as the reference evaluates it: Python float pow (libm double), then fp32 (:262-266)
-        std::vector<float> tab(max_depth + 4);
-        for (int l = 0; l < max_depth + 4; ++l) tab[l] = l > 0 ? (float)pow((double)l, 0.7) : 1.0f;
-        S2VT_HIP(hipMemcpyAsync(const_cast<float*>(q.pow07), tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, st));
-        S2VT_HIP(hipStreamSynchronize(st));                  // (the table leaves scope; once per search)
+        // The table lives in pinned host memory for the life of the process (it depends on nothing but the length), so the copy
+        // is asynchronous: no host synchronisation at the start of a search, and the call can be stream-captured.
+        static float* tab = nullptr;
+        static int tab_len = 0;
+        if (tab_len < max_depth + 4) {
+            float* grown = nullptr;
+            const int len = (max_depth + 4 + 1023) / 1024 * 1024;
+            S2VT_HIP(hipHostMalloc(reinterpret_cast<void**>(&grown), (size_t)len * sizeof(float), hipHostMallocDefault));
+            for (int l = 0; l < len; ++l) grown[l] = l > 0 ? (float)pow((double)l, 0.7) : 1.0f;
+            tab = grown;            // (an older, shorter table stays allocated: copies from it may still be in flight)
+            tab_len = len;
+        }
+        S2VT_HIP(hipMemcpyAsync(const_cast<float*>(q.pow07), tab, (size_t)(max_depth + 4) * sizeof(float), hipMemcpyHostToDevice, st));
         S2VT_HIP(hipMemsetAsync(q.done_count, 0, sizeof(int), st));
     }
     hipLaunchKernelGGL(beam_queue_kernel, dim3(B), dim3(64), 0, st, q);

@@ -115,6 +115,65 @@ int mean_ce_fwd(hipStream_t s, const float* logits, int64_t rows, int V, const i
     return 0;
 }
 
+// ---------------------------------------------------------------------------------- MaskCriterion's outer arithmetic
+// utils.py:23-25 of the reference around the mean CE: w = mask[:, 1:] flattened, loss = sum(mean_ce * w) / sum(w) (NaN for an
+// all-zero mask, as upstream), evaluated product by product as the reference does - ONE workgroup behind the per-row kernel
+// instead of a dozen elementwise / reduction launches of the host framework.  out[0] = loss, out[1] = mean_ce, out[2] = sum(w).
+// Fixed summation order (thread strips, wave butterfly, four waves in order): deterministic.
+__device__ __forceinline__ float block_sum_256(float s, float* sred) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    s = wave_sum(s);
+    __syncthreads();                       // (sred may still be read from the previous reduction)
+    if (lane == 0) sred[wave] = s;
+    __syncthreads();
+    return (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+__global__ __launch_bounds__(256) void mask_criterion_fwd_kernel(const float* rowloss, int64_t rows, const float* mask, int64_t ldm,
+                                                                 int Lm1, float* out) {
+    __shared__ float sred[4];
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (int64_t r = tid; r < rows; r += 256) s += rowloss[r];
+    const float mean_ce = block_sum_256(s, sred) / (float)rows;          // (ce_mean_kernel's arithmetic)
+    float num = 0.f, den = 0.f;
+    for (int64_t r = tid; r < rows; r += 256) {
+        const float w = mask[(r / Lm1) * ldm + (r % Lm1) + 1];
+        num += mean_ce * w;
+        den += w;
+    }
+    num = block_sum_256(num, sred);
+    den = block_sum_256(den, sred);
+    if (tid == 0) { out[0] = num / den; out[1] = mean_ce; out[2] = den; }
+}
+// autograd of the same three lines: d loss / d mean_ce = sum_i (gout / sum(w)) * w_i  ->  g_ce[0]
+__global__ __launch_bounds__(256) void mask_criterion_bwd_kernel(const float* mask, int64_t ldm, int64_t rows, int Lm1, const float* fwd_out,
+                                                                 const float* gout, float* g_ce) {
+    __shared__ float sred[4];
+    const int tid = threadIdx.x;
+    const float q = gout[0] / fwd_out[2];
+    float s = 0.f;
+    for (int64_t r = tid; r < rows; r += 256) s += q * mask[(r / Lm1) * ldm + (r % Lm1) + 1];
+    s = block_sum_256(s, sred);
+    if (tid == 0) g_ce[0] = s;
+}
+
+int mask_criterion_fwd(hipStream_t s, const float* logits, int64_t rows, int V, const int64_t* target, int Lm1, int64_t ldt,
+                       const float* mask, int64_t ldm, float* lse, float* rowloss, float* out3, int* err_flag) {
+    S2VT_REQUIRE(rows > 0 && V > 0 && logits && target && mask && lse && rowloss && out3, "mask_criterion_fwd: bad arguments");
+    hipLaunchKernelGGL(ce_row_kernel, dim3((unsigned)rows), dim3(256), 0, s, logits, V, target, Lm1, ldt, lse, rowloss, err_flag);
+    S2VT_LAUNCH_CHECK("ce_row_kernel");
+    hipLaunchKernelGGL(mask_criterion_fwd_kernel, dim3(1), dim3(256), 0, s, rowloss, rows, mask, ldm, Lm1, out3);
+    S2VT_LAUNCH_CHECK("mask_criterion_fwd_kernel");
+    return 0;
+}
+int mask_criterion_bwd(hipStream_t s, const float* mask, int64_t ldm, int64_t rows, int Lm1, const float* fwd_out, const float* gout,
+                       float* g_ce) {
+    S2VT_REQUIRE(rows > 0 && mask && fwd_out && gout && g_ce, "mask_criterion_bwd: bad arguments");
+    hipLaunchKernelGGL(mask_criterion_bwd_kernel, dim3(1), dim3(256), 0, s, mask, ldm, rows, Lm1, fwd_out, gout, g_ce);
+    S2VT_LAUNCH_CHECK("mask_criterion_bwd_kernel");
+    return 0;
+}
+
 // dlogits[r][v] = (exp(logit - lse_r) - [v == target_r]) * gout / rows
 __global__ __launch_bounds__(256) void ce_bwd_kernel(const float* logits, int64_t rows, int V, const int64_t* target,
                                                      int Lm1, int64_t ldt, const float* lse, const float* gout,
@@ -308,8 +367,7 @@ __global__ __launch_bounds__(256) void top20_logprob_reg_kernel(const float* log
 int top20_logprob(hipStream_t s, const float* logits, int64_t ld, int64_t rows, int V, int32_t* top_ix, float* top_lp) {
     if (rows <= 0) return 0;
     S2VT_REQUIRE(V >= TOPK_N && (size_t)V * sizeof(float) <= 150 * 1024, "top20_logprob: 20 <= vocab_size <= 38400");
-    static const bool lds_form = getenv("S2VT_TOP20_LDS") && atoi(getenv("S2VT_TOP20_LDS")) != 0;      // A/B switch
-    if (!lds_form && V <= 256 * 64) {
+    if (V <= 256 * 64) {            // the row in registers; larger vocabularies: staged in LDS (top20_logprob_kernel)
         const dim3 grid((unsigned)rows), block(256);
         if (V <= 256 * 16) hipLaunchKernelGGL(top20_logprob_reg_kernel<16>, grid, block, 0, s, logits, ld, V, top_ix, top_lp);
         else if (V <= 256 * 32) hipLaunchKernelGGL(top20_logprob_reg_kernel<32>, grid, block, 0, s, logits, ld, V, top_ix, top_lp);

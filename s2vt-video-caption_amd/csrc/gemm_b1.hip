@@ -372,7 +372,7 @@ int splitk_reduce(hipStream_t stream, const float* slabs, int nsplit, int M, int
 static const double kB1Stage[6] = {0, 0, 1.15, 1.50, 1.70, 2.25};
 static const double kB1Epi[6] = {0, 0, 4.5, 6.0, 8.0, 10.0};
 
-static int g_b1_force_mi = -1, g_b1_force_n = -1;
+static int g_b1_force_mi = 0, g_b1_force_n = 0;
 void gemm_b1_tune(int tile_rows, int nsplit) {
     g_b1_force_mi = (tile_rows >= 128 && tile_rows <= 320 && tile_rows % 64 == 0) ? tile_rows / 64 : 0;
     g_b1_force_n = nsplit > 0 ? nsplit : 0;
@@ -410,23 +410,12 @@ static int gemm_b1_impl(hipStream_t stream, bool tt, int M, int N, int K, const 
     p.A = A; p.lda = lda;
     p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.cmap = cmap; p.bias = bias; p.accumulate = accumulate ? 1 : 0;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-        (void)hipGetLastError();
-        // S2VT_CU_RESERVE=n: plan the persistent grids for n compute units fewer.  A launch is sized to ONE workgroup per compute unit
-        // with a static share of the tiles each; a long-lived foreign kernel on some of the units (a communication kernel of a
-        // data-parallel run) makes the workgroups that find no unit wait for a whole share.  Default 0.
-        const char* e = getenv("S2VT_CU_RESERVE");
-        const int reserve = e ? atoi(e) : 0;
-        if (reserve > 0 && reserve < n - 8) n -= reserve;
-        ncu = n / 8 * 8;
-    }
-    // S2VT_B1_MI=2..5 / S2VT_B1_NSPLIT=n or s2vt_gemm_tune(): overrides of the time model (kernel tests run every tile height,
+    // option "cu_reserve" = n: plan the persistent grids for n compute units fewer.  A launch is sized to ONE workgroup per compute
+    // unit with a static share of the tiles each; a long-lived foreign kernel on some of the units (a communication kernel of a
+    // data-parallel run) makes the workgroups that find no unit wait for a whole share (multi-GPU).
+    const int ncu = planned_compute_units();
+    // s2vt_gemm_tune(1, tile_rows, nsplit): overrides of the time model (kernel tests run every tile height,
     // tools/bench_gemm_shapes.py calibrates the model with them)
-    if (g_b1_force_mi < 0) { const char* e = getenv("S2VT_B1_MI"); g_b1_force_mi = e ? atoi(e) : 0; }
-    if (g_b1_force_n < 0) { const char* e = getenv("S2VT_B1_NSPLIT"); g_b1_force_n = e ? atoi(e) : 0; }
     const int force_mi = g_b1_force_mi, force_n = g_b1_force_n;
     // tile height, split-K factor and grid by the time model: every workgroup walks ceil(its XCD's chunk / workgroups of the
     // XCD) tiles of nk stages + an epilogue; split-K adds the fixed-order slab combine ((n + 1) passes over M x N floats at
@@ -434,6 +423,9 @@ static int gemm_b1_impl(hipStream_t stream, bool tt, int M, int N, int K, const 
     const int ntn = cdiv(N, 256);
     int best_mi = 4, best_ns = 1, best_g = 8;
     double best = 1e30;
+    // (transposed reads: a k slice of a row image behind one descriptor and int offsets stays below 2 GB - larger images are cut
+    // into k slices, as in gemm_x3.hip)
+    const int64_t ldmax = lda > ldb ? lda : ldb, kTTSpan = 0x7FFFF000ll;
     static const int order[4] = {4, 5, 3, 2};
     for (int oi = 0; oi < 4; ++oi) {
         const int mi = order[oi];
@@ -444,6 +436,7 @@ static int gemm_b1_impl(hipStream_t stream, bool tt, int M, int N, int K, const 
             if (force_n && n != force_n) continue;
             const int ks = cdiv(cdiv(K, n), 64) * 64, nn = cdiv(K, ks);
             if (nn != n) continue;
+            if (tt && (int64_t)ks * ldmax * 2 >= kTTSpan) continue;     // (a k slice of a row image must fit the signed 32-bit offsets)
             int g = ncu / nn / 8 * 8;
             if (g < 8) g = 8;
             if (g > cdiv(tiles, 8) * 8) g = cdiv(tiles, 8) * 8;
@@ -455,6 +448,9 @@ static int gemm_b1_impl(hipStream_t stream, bool tt, int M, int N, int K, const 
         }
     }
     if (best > 1e29) {      // (an override that no candidate met: one slice of 256-row tiles)
+        S2VT_REQUIRE(!tt || (int64_t)K * ldmax * 2 < kTTSpan,
+                     "gemm_b1_tt: a row image of %lld bytes needs k slices below 2 GB and split-K scratch for them (%zu floats given)",
+                     (long long)((int64_t)K * ldmax * 2), splitk_ws_floats);
         best_mi = 4; best_ns = 1;
         best_g = cdiv(cdiv(M, 256) * ntn, 8) * 8;
         if (best_g > ncu) best_g = ncu;

@@ -380,7 +380,7 @@ int splitk_reduce(hipStream_t stream, const float* slabs, int nsplit, int M, int
 // under S2VT_X3_MI); the stage is bound by the six plane products (12 MI MFMAs per wave)
 static const double kX3Stage[5] = {0, 0, 1.35, 1.75, 2.15};
 static const double kX3Epi[5] = {0, 0, 4.5, 6.0, 8.0};
-static int g_x3_force_mi = -1, g_x3_force_n = -1;
+static int g_x3_force_mi = 0, g_x3_force_n = 0;
 void gemm_x3_tune(int tile_rows, int nsplit) {
     g_x3_force_mi = (tile_rows >= 128 && tile_rows <= 256 && tile_rows % 64 == 0) ? tile_rows / 64 : 0;
     g_x3_force_n = nsplit > 0 ? nsplit : 0;
@@ -409,8 +409,8 @@ static int gemm_x3_impl(hipStream_t stream, bool tt, int M, int N, int K, const 
     if (tt) {
         S2VT_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= 3 * (int64_t)((M + 63) / 64 * 64) &&
                          ldb >= 3 * (int64_t)((N + 63) / 64 * 64) && (reinterpret_cast<uintptr_t>(A) & 15) == 0 &&
-                         (reinterpret_cast<uintptr_t>(B) & 15) == 0 && (int64_t)K * lda * 2 < (1ll << 32) && (int64_t)K * ldb * 2 < (1ll << 32),
-                     "gemm_x3_tt: K (image rows) must be a multiple of 64, the row images hold pad64(M) / pad64(N) columns, < 4 GB each");
+                         (reinterpret_cast<uintptr_t>(B) & 15) == 0,
+                     "gemm_x3_tt: K (image rows) must be a multiple of 64, the row images hold pad64(M) / pad64(N) columns");
     } else
     S2VT_REQUIRE(K > 0 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && lda >= 3 * (int64_t)K && ldb >= 3 * (int64_t)K &&
                      (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(B) & 15) == 0,
@@ -420,22 +420,11 @@ static int gemm_x3_impl(hipStream_t stream, bool tt, int M, int N, int K, const 
     p.A = A; p.lda = lda;
     p.B = B; p.ldb = ldb;
     p.C = C; p.ldc = ldc; p.cmap = cmap; p.bias = bias; p.accumulate = accumulate ? 1 : 0;
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-        (void)hipGetLastError();
-        // S2VT_CU_RESERVE=n: plan the persistent grids for n compute units fewer.  A launch is sized to ONE workgroup per compute unit
-        // with a static share of the tiles each; a long-lived foreign kernel on some of the units (a communication kernel of a
-        // data-parallel run) makes the workgroups that find no unit wait for a whole share.  Default 0.
-        const char* e = getenv("S2VT_CU_RESERVE");
-        const int reserve = e ? atoi(e) : 0;
-        if (reserve > 0 && reserve < n - 8) n -= reserve;
-        ncu = n / 8 * 8;
-    }
-    // S2VT_X3_MI=2..4 / S2VT_X3_NSPLIT=n or s2vt_gemm_tune(3, ...): overrides of the time model
-    if (g_x3_force_mi < 0) { const char* e = getenv("S2VT_X3_MI"); g_x3_force_mi = e ? atoi(e) : 0; }
-    if (g_x3_force_n < 0) { const char* e = getenv("S2VT_X3_NSPLIT"); g_x3_force_n = e ? atoi(e) : 0; }
+    // option "cu_reserve" = n: plan the persistent grids for n compute units fewer.  A launch is sized to ONE workgroup per compute
+    // unit with a static share of the tiles each; a long-lived foreign kernel on some of the units (a communication kernel of a
+    // data-parallel run) makes the workgroups that find no unit wait for a whole share (multi-GPU).
+    const int ncu = planned_compute_units();
+    // s2vt_gemm_tune(3, tile_rows, nsplit): overrides of the time model (kernel tests run every tile height, tools/bench_gemm_shapes.py)
     const int force_mi = g_x3_force_mi, force_n = g_x3_force_n;
     // One workgroup per CU.  Tile height, split-K factor and grid by the time model: every workgroup walks ceil(its XCD's chunk /
     // workgroups of the XCD) tiles of nk stages + an epilogue; split-K adds the fixed-order slab combine ((n + 1) passes over
@@ -443,6 +432,10 @@ static int gemm_x3_impl(hipStream_t stream, bool tt, int M, int N, int K, const 
     const int ntn = cdiv(N, 256);
     int best_mi = 4, best_ns = 1, best_g = 8;
     double best = 1e30;
+    // Transposed reads address a k slice of a row image through ONE buffer descriptor and 32-bit offsets: a slice (ks image rows of
+    // ld elements) must stay below 4 GB.  An image beyond that (dlogits from B = 768 on at V = 12000) is cut into k slices here -
+    // the split-K path with its fixed-order combine - instead of being refused.
+    const int64_t ldmax = lda > ldb ? lda : ldb, kTTSpan = 0xFFFFF000ll;
     static const int order[3] = {4, 3, 2};
     for (int oi = 0; oi < 3; ++oi) {
         const int mi = order[oi];
@@ -453,6 +446,7 @@ static int gemm_x3_impl(hipStream_t stream, bool tt, int M, int N, int K, const 
             if (force_n && n != force_n) continue;
             const int ks = cdiv(cdiv(K, n), 64) * 64, nn = cdiv(K, ks);
             if (nn != n) continue;
+            if (tt && (int64_t)ks * ldmax * 2 >= kTTSpan) continue;     // (a k slice of a row image must fit the 32-bit offsets)
             int g = ncu / nn / 8 * 8;
             if (g < 8) g = 8;
             if (g > cdiv(tiles, 8) * 8) g = cdiv(tiles, 8) * 8;
@@ -464,6 +458,9 @@ static int gemm_x3_impl(hipStream_t stream, bool tt, int M, int N, int K, const 
         }
     }
     if (best > 1e29) {      // (an override that no candidate met: one slice of 256-row tiles)
+        S2VT_REQUIRE(!tt || (int64_t)K * ldmax * 2 < kTTSpan,
+                     "gemm_x3_tt: a row image of %lld bytes needs k slices below 4 GB and split-K scratch for them (%zu floats given)",
+                     (long long)((int64_t)K * ldmax * 2), splitk_ws_floats);
         best_mi = 4; best_ns = 1;
         best_g = cdiv(cdiv(M, 256) * ntn, 8) * 8;
         if (best_g > ncu) best_g = ncu;

@@ -182,19 +182,6 @@ struct SeqBwdBf16Args {
 int lstm_seq_bwd_bf16_persist_supported(int B, int H, int Kp4);
 int lstm_seq_bwd_bf16_persist2(hipStream_t stream, SeqBwdBf16Args a, const SeqBwdBf16Args* b);
 
-// ---- lstm_persist_f32.hip: persistent fp32 recurrence (config 2 arithmetic: exact-fp32 MFMA)
-struct SeqFwdF32Args {
-    int B, H;                                       // H % 8 == 0, H <= 1024
-    int t0, t1, n_gx;
-    const float* w_hh; int64_t ldw;                 // [4H][H]
-    float* h_all;                                   // [T*B][H] time-major: h_{t-1} in, h_t out (the hand-off payload)
-    float* gx_stash; const float* bias; float* c_all;
-    unsigned int* sync; int* err;
-    int RB, NS;                                     // set by the launcher
-    unsigned long long* stamps; int stamp_block;    // timing experiments only (experiment.h); null in the product
-};
-int lstm_seq_fwd_f32_persist_supported(int B, int H);
-int lstm_seq_fwd_f32_persist2(hipStream_t stream, SeqFwdF32Args a, const SeqFwdF32Args* b);
 // split-precision (three bf16 planes per operand, six plane products: fp32-equivalent) persistent forward, lstm_persist_x3.hip
 struct SeqFwdX3Args {
     int B, H, Kp;                                   // Kp = H rounded up to 64 (<= 1024): row length of the plane images
@@ -228,18 +215,6 @@ int lstm_seq_bwd_x3_persist_supported(int B, int H);
 size_t lstm_seq_bwd_x3_part_slot_floats(int B, int H);
 int lstm_seq_bwd_x3_persist2(hipStream_t stream, SeqBwdX3Args a, const SeqBwdX3Args* b);
 int split3_wt(hipStream_t stream, const float* wt, int H, int Kp, int Hp, unsigned short* dst, int64_t plane);
-struct SeqBwdF32Args {
-    int B, H;                                       // H % 4 == 0, H <= 1024
-    int T, t0, t1;
-    const float* w_hh_t; int64_t ldwt;              // W_hh^T [H][4H]
-    const float* dh_out; int dh_first;
-    float* stash_dg;                                // [T*B][4H]: activated gates in, dG out (in place; dG_{t+1} is the operand)
-    const float* c_all; float* dc;
-    unsigned int* sync; int* err;
-    int RB, NS;
-};
-int lstm_seq_bwd_f32_persist_supported(int B, int H);
-int lstm_seq_bwd_f32_persist2(hipStream_t stream, SeqBwdF32Args a, const SeqBwdF32Args* b);
 
 struct LogitsArgmaxArgs {
     int B, H, V;
@@ -294,5 +269,10 @@ int mean_ce_fwd(hipStream_t s, const float* logits, int64_t rows, int V, const i
                 float* lse, float* rowloss, float* loss_out, int* err_flag);
 int mean_ce_bwd(hipStream_t s, const float* logits, int64_t rows, int V, const int64_t* target, int Lm1, int64_t ldt,
                 const float* lse, const float* gout, float* dlogits);
+// MaskCriterion as a whole (utils.py:13-26): per-row CE, then mean / mask weighting / division in one workgroup; out3 = {loss, mean_ce, sum(w)}
+int mask_criterion_fwd(hipStream_t s, const float* logits, int64_t rows, int V, const int64_t* target, int Lm1, int64_t ldt,
+                       const float* mask, int64_t ldm, float* lse, float* rowloss, float* out3, int* err_flag);
+int mask_criterion_bwd(hipStream_t s, const float* mask, int64_t ldm, int64_t rows, int Lm1, const float* fwd_out, const float* gout,
+                       float* g_ce);
 
 }  // namespace s2vt

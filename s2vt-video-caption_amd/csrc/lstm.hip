@@ -511,12 +511,10 @@ int lstm_step_bwd2(hipStream_t stream, const StepBwdArgs& a, const StepBwdArgs* 
     auto okv = [](const StepBwdArgs& x) { return !x.dg_next || (vec_ok(x.dg_next, x.lddg) && vec_ok(x.w_hh_t, x.ldwt)); };
     const bool vec = okv(a) && (!b || okv(*b));
     const StepBwdArgs& bb = b ? *b : a;
-    // 32-row tiles where they still fill the chip (B >= 128 at H = 1000; S2VT_BWD_ROWS=16|32 overrides): a workgroup then takes
+    // 32-row tiles where they still fill the chip (B >= 128 at H = 1000): a workgroup then takes
     // in dG of 32 rows + one W_hh^T slice (768 KB) where two 16-row workgroups take in 1 MB - config-3-shard step (B = 128)
     // 20.56 -> 20.11 ms; at B = 64 they would leave half the compute units idle (11.6 -> 12.0 ms)
-    static int rows_env = -1;
-    if (rows_env < 0) { const char* e = getenv("S2VT_BWD_ROWS"); rows_env = e ? atoi(e) : 0; }
-    const bool wide = vec && (rows_env ? rows_env == 32 : cdiv(a.H, 16) * cdiv(a.B, 32) >= 240);
+    const bool wide = vec && cdiv(a.H, 16) * cdiv(a.B, 32) >= 240;
     if (wide) {
         const int na = xcd_grid(cdiv(a.H, 16), cdiv(a.B, 32));
         hipLaunchKernelGGL((lstm_step_bwd_kernel<2, 1, true>), dim3(b ? 2 * na : na), dim3(NW_BWD * 64), 0, stream, a, bb, na);

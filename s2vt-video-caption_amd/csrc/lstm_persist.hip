@@ -337,9 +337,7 @@ __device__ __forceinline__ int persist_role(int bid, int na, int nC, int xg, boo
 }
 // the launcher's side of it: G groups, or 0 for the plain order
 static int xcd_groups(int na, int nb, int nC) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("S2VT_PERSIST_XCD"); on = e ? atoi(e) : 1; }
-    if (!on || nC <= 0 || na % nC || nb % nC) return 0;
+    if (nC <= 0 || na % nC || nb % nC) return 0;
     if (nb && nb != na) return 0;
     const int G = (na + nb) / nC;
     return (G > 0 && 8 % G == 0 && ((na + nb) % 8) == 0) ? G : 0;
@@ -681,14 +679,13 @@ static int chains_for(int B, int H, int cap, int un, bool single = false) {
 }
 
 // Which shape of the BPTT kernel a layer of (B, H) runs with: 32 units per workgroup (one workgroup per compute unit)
-// wherever two such layers fit the device, else 16 units (two per compute unit).  S2VT_BPTT_UNITS=16|32 pins one (tests,
-// A/B timing).
+// wherever two such layers fit the device, else 16 units (two per compute unit).  Option "bptt_units" = 16 | 32 pins one (the
+// kernel tests run both; 0: the rule above).
 struct BwdPlan { int un, ns, cap; };
 static BwdPlan bwd_plan(int B, int H, int Kp4, bool single = false) {
     BwdPlan none = {0, 0, 0};
     if (!(B > 0 && B % P_SR == 0 && H % 8 == 0 && Kp4 % 64 == 0 && Kp4 >= 4 * H && Kp4 <= 64 * Q_KCH)) return none;
-    static int pref = -1;
-    if (pref < 0) { const char* e = getenv("S2VT_BPTT_UNITS"); pref = e ? atoi(e) : 0; }
+    const int pref = option(O_BPTT_UNITS);
     if (pref != 16) {
         int cap = coresident_capacity(reinterpret_cast<const void*>(&lstm_seq_bwd_bf16_persist_kernel<8, 32>), 512);
         if (cap > P_MAX_WG / 2) cap = P_MAX_WG / 2;
@@ -791,8 +788,7 @@ int lstm_seq_fwd_bf16_persist2(hipStream_t stream, SeqFwdBf16Args a, const SeqFw
     // (no XCD-aware dealing for the forward: with TWO workgroups per compute unit the neighbours on a CU must be out of phase to
     // hide each other's hand-off latencies, and dealing a group to one XCD makes them members of the same chain - measured
     // 1.99 vs 1.84 ms per config-3 forward; the one-per-CU BPTT launch gains from it: 2.90 vs 3.12 ms)
-    static const bool fwd_xcd = getenv("S2VT_PERSIST_XCD_FWD") && atoi(getenv("S2VT_PERSIST_XCD_FWD")) != 0;
-    const int xg = (fwd_xcd && (!b || (bb.B == a.B && bb.H == a.H))) ? xcd_groups(na, nb, cdiv(a.H, P_UN)) : 0;
+    const int xg = 0;
     if (a.Kp == 64 * P_KCH)
         hipLaunchKernelGGL((lstm_seq_fwd_bf16_persist_kernel<true>), dim3(na + nb), dim3(P_NT), 0, stream, a, bb, na, xg);
     else

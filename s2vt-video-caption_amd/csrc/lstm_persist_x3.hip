@@ -437,11 +437,10 @@ int lstm_seq_fwd_x3_persist2(hipStream_t stream, SeqFwdX3Args a, const SeqFwdX3A
     if (a.t0 == 0) S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
     if (b && bb.t0 == 0) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
     // XCD-aware dealing (see the kernel) when the groups divide the 8 XCDs and the padded grid still fits the device
-    static const bool xcd_on = !(getenv("S2VT_PERSIST_XCD") && atoi(getenv("S2VT_PERSIST_XCD")) == 0);
     const int nC = cdiv(a.H, X_UN);
     const int G = (na + nb) / nC;
     int xg = 0, grid = na + nb;
-    if (xcd_on && (!b || (bb.B == a.B && bb.H == a.H)) && G > 0 && G <= 8 && 8 % G == 0) {
+    if ((!b || (bb.B == a.B && bb.H == a.H)) && G > 0 && G <= 8 && 8 % G == 0) {
         const int padded = 8 * cdiv(nC, 8 / G);
         if (padded <= fwd_x3_capacity()) { xg = G; grid = padded; }
     }
@@ -817,10 +816,9 @@ int lstm_seq_bwd_x3_persist2(hipStream_t stream, SeqBwdX3Args a, const SeqBwdX3A
     // the hand-off counters count finished timesteps of the whole sequence: zeroed with its first block (t1 == T) only
     if (a.t1 == a.T) S2VT_HIP(hipMemsetAsync(a.sync, 0, lstm_persist_sync_bytes(), stream));
     if (b && bb.t1 == bb.T) S2VT_HIP(hipMemsetAsync(bb.sync, 0, lstm_persist_sync_bytes(), stream));
-    static const bool xcd_on = !(getenv("S2VT_PERSIST_XCD") && atoi(getenv("S2VT_PERSIST_XCD")) == 0);
     const int G = (na + nb) / nC;
     int xg = 0, grid = na + nb;
-    if (xcd_on && (!b || (bb.B == a.B && bb.H == a.H)) && G > 0 && G <= 8 && 8 % G == 0) {
+    if ((!b || (bb.B == a.B && bb.H == a.H)) && G > 0 && G <= 8 && 8 % G == 0) {
         const int padded = 8 * cdiv(nC, 8 / G);
         if (padded <= bwd_x3_capacity()) { xg = G; grid = padded; }
     }

@@ -263,27 +263,61 @@ def decode_encode(feats, params, owner, depth=0):
         rc = lib.s2vt_decode_encode_cached(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), _ptr(ws), nbytes, _ptr(cache), cache.numel(),
                                            1 if valid else 0, _ptr(out[0]), _ptr(out[1]), _ptr(out[2]), _ptr(out[3]), _ptr(gx_dec),
                                            depth, _stream(dev))
-        if rc != 0:
-            return None                              # (a shape the library's own predicate refused: capi.last_error() says why)
+        if rc == -1:
+            return None                              # (S2VT_ERR_ARG: a shape the library's own predicate refused - before anything was
+                                                     #  enqueued - capi.last_error() says why; the caller runs its own encoder)
+        capi.check(rc, "s2vt_decode_encode_cached")  # anything else is a real error (HIP, time-out, bad token id): raise
         entry = _DECODE_CACHES.get(owner)
         if entry is not None and entry[1] is cache:
             entry[2] = True
     return out[0], out[1], out[2], out[3], gx_dec
 
 
+def _ce_inputs(logits, target):
+    logits = _f32c(logits, "logits")
+    require_hip(target, "target")
+    if target.dtype != torch.int64:
+        target = target.long()
+    if target.stride(1) != 1:
+        target = target.contiguous()
+    B, Lm1, V = logits.shape
+    if target.shape[0] != B or target.shape[1] != Lm1 + 1:
+        raise ValueError("target must be [B, L] = [%d, %d], got %s" % (B, Lm1 + 1, tuple(target.shape)))
+    return logits, target
+
+
+def _fusable_train_node(logits):
+    """The _TrainForward node behind `logits` when the criterion's backward may write the dlogits operand planes into that
+    forward's workspace instead of a [B, L-1, V] fp32 tensor (fused route), else None."""
+    node = getattr(logits, "grad_fn", None)
+    return node if (node is not None and getattr(node, "fusable", False) and getattr(node, "ws", None) is not None
+                    and logits.is_contiguous()) else None
+
+
+def _ce_backward(lib, node, logits, target, lse, g):
+    """d(mean CE)/d(logits) * g (g: one device float) - fused into the train workspace of `node` where that applies."""
+    B, Lm1, V = logits.shape
+    dev = logits.device
+    if node is not None and node.ws is not None and not node.used and not node.dlog_fused and FUSE_CE:
+        with torch.cuda.device(dev):
+            capi.check(lib.s2vt_mean_ce_backward_fused(ctypes.byref(node.d), _ptr(logits), _ptr(target), target.stride(0),
+                                                       _ptr(lse), _ptr(g), _ptr(node.ws), node.ws.numel(), _stream(dev)),
+                       "s2vt_mean_ce_backward_fused")
+        node.dlog_fused = True
+        return torch.zeros((), dtype=logits.dtype, device=dev).expand(B, Lm1, V)     # placeholder: no memory behind it
+    with torch.cuda.device(dev):
+        dlogits = torch.empty_like(logits)
+        capi.check(lib.s2vt_mean_ce_backward(B, Lm1, V, _ptr(logits), _ptr(target), target.stride(0), _ptr(lse),
+                                             _ptr(g), _ptr(dlogits), _stream(dev)), "s2vt_mean_ce_backward")
+    return dlogits
+
+
 class _MeanCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, target):
         lib = capi.load()
-        logits = _f32c(logits, "logits")
-        require_hip(target, "target")
-        if target.dtype != torch.int64:
-            target = target.long()
-        if target.stride(1) != 1:
-            target = target.contiguous()
+        logits, target = _ce_inputs(logits, target)
         B, Lm1, V = logits.shape
-        if target.shape[0] != B or target.shape[1] != Lm1 + 1:
-            raise ValueError("target must be [B, L] = [%d, %d], got %s" % (B, Lm1 + 1, tuple(target.shape)))
         dev = logits.device
         with torch.cuda.device(dev):
             scratch = torch.empty(2 * B * Lm1 + 1, dtype=torch.float32, device=dev)
@@ -291,35 +325,62 @@ class _MeanCE(torch.autograd.Function):
             capi.check(lib.s2vt_mean_ce_forward(B, Lm1, V, _ptr(logits), _ptr(target), target.stride(0), _ptr(lse),
                                                 _ptr(rowloss), _ptr(loss), _stream(dev)), "s2vt_mean_ce_forward")
         ctx.save_for_backward(logits, target, lse)
-        # fused route: the logits come straight from S2VT.forward(mode='train') on the plane drivers -> the backward below
-        # writes the dlogits operand planes into that forward's workspace instead of a [B, L-1, V] fp32 tensor
-        node = getattr(logits, "grad_fn", None)
-        ctx.train_node = node if (node is not None and getattr(node, "fusable", False) and getattr(node, "ws", None) is not None
-                                  and logits.is_contiguous()) else None
+        ctx.train_node = _fusable_train_node(logits)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, gout):
-        lib = capi.load()
         logits, target, lse = ctx.saved_tensors
+        gout = _f32c(gout.reshape(1), "grad_output")
+        return _ce_backward(capi.load(), ctx.train_node, logits, target, lse, gout), None
+
+
+class _MaskCriterion(torch.autograd.Function):
+    """MaskCriterion.forward (utils.py:13-26) in two launches: per-row CE, then mean / mask weighting / division."""
+
+    @staticmethod
+    def forward(ctx, logits, target, mask):
+        lib = capi.load()
+        logits, target = _ce_inputs(logits, target)
+        require_hip(mask, "mask")
+        if mask.dtype != torch.float32:
+            mask = mask.float()
+        if mask.dim() != 2 or mask.stride(1) != 1:
+            mask = mask.reshape(mask.shape[0], -1).contiguous()
+        B, Lm1, V = logits.shape
+        if mask.shape[0] != B or mask.shape[1] != Lm1 + 1:
+            raise ValueError("mask must be [B, L] = [%d, %d], got %s" % (B, Lm1 + 1, tuple(mask.shape)))
+        dev = logits.device
+        with torch.cuda.device(dev):
+            scratch = torch.empty(2 * B * Lm1 + 4, dtype=torch.float32, device=dev)
+            lse, rowloss, out3 = scratch[:B * Lm1], scratch[B * Lm1:2 * B * Lm1], scratch[2 * B * Lm1:]
+            capi.check(lib.s2vt_mask_criterion_forward(B, Lm1, V, _ptr(logits), _ptr(target), target.stride(0), _ptr(mask),
+                                                       mask.stride(0), _ptr(lse), _ptr(rowloss), _ptr(out3), _stream(dev)),
+                       "s2vt_mask_criterion_forward")
+        ctx.save_for_backward(logits, target, lse, mask, out3)
+        ctx.train_node = _fusable_train_node(logits)
+        return out3[0].reshape(())
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = capi.load()
+        logits, target, lse, mask, out3 = ctx.saved_tensors
         B, Lm1, V = logits.shape
         dev = logits.device
         gout = _f32c(gout.reshape(1), "grad_output")
-        node = ctx.train_node
-        if node is not None and node.ws is not None and not node.used and not node.dlog_fused and FUSE_CE:
-            with torch.cuda.device(dev):
-                capi.check(lib.s2vt_mean_ce_backward_fused(ctypes.byref(node.d), _ptr(logits), _ptr(target), target.stride(0),
-                                                           _ptr(lse), _ptr(gout), _ptr(node.ws), node.ws.numel(), _stream(dev)),
-                           "s2vt_mean_ce_backward_fused")
-            node.dlog_fused = True
-            return torch.zeros((), dtype=logits.dtype, device=dev).expand(B, Lm1, V), None     # placeholder: no memory behind it
         with torch.cuda.device(dev):
-            dlogits = torch.empty_like(logits)
-            capi.check(lib.s2vt_mean_ce_backward(B, Lm1, V, _ptr(logits), _ptr(target), target.stride(0), _ptr(lse),
-                                                 _ptr(gout), _ptr(dlogits), _stream(dev)), "s2vt_mean_ce_backward")
-        return dlogits, None
+            g_ce = torch.empty(1, dtype=torch.float32, device=dev)
+            capi.check(lib.s2vt_mask_criterion_backward(B, Lm1, _ptr(mask), mask.stride(0), _ptr(out3), _ptr(gout), _ptr(g_ce),
+                                                        _stream(dev)), "s2vt_mask_criterion_backward")
+        return _ce_backward(lib, ctx.train_node, logits, target, lse, g_ce), None, None
 
 
 def mean_cross_entropy(logits, target):
     """Mean CE of logits [B, L-1, V] against target[:, 1:] (target int64 [B, L]) — utils.py:11,22."""
     return _MeanCE.apply(logits, target)
+
+
+def mask_criterion(logits, target, mask):
+    """MaskCriterion()(logits, target, mask) of the reference (utils.py:13-26): mean CE against target[:, 1:], weighted with
+    mask[:, 1:] and divided by its sum (NaN for an all-zero mask, as upstream).  No gradient flows to the mask."""
+    return _MaskCriterion.apply(logits, target, mask)

@@ -316,29 +316,20 @@ def lstm_seq_bwd_bf16_pair(w0, w1, dh0, dh1, dh_first, c0, c1, gates0, gates1, T
     return dg0, dg1
 
 
-def _persist_ws(dev):
-    lib = capi.load()
-    n = lib.s2vt_lstm_persist_workspace_bytes()
-    return torch.zeros(n, dtype=torch.uint8, device=dev), n
-
-
-def lstm_seq_fwd_persist(T, B, gx, n_gx, bias, w_hh, block=0, second=None, x3=False, poison=True):
-    """fp32 layer forward with the persistent kernel: returns (h_all, c_all, gates).  `second` = (gx, bias, w_hh) of another
-    layer of the same shape that shares every launch: then a pair of result tuples is returned.  x3: the split-precision kernel
-    (three bf16 planes per operand, lstm_persist_x3.hip) instead of the exact-fp32 MFMA one."""
+def lstm_seq_fwd_persist(T, B, gx, n_gx, bias, w_hh, block=0, second=None, poison=True):
+    """fp32-equivalent layer forward with the persistent split-precision kernel (three bf16 planes per operand,
+    lstm_persist_x3.hip): returns (h_all, c_all, gates).  `second` = (gx, bias, w_hh) of another layer of the same shape that
+    shares every launch: then a pair of result tuples is returned."""
     lib = capi.load()
     w_hh = _f32c(w_hh, "w_hh")
     H = w_hh.shape[1]
     dev = w_hh.device
-    fn = lib.s2vt_lstm_seq_fwd_x3_persist if x3 else lib.s2vt_lstm_seq_fwd_persist
     with torch.cuda.device(dev):
-        if x3:      # (0xFF bytes: bf16 NaN patterns - the kernel must never read a plane element it has not written)
-            n = lib.s2vt_lstm_seq_x3_workspace_bytes(T, B, H)
-            if n == 0:
-                raise capi.S2VTHipError("lstm_seq_fwd_persist(x3=True): shape B=%d H=%d is not supported on this device" % (B, H))
-            ws = torch.full((n,), 0xFF, dtype=torch.uint8, device=dev) if poison else torch.empty(n, dtype=torch.uint8, device=dev)
-        else:
-            ws, n = _persist_ws(dev)
+        # (0xFF bytes: bf16 NaN patterns - the kernel must never read a plane element it has not written)
+        n = lib.s2vt_lstm_seq_x3_workspace_bytes(T, B, H)
+        if n == 0:
+            raise capi.S2VTHipError("lstm_seq_fwd_persist: shape B=%d H=%d is not supported on this device" % (B, H))
+        ws = torch.full((n,), 0xFF, dtype=torch.uint8, device=dev) if poison else torch.empty(n, dtype=torch.uint8, device=dev)
         sets = []
         for g, b, w in [(gx, bias, w_hh)] + ([second] if second is not None else []):
             stash = torch.empty(T * B, 4 * H, dtype=torch.float32, device=dev)
@@ -347,43 +338,29 @@ def lstm_seq_fwd_persist(T, B, gx, n_gx, bias, w_hh, block=0, second=None, x3=Fa
             sets.append((stash, b, _f32c(w, "w_hh"), torch.empty(T * B, H, dtype=torch.float32, device=dev),
                          torch.empty(T * B, H, dtype=torch.float32, device=dev)))
         a, b2 = sets[0], (sets[1] if len(sets) > 1 else (None,) * 5)
-        capi.check(fn(T, B, H, _ptr(a[0]), _ptr(b2[0]), int(n_gx), _ptr(a[1]), _ptr(b2[1]), _ptr(a[2]),
-                      _ptr(b2[2]), _ptr(a[3]), _ptr(b2[3]), _ptr(a[4]), _ptr(b2[4]), int(block),
-                      _ptr(ws), n, _stream(dev)), "s2vt_lstm_seq_fwd_x3_persist" if x3 else "s2vt_lstm_seq_fwd_persist")
+        capi.check(lib.s2vt_lstm_seq_fwd_x3_persist(T, B, H, _ptr(a[0]), _ptr(b2[0]), int(n_gx), _ptr(a[1]), _ptr(b2[1]), _ptr(a[2]),
+                                                    _ptr(b2[2]), _ptr(a[3]), _ptr(b2[3]), _ptr(a[4]), _ptr(b2[4]), int(block),
+                                                    _ptr(ws), n, _stream(dev)), "s2vt_lstm_seq_fwd_x3_persist")
         _check_persist_err(ws)
     outs = [(x[3], x[4], x[0]) for x in sets]
     return outs[0] if second is None else tuple(outs)
 
 
-def lstm_seq_bwd_persist(T, B, w_hh, dh_out, dh_first, c_all, gates, block=0, second=None, x3=False):
-    """fp32 BPTT with the persistent kernel: returns dG (`gates` untouched).  `second` = (w_hh, dh_out, c_all, gates).
-    x3: the split-precision reduce-scatter kernel (lstm_persist_x3.hip) instead of the exact-fp32 MFMA one."""
+def lstm_seq_bwd_persist(T, B, w_hh, dh_out, dh_first, c_all, gates, block=0, second=None):
+    """fp32-equivalent BPTT with the persistent split-precision reduce-scatter kernel (lstm_persist_x3.hip): returns dG (`gates`
+    untouched).  `second` = (w_hh, dh_out, c_all, gates)."""
     lib = capi.load()
     w_hh = _f32c(w_hh, "w_hh")
     H = w_hh.shape[1]
     dev = w_hh.device
-    if x3:
-        with torch.cuda.device(dev):
-            n = lib.s2vt_lstm_seq_bwd_x3_workspace_bytes(T, B, H, int(block))
-            ws = torch.full((n,), 0xFF, dtype=torch.uint8, device=dev)     # (NaN patterns: nothing may be read before it is written)
-            sets = [(_f32c(w, "w_hh"), dh, _f32c(c, "c_all"), _f32c(g, "gates").clone())
-                    for w, dh, c, g in [(w_hh, dh_out, c_all, gates)] + ([second] if second is not None else [])]
-            a, b2 = sets[0], (sets[1] if len(sets) > 1 else (None,) * 4)
-            capi.check(lib.s2vt_lstm_seq_bwd_x3_persist(T, B, H, _ptr(a[0]), _ptr(b2[0]), _ptr(a[1]), _ptr(b2[1]), int(dh_first),
-                                                        _ptr(a[2]), _ptr(b2[2]), _ptr(a[3]), _ptr(b2[3]), int(block), _ptr(ws), n,
-                                                        _stream(dev)), "s2vt_lstm_seq_bwd_x3_persist")
-            _check_persist_err(ws)
-        return sets[0][3] if second is None else (sets[0][3], sets[1][3])
     with torch.cuda.device(dev):
-        ws, n = _persist_ws(dev)
-        sets = []
-        for w, dh, c, g in [(w_hh, dh_out, c_all, gates)] + ([second] if second is not None else []):
-            sets.append((_f32c(w, "w_hh"), dh, _f32c(c, "c_all"), _f32c(g, "gates").clone(),
-                         torch.empty(H, 4 * H, dtype=torch.float32, device=dev), torch.empty(B, H, dtype=torch.float32, device=dev)))
-        a, b2 = sets[0], (sets[1] if len(sets) > 1 else (None,) * 6)
-        capi.check(lib.s2vt_lstm_seq_bwd_persist(T, B, H, _ptr(a[0]), _ptr(b2[0]), _ptr(a[1]), _ptr(b2[1]), int(dh_first), _ptr(a[2]),
-                                                 _ptr(b2[2]), _ptr(a[3]), _ptr(b2[3]), _ptr(a[4]), _ptr(b2[4]), _ptr(a[5]), _ptr(b2[5]),
-                                                 int(block), _ptr(ws), n, _stream(dev)), "s2vt_lstm_seq_bwd_persist")
+        n = lib.s2vt_lstm_seq_bwd_x3_workspace_bytes(T, B, H, int(block))
+        ws = torch.full((n,), 0xFF, dtype=torch.uint8, device=dev)     # (NaN patterns: nothing may be read before it is written)
+        sets = [(_f32c(w, "w_hh"), dh, _f32c(c, "c_all"), _f32c(g, "gates").clone())
+                for w, dh, c, g in [(w_hh, dh_out, c_all, gates)] + ([second] if second is not None else [])]
+        a, b2 = sets[0], (sets[1] if len(sets) > 1 else (None,) * 4)
+        capi.check(lib.s2vt_lstm_seq_bwd_x3_persist(T, B, H, _ptr(a[0]), _ptr(b2[0]), _ptr(a[1]), _ptr(b2[1]), int(dh_first),
+                                                    _ptr(a[2]), _ptr(b2[2]), _ptr(a[3]), _ptr(b2[3]), int(block), _ptr(ws), n,
+                                                    _stream(dev)), "s2vt_lstm_seq_bwd_x3_persist")
         _check_persist_err(ws)
-    outs = [x[3] for x in sets]
-    return outs[0] if second is None else tuple(outs)
+    return sets[0][3] if second is None else (sets[0][3], sets[1][3])

@@ -26,7 +26,7 @@ def test_header_symbols_all_exported_and_bound(lib):
         assert hasattr(raw, name), "libs2vt_hip.so does not export %s" % name
         assert name in capi.SIGNATURES, "capi.py does not bind %s" % name
     assert sorted(capi.SIGNATURES) == declared
-    assert lib.s2vt_abi_version() == capi.ABI_VERSION == 8
+    assert lib.s2vt_abi_version() == capi.ABI_VERSION == 9
 
 
 def test_workspace_queries_and_argument_errors(lib):

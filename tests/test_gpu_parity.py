@@ -129,22 +129,45 @@ def test_c2_full_size_against_reference_golden(lib, golden, gemm_mode):
         lib.s2vt_set_gemm_mode(prev)
 
 
-@pytest.mark.parametrize("mode,plan", [(2, (3, 2)), (0, (0, 0))])
-def test_c2_train_in_the_other_recurrence_modes(lib, golden, mode, plan):
-    """The same config-2 train step in the non-default recurrence modes (the default, mode 1 = split-precision persistent
-    forward + launch-per-timestep BPTT, is test_c2_full_size_against_reference_golden): mode 2 adds the exact-fp32 persistent
-    BPTT of lstm_persist_f32.hip; mode 0 runs every recurrence as launches per timestep on two streams (round 2's default, still
-    the path of hidden sizes above 1024 and of a shared card)."""
+@pytest.mark.parametrize("option,value,plan", [("persist", 0, (0, 0)), ("persist_x3_fwd", 0, (0, None)), ("persist_x3_bwd", 0, (3, 0)),
+                                               ("persist_x3_bwd", 1, (3, 3)), ("pipe_block", 0, None), ("pipe_block", 20, None),
+                                               ("graph", 1, None), ("cu_reserve", 24, None), ("decode_fused", 0, None)])
+def test_c2_train_and_decode_under_every_option(lib, golden, option, value, plan):
+    """The config-2 fixture (greedy ids bit-exact, two Adam steps within 1e-4, every gradient) with ONE run-time option of the
+    library moved off / onto its default through s2vt_set_option - the whole switch table of csrc/options.hip except the
+    arithmetic mode (test_c2_full_size_against_reference_golden runs gemm modes 3 and 0, the c3 tests mode 1) and bptt_units (bf16
+    kernels: test_gpu_kernels.py): launches per timestep everywhere, the split-precision persistent kernels per direction, no layer
+    pipeline / another block length, hipGraph replay, grids planned for fewer compute units, the two-chain decode schedule."""
     from s2vt_video_caption_amd import capi
     g = golden("c2")
     d, sd, feats, caps, mask = _setup(g, "c2")
-    prev = lib.s2vt_set_recurrence_mode(mode)
+    prev = lib.s2vt_set_option(option.encode(), value)
+    assert prev != -(2 ** 31), "unknown option"
     try:
-        assert capi.recurrence_plan(d["B"], d["H"]) == plan
+        assert lib.s2vt_set_option(option.encode(), -1) == value
+        if plan is not None:
+            got = capi.recurrence_plan(d["B"], d["H"])
+            assert got[0] == plan[0] and (plan[1] is None or got[1] == plan[1]), (got, plan)
         _c2_body(g, d, sd, feats, caps, mask)
         capi.check_async_error()
     finally:
-        lib.s2vt_set_recurrence_mode(prev)
+        lib.s2vt_set_option(option.encode(), prev)
+
+
+def test_every_option_of_the_library_is_named_in_the_header_and_covered(lib):
+    """The option table (s2vt_option_count / s2vt_option_name) against include/s2vt_hip.h's list and this file's parametrisations:
+    a switch nobody documents or tests cannot be added."""
+    import os
+    import re
+    names = [lib.s2vt_option_name(i).decode() for i in range(lib.s2vt_option_count())]
+    assert len(set(names)) == len(names) and lib.s2vt_option_name(len(names)) is None
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "s2vt_hip.h")).read()
+    tests = "".join(open(os.path.join(root, "tests", f)).read() for f in os.listdir(os.path.join(root, "tests")) if f.endswith(".py"))
+    for n in names:
+        assert re.search(r"^ \*   %s\s" % re.escape(n), header, re.M), "option %s is not documented in include/s2vt_hip.h" % n
+        assert ('"%s"' % n) in tests or ("%s=" % n) in tests, "option %s has no test" % n
+    assert lib.s2vt_set_option(b"no_such_option", 1) == -(2 ** 31)
 
 
 def test_c4_shard_full_size_against_reference_golden(lib, golden):
@@ -1042,40 +1065,37 @@ def test_decode_cache_filled_under_one_mode_serves_every_other(lib, golden):
         functional.clear_decode_cache()
 
 
-_BPTT_CHILD = r"""
-import json, sys
-sys.path.insert(0, %r)
-import torch, S2VTModel, utils
-from s2vt_video_caption_amd import capi, synth
-d = synth.CONFIGS["c2"]
-sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=21)
-feats, caps, mask = (t.to("cuda:0") for t in synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=22))
-m = S2VTModel.S2VT(d["V"], d["F"], d["L"], dim_hid=d["H"], dim_embed=d["E"])
-m.load_state_dict(sd); m.to("cuda:0").train()
-loss = utils.MaskCriterion()(m(feats, targets=caps[:, :-1], mode="train"), caps, mask)
-loss.backward()
-torch.cuda.synchronize(); capi.check_async_error()
-print(json.dumps({"plan": capi.recurrence_plan(d["B"], d["H"]), "loss": float(loss.detach()),
-                  "norms": {k: float(p.grad.double().norm()) for k, p in m.named_parameters()},
-                  "heads": {k: p.grad.reshape(-1)[:8].cpu().tolist() for k, p in m.named_parameters()}}))
-"""
+def _c2_step_summary(lib):
+    from s2vt_video_caption_amd import capi
+    d = synth.CONFIGS["c2"]
+    sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=21)
+    feats, caps, mask = (t.to(DEV) for t in synth.make_batch(d["B"], d["L"], d["F"], d["V"], seed=22))
+    m = _model(d, sd).train()
+    loss = utils_mod().MaskCriterion()(m(feats, targets=caps[:, :-1], mode="train"), caps, mask)
+    loss.backward()
+    torch.cuda.synchronize()
+    capi.check_async_error()
+    return {"plan": list(capi.recurrence_plan(d["B"], d["H"])), "loss": float(loss.detach()),
+            "norms": {k: float(p.grad.double().norm()) for k, p in m.named_parameters()},
+            "heads": {k: p.grad.reshape(-1)[:8].cpu().tolist() for k, p in m.named_parameters()}}
 
 
-def test_opt_in_persistent_bptt_is_the_default_backward_within_fp32_rounding(lib):
-    """S2VT_PERSIST_X3_BWD=1 (the split-precision reduce-scatter BPTT, an opt-in: faster as a kernel, slower end to end) through
-    the whole config-2 train step in a child process (the switch is read once per process): same loss bits (the forward is
-    unchanged), every gradient within fp32 rounding of the default launch-per-timestep backward's."""
-    import json
-    import subprocess
-    import sys as _sys
-    import os
-    code = _BPTT_CHILD % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def utils_mod():
+    import utils
+    return utils
+
+
+def test_persistent_bptt_is_the_launch_per_timestep_backward_within_fp32_rounding(lib):
+    """Option persist_x3_bwd (the split-precision reduce-scatter BPTT) against the launch-per-timestep BPTT through the whole
+    config-2 train step: same loss bits (the forward is unchanged), every gradient within fp32 rounding."""
     outs = []
-    for flag in ("0", "1"):
-        env = dict(os.environ, S2VT_PERSIST_X3_BWD=flag)
-        r = subprocess.run([_sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
-        assert r.returncode == 0, r.stderr.decode()[-2000:]
-        outs.append(json.loads(r.stdout.decode().strip().splitlines()[-1]))
+    prev = lib.s2vt_set_option(b"persist_x3_bwd", -1)
+    try:
+        for flag in (0, 1):
+            lib.s2vt_set_option(b"persist_x3_bwd", flag)
+            outs.append(_c2_step_summary(lib))
+    finally:
+        lib.s2vt_set_option(b"persist_x3_bwd", prev)
     base, opt = outs
     assert base["plan"] == [3, 0] and opt["plan"] == [3, 3]
     assert base["loss"] == opt["loss"]

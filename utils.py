@@ -17,9 +17,12 @@ class MaskCriterion(nn.Module):
 
     def forward(self, logits, target, mask):
         # logits [N, seq_len-1, V]; target, mask [N, seq_len]
-        mean_ce = _F.mean_cross_entropy(logits, target)         # HIP kernels: CE against target[:, 1:], mean reduction
-        weights = mask[:, 1:].reshape(-1)                       # utils.py:23-24
-        return (mean_ce * weights).sum() / weights.sum()        # utils.py:24-25
+        if getattr(mask, "requires_grad", False):               # (never in the reference: the mask comes from the data loader)
+            mean_ce = _F.mean_cross_entropy(logits, target)
+            weights = mask[:, 1:].reshape(-1)                   # utils.py:23-24
+            return (mean_ce * weights).sum() / weights.sum()    # utils.py:24-25
+        # HIP kernels: CE against target[:, 1:], its mean, (mean * w).sum() / w.sum() with w = mask[:, 1:] - two launches
+        return _F.mask_criterion(logits, target, mask)
 
 
 class EarlyStopping:
