@@ -83,7 +83,7 @@ def beam_search(model, feats, params, beam_width=3, max_depth=30):
 
     def layer(gx, w_hh):
         if px:
-            return ops.lstm_seq_fwd_persist(L, B, gx, L, None, w_hh, x3=True, poison=False)
+            return ops.lstm_seq_fwd_persist(L, B, gx, L, None, w_hh, poison=False)
         return ops.lstm_seq_fwd(L, B, gx, L, None, w_hh)
     h1_all, c1_all, _ = layer(gx1, w_hh1)
     gx2 = _gemm_strided(h1_all, w_v, bsum2)

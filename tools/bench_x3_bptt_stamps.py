@@ -36,11 +36,11 @@ for B, pair in ((64, False), (64, True), (128, True)):
     if STAMPS:
         lib.s2vt_experiment_set_stamps(None, -1)
     for _ in range(2):
-        ops.lstm_seq_bwd_persist(T, B, w, dh, 0, c_all, gates, block=0, second=second, x3=True)
+        ops.lstm_seq_bwd_persist(T, B, w, dh, 0, c_all, gates, block=0, second=second)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    ops.lstm_seq_bwd_persist(T, B, w, dh, 0, c_all, gates, block=0, second=second, x3=True)
+    ops.lstm_seq_bwd_persist(T, B, w, dh, 0, c_all, gates, block=0, second=second)
     e1.record()
     torch.cuda.synchronize()
     print("B=%d %s: %.1f us per timestep (whole call incl. W^T transpose / split and allocations, T=%d)" % (B, "two layers" if pair else "one layer", e0.elapsed_time(e1) * 1e3 / T, T))
@@ -49,7 +49,7 @@ for B, pair in ((64, False), (64, True), (128, True)):
     for blockid in (0, 17, 62, 100):
         stamps = torch.zeros(4096 * 16, dtype=torch.int64, device=DEV)
         lib.s2vt_experiment_set_stamps(ctypes.c_void_p(stamps.data_ptr()), blockid)
-        ops.lstm_seq_bwd_persist(T, B, w, dh, 0, c_all, gates, block=0, second=second, x3=True)
+        ops.lstm_seq_bwd_persist(T, B, w, dh, 0, c_all, gates, block=0, second=second)
         torch.cuda.synchronize()
         s = stamps.cpu().numpy().reshape(4096, 16)
         ns = 2 if (B == 128 and pair) else 1
