@@ -72,6 +72,13 @@ const char* s2vt_last_error(void);
 
 /* ---------------------------------------------------------------- whole-path entry points */
 
+/* The batch size the whole-path drivers RUN at for a caller's batch B in the current arithmetic mode: in the plane modes (gemm mode
+ * 3 / 1) a batch that is not a multiple of 64 - the reference's defaults are 16 (train.py:27) and 10 (eval.py:27) - is padded
+ * to the next multiple inside the workspace (zero features, token 0; the pad rows' logits / ids are never handed out and their
+ * gradient contributions are exact zeros), so that every batch takes the plane GEMMs, the persistent recurrence kernels and the
+ * decode cache; gemm mode 0 (exact-fp32 MFMA, launches per timestep) runs any batch as it is. */
+int32_t s2vt_padded_batch(int32_t B);
+
 /* Bytes of workspace s2vt_train_forward/backward need (saved activations + scratch). */
 size_t s2vt_train_workspace_bytes(const s2vt_dims* d);
 

@@ -39,6 +39,7 @@ ABI_VERSION = 9          # S2VT_ABI_VERSION of include/s2vt_hip.h this binding w
 SIGNATURES = {
     "s2vt_abi_version": (c_int32, []),
     "s2vt_last_error": (c_char_p, []),
+    "s2vt_padded_batch": (c_int32, [c_int32]),
     "s2vt_train_workspace_bytes": (c_size_t, [POINTER(Dims)]),
     "s2vt_train_forward": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),

@@ -101,7 +101,7 @@ static int beam_step_impl(const s2vt_dims* d, const s2vt_params* p, int32_t R, c
     // with the embedding rows gathered inside the kernel's second K segment (:211-212)
     if ((rc = gather_rows_f32(st, word_h_in, H, row_state, R, H, w.ph))) return rc;
     if ((rc = gather_rows_f32(st, word_c_in, H, row_state, R, H, w.pc))) return rc;
-    if (cache && planes_ok(*d) && H <= 1024) {
+    if (cache && gemm_mode() != 0 && H <= 1024) {     // (any batch: the row counts of its GEMMs are free, the images are the cache's)
         // PLANE PATH (the weight-derived images of a greedy decode of the same weights, s2vt_greedy_decode_cached: W_v and W_o
         // as blocked 3-plane operands, the per-token gate table): the vid_out half of the gate input once per SAMPLE (every beam
         // slot reads its sample's row), the embedded word from the table, out_linear on the bf16 matrix cores in split
@@ -131,7 +131,7 @@ static int beam_step_impl(const s2vt_dims* d, const s2vt_params* p, int32_t R, c
         if ((rc = top20_logprob(st, w.logits, V, R, V, top_ix, top_lp))) return rc;
         return post_async_error(st, w.err, 3);       // (ring slot: no wait for the previous depth step)
     }
-    S2VT_REQUIRE(!gx_vid, "s2vt_beam_step_gx: the precomputed vid_rnn half needs the plane path (B % 64 == 0, H <= 1024)");
+    S2VT_REQUIRE(!gx_vid, "s2vt_beam_step_gx: the precomputed vid_rnn half needs the plane path (gemm mode 1 / 3, H <= 1024)");
     if ((rc = lgemm(ln, true, true, R, 4 * H, H, vid_h_out, H, gather(row_b), p->word_w_ih + E, E + H, ID, w.gx, 4 * H, ID,
                     w.bsum2, false)))
         return rc;

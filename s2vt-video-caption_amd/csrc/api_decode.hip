@@ -78,7 +78,7 @@ DecodeConst carve_decode_const(const s2vt_dims& d, void* base) {
     k.gtab = nullptr;
     k.xw1 = k.xw2 = nullptr;
     k.wf = k.wih1 = k.wv = k.wo = k.whh = PB{nullptr, 0, 0};
-    if (planes_ok(d)) {
+    if (gemm_mode() != 0) {     // (the images depend on the weights' dims only: one cache serves every batch size)
         XP = 3;
         auto mk = [&](size_t rows, size_t kk) {
             PB b;
@@ -100,8 +100,29 @@ DecodeConst carve_decode_const(const s2vt_dims& d, void* base) {
 }  // namespace s2vt
 extern "C" {
 
+// Batches that are not multiples of 64 (eval.py:27 decodes 10 clips at a time) are padded inside the workspace, like the train
+// drivers' (api_train.hip): zero features for the pad samples, whose ids / states are never handed out.
+static inline bool batch_padded(const s2vt_dims& d) { return gemm_mode() != 0 && d.B % 64 != 0; }
+static inline s2vt_dims padded_dims(const s2vt_dims& d) { s2vt_dims q = d; q.B = (d.B + 63) / 64 * 64; return q; }
+struct DecodePad { float* feats; int64_t* ids; float* states; float* gx_dec; size_t bytes; };
+static DecodePad carve_decode_pad(const s2vt_dims& d, const s2vt_dims& dp, void* base) {
+    const size_t Bp = dp.B, L = d.L, F = d.F, H = d.H;
+    Carver c{reinterpret_cast<char*>(base), 0, 0};
+    DecodePad w;
+    w.feats = c.take<float>(Bp * L * F);
+    w.ids = c.take<int64_t>(Bp * (L - 1));
+    w.states = c.take<float>(4 * Bp * H);                  // vid_h, vid_c, word_h, word_c of s2vt_decode_encode_cached
+    w.gx_dec = c.take<float>((L - 1) * Bp * 4 * H);
+    w.bytes = align_up(c.off, 256);
+    return w;
+}
+static size_t decode_core_bytes(const s2vt_dims& d) { return align_up(carve_decode(d, nullptr).bytes + carve_decode_const(d, nullptr).bytes, 256); }
 size_t s2vt_decode_workspace_bytes(const s2vt_dims* d) {
     if (!dims_ok(d)) return 0;
+    if (batch_padded(*d)) {
+        const s2vt_dims dp = padded_dims(*d);
+        return decode_core_bytes(dp) + carve_decode_pad(*d, dp, nullptr).bytes;
+    }
     return carve_decode(*d, nullptr).bytes + carve_decode_const(*d, nullptr).bytes;
 }
 size_t s2vt_decode_cache_bytes(const s2vt_dims* d) {
@@ -140,7 +161,40 @@ int s2vt_decode_encode_cached(const s2vt_dims* d, const s2vt_params* p, const fl
     const EncodeOut enc{vid_h, vid_c, word_h, word_c, gx_dec, gx_dec ? depth : 0};
     return greedy_decode_impl(d, p, feats, 0, nullptr, workspace, workspace_bytes, cache, cache_bytes, cache_valid != 0, stream, &enc);
 }
+static int greedy_decode_core(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
+                              void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, bool cache_valid,
+                              void* stream, const EncodeOut* enc);
 static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
+                              void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, bool cache_valid,
+                              void* stream, const EncodeOut* enc) {
+    S2VT_REQUIRE(dims_ok(d) && p && feats && (ids || enc) && workspace, "s2vt_greedy_decode: null/invalid argument");
+    if (!batch_padded(*d))
+        return greedy_decode_core(d, p, feats, sos_ix, ids, workspace, workspace_bytes, cache, cache_bytes, cache_valid, stream, enc);
+    const s2vt_dims dp = padded_dims(*d);
+    const size_t core = decode_core_bytes(dp);
+    const DecodePad s = carve_decode_pad(*d, dp, reinterpret_cast<char*>(workspace) + core);
+    S2VT_REQUIRE(workspace_bytes >= core + s.bytes, "s2vt_greedy_decode: workspace %zu < %zu bytes", workspace_bytes, core + s.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t B = d->B, Bp = dp.B, L = d->L, F = d->F, H = d->H;
+    int rc;
+    S2VT_HIP(hipMemcpyAsync(s.feats, feats, B * L * F * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if ((rc = fill_zero(st, s.feats + B * L * F, (Bp - B) * L * F * sizeof(float)))) return rc;
+    if (!enc) {
+        if ((rc = greedy_decode_core(&dp, p, s.feats, sos_ix, s.ids, workspace, core, cache, cache_bytes, cache_valid, stream, nullptr))) return rc;
+        S2VT_HIP(hipMemcpyAsync(ids, s.ids, B * (L - 1) * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+        return 0;
+    }
+    const EncodeOut pe{s.states, s.states + Bp * H, s.states + 2 * Bp * H, s.states + 3 * Bp * H, enc->depth > 0 ? s.gx_dec : nullptr, enc->depth};
+    if ((rc = greedy_decode_core(&dp, p, s.feats, sos_ix, nullptr, workspace, core, cache, cache_bytes, cache_valid, stream, &pe))) return rc;
+    float* outs[4] = {enc->vid_h, enc->vid_c, enc->word_h, enc->word_c};
+    for (int k = 0; k < 4; ++k)
+        S2VT_HIP(hipMemcpyAsync(outs[k], s.states + (size_t)k * Bp * H, B * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (enc->depth > 0)      // [depth][Bp][4H] -> [depth][B][4H]
+        S2VT_HIP(hipMemcpy2DAsync(enc->gx_dec, B * 4 * H * sizeof(float), s.gx_dec, Bp * 4 * H * sizeof(float), B * 4 * H * sizeof(float),
+                                  (size_t)enc->depth, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+static int greedy_decode_core(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
                               void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, bool cache_valid,
                               void* stream, const EncodeOut* enc) {
     S2VT_REQUIRE(dims_ok(d) && p && feats && (ids || enc) && workspace, "s2vt_greedy_decode: null/invalid argument");

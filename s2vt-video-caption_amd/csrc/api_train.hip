@@ -514,8 +514,47 @@ using namespace s2vt;
 
 extern "C" {
 
+// ------------------------------------------------------------------ batches that are not multiples of 64
+// The plane drivers (split-precision / bf16 GEMMs on blocked row images, the persistent recurrence kernels, transposed-read
+// weight-gradient GEMMs whose k index is time * B + b) need B % 64 == 0.  Any other batch - the reference's own defaults are
+// batch_size = 16 (train.py:27) and 10 (eval.py:27) - is PADDED to the next multiple of 64 inside the workspace instead of
+// being sent to the launch-per-timestep fp32-MFMA driver: the pad samples see zero features and token 0, their logits are
+// never handed out, and their dlogits rows are zero, so every gradient they contribute is an exact zero (dG = 0 for a row
+// whose dh and dc are 0) - the sums the real rows form are unchanged up to the order of fp32 additions.  Staging copies:
+// features, targets, logits / dlogits, the dropout mask (a few tens of MB at these batch sizes).
+static inline bool batch_padded(const s2vt_dims& d) { return gemm_mode() != 0 && d.B % 64 != 0; }
+static inline s2vt_dims padded_dims(const s2vt_dims& d) { s2vt_dims q = d; q.B = (d.B + 63) / 64 * 64; return q; }
+struct PadWS { float* feats; int64_t* targets; float* logits; float* mask; float* dfeats; size_t bytes; };
+static PadWS carve_pad(const s2vt_dims& d, const s2vt_dims& dp, void* base) {
+    const size_t Bp = dp.B, L = d.L, F = d.F, H = d.H, V = d.V;
+    Carver c{reinterpret_cast<char*>(base), 0, 0};
+    PadWS w;
+    w.feats = c.take<float>(Bp * L * F);
+    w.targets = c.take<int64_t>(Bp * (L - 1));
+    w.logits = c.take<float>(Bp * (L - 1) * V);          // logits of the forward, dlogits of the backward
+    w.mask = c.take<float>((L - 1) * Bp * H);            // out_drop mask, time-major (dropout entry points only)
+    w.dfeats = c.take<float>(Bp * L * F);
+    w.bytes = align_up(c.off, 256);
+    return w;
+}
+static size_t train_core_bytes(const s2vt_dims& d);
+
+int32_t s2vt_padded_batch(int32_t B) {
+    if (B <= 0) return 0;
+    s2vt_dims d = {B, 2, 1, 1, 1, 1};
+    return batch_padded(d) ? padded_dims(d).B : B;
+}
+
 size_t s2vt_train_workspace_bytes(const s2vt_dims* d) {
     if (!dims_ok(d)) return 0;
+    if (batch_padded(*d)) {
+        const s2vt_dims dp = padded_dims(*d);
+        return align_up(train_core_bytes(dp), 256) + carve_pad(*d, dp, nullptr).bytes;
+    }
+    return train_core_bytes(*d);
+}
+static size_t train_core_bytes(const s2vt_dims& dd) {
+    const s2vt_dims* d = &dd;
     size_t n = carve_train(*d, nullptr).bytes;
     if (planes_ok(*d)) {
         const int keep = XP;                       // a size query must not change the state of a running path
@@ -526,10 +565,40 @@ size_t s2vt_train_workspace_bytes(const s2vt_dims* d) {
     return n;
 }
 
+static int train_forward_core(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
+                              int64_t targets_ld, float* logits, void* workspace, size_t workspace_bytes, void* stream,
+                              const float* out_mask);
 static int train_forward_impl(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
                               int64_t targets_ld, float* logits, void* workspace, size_t workspace_bytes, void* stream,
                               const float* out_mask) {
     S2VT_REQUIRE(dims_ok(d) && p && feats && targets && logits && workspace, "s2vt_train_forward: null/invalid argument");
+    if (!batch_padded(*d)) return train_forward_core(d, p, feats, targets, targets_ld, logits, workspace, workspace_bytes, stream, out_mask);
+    // padded batch: stage [features | zeros], [targets | token 0], run the plane drivers at the padded size, hand out the real rows
+    const s2vt_dims dp = padded_dims(*d);
+    const size_t core = align_up(train_core_bytes(dp), 256);
+    const PadWS s = carve_pad(*d, dp, reinterpret_cast<char*>(workspace) + core);
+    S2VT_REQUIRE(workspace_bytes >= core + s.bytes, "s2vt_train_forward: workspace %zu < %zu bytes", workspace_bytes, core + s.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t B = d->B, Bp = dp.B, L = d->L, F = d->F, H = d->H, V = d->V;
+    int rc;
+    S2VT_HIP(hipMemcpyAsync(s.feats, feats, B * L * F * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if ((rc = fill_zero(st, s.feats + B * L * F, (Bp - B) * L * F * sizeof(float)))) return rc;
+    if ((rc = fill_zero(st, s.targets, Bp * (L - 1) * sizeof(int64_t)))) return rc;
+    S2VT_HIP(hipMemcpy2DAsync(s.targets, (L - 1) * sizeof(int64_t), targets, (size_t)targets_ld * sizeof(int64_t), (L - 1) * sizeof(int64_t), B,
+                              hipMemcpyDeviceToDevice, st));
+    if (out_mask) {      // time-major rows t * B + b -> t * Bp + b; the pad rows' mask is zero
+        if ((rc = fill_zero(st, s.mask, (L - 1) * Bp * H * sizeof(float)))) return rc;
+        S2VT_HIP(hipMemcpy2DAsync(s.mask, Bp * H * sizeof(float), out_mask, B * H * sizeof(float), B * H * sizeof(float), L - 1,
+                                  hipMemcpyDeviceToDevice, st));
+    }
+    if ((rc = train_forward_core(&dp, p, s.feats, s.targets, (int64_t)(L - 1), s.logits, workspace, core, stream, out_mask ? s.mask : nullptr)))
+        return rc;
+    S2VT_HIP(hipMemcpyAsync(logits, s.logits, B * (L - 1) * V * sizeof(float), hipMemcpyDeviceToDevice, st));      // batch-major: the first B rows
+    return 0;
+}
+static int train_forward_core(const s2vt_dims* d, const s2vt_params* p, const float* feats, const int64_t* targets,
+                              int64_t targets_ld, float* logits, void* workspace, size_t workspace_bytes, void* stream,
+                              const float* out_mask) {
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_forward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;
@@ -616,10 +685,33 @@ int s2vt_train_forward_dropout(const s2vt_dims* d, const s2vt_params* p, const f
     return train_forward_impl(d, p, feats, targets, targets_ld, logits, workspace, workspace_bytes, stream, out_mask);
 }
 
+static int train_backward_core(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
+                               const s2vt_grads* g, float* dfeats, void* workspace, size_t workspace_bytes, void* stream,
+                               const float* out_mask);
 static int train_backward_impl(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
                                const s2vt_grads* g, float* dfeats, void* workspace, size_t workspace_bytes, void* stream,
                                const float* out_mask) {
     S2VT_REQUIRE(dims_ok(d) && p && feats && g && workspace, "s2vt_train_backward: null/invalid argument");
+    if (!batch_padded(*d)) return train_backward_core(d, p, feats, dlogits, g, dfeats, workspace, workspace_bytes, stream, out_mask);
+    // padded batch (see batch_padded): dlogits rows of the pad samples are zero, the staged features / mask are the forward's
+    S2VT_REQUIRE(dlogits, "s2vt_train_backward: dlogits is null (the fused criterion backward needs a batch that is a multiple of 64)");
+    const s2vt_dims dp = padded_dims(*d);
+    const size_t core = align_up(train_core_bytes(dp), 256);
+    const PadWS s = carve_pad(*d, dp, reinterpret_cast<char*>(workspace) + core);
+    S2VT_REQUIRE(workspace_bytes >= core + s.bytes, "s2vt_train_backward: workspace %zu < %zu bytes", workspace_bytes, core + s.bytes);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t B = d->B, Bp = dp.B, L = d->L, F = d->F, V = d->V;
+    int rc;
+    S2VT_HIP(hipMemcpyAsync(s.logits, dlogits, B * (L - 1) * V * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if ((rc = fill_zero(st, s.logits + B * (L - 1) * V, (Bp - B) * (L - 1) * V * sizeof(float)))) return rc;
+    if ((rc = train_backward_core(&dp, p, s.feats, s.logits, g, dfeats ? s.dfeats : nullptr, workspace, core, stream, out_mask ? s.mask : nullptr)))
+        return rc;
+    if (dfeats) S2VT_HIP(hipMemcpyAsync(dfeats, s.dfeats, B * L * F * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+static int train_backward_core(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
+                               const s2vt_grads* g, float* dfeats, void* workspace, size_t workspace_bytes, void* stream,
+                               const float* out_mask) {
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;

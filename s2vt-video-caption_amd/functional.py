@@ -187,9 +187,9 @@ def clear_decode_cache(model=None):
 
 def decode_cache_entry(owner, raw_params, d, dev, lib):
     """(cache tensor, valid) of `owner`'s weight-derived decode images for the parameters as they stand, or (None, False) where
-    the cache does not apply (no owner, DECODE_CACHE off, a batch that is not a multiple of 64, fp32-MFMA mode).  valid = False:
+    the cache does not apply (no owner, DECODE_CACHE off, fp32-MFMA mode; any batch size - the library pads to a multiple of 64).  valid = False:
     the tensor is fresh and the next s2vt_greedy_decode_cached call must fill it (cache_valid = 0)."""
-    if owner is None or not DECODE_CACHE or d.B % 64 != 0 or lib.s2vt_set_gemm_mode(-1) == 0:
+    if owner is None or not DECODE_CACHE or lib.s2vt_set_gemm_mode(-1) == 0:
         return None, False
     # (the batch size, the recurrence mode and the pipeline block are NOT in the key: a filling call writes every
     # image the cache holds, whichever of them its own batch / modes read - s2vt_greedy_decode_cached)
@@ -248,8 +248,8 @@ def decode_encode(feats, params, owner, depth=0):
     params = tuple(_f32c(p.detach(), "parameter") for p in params)
     d = _dims(feats, params)
     dev = feats.device
-    if lib.s2vt_lstm_seq_x3_workspace_bytes(d.L, d.B, d.H) == 0 or lib.s2vt_set_recurrence_mode(-1) == 0:
-        return None
+    if lib.s2vt_lstm_seq_x3_workspace_bytes(d.L, (d.B + 63) // 64 * 64, d.H) == 0 or lib.s2vt_set_recurrence_mode(-1) == 0:
+        return None                                  # (the library pads the batch to a multiple of 64 itself)
     with torch.cuda.device(dev):
         cache, valid = decode_cache_entry(owner, raw, d, dev, lib)
         if cache is None:

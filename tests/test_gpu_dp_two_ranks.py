@@ -48,6 +48,10 @@ def _worker(rank, world, port, out_dir, cfg, B):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     m, crit, feats, caps, mask = _setup(cfg, B, rank, world)
     from s2vt_video_caption_amd import capi, dp
+    # TWO processes share this card: a persistent recurrence launch needs every one of its workgroups resident, and two such
+    # launches of two processes would each hold part of the compute units and wait for the rest (bounded: S2VT_ERR_TIMEOUT) -
+    # the documented setting for a shared card is launches per timestep (one process per GPU is the product)
+    capi.load().s2vt_set_option(b"persist", 0)
     opt = torch.optim.Adam(m.parameters(), lr=1e-4)
     red = dp.FlatGradAllReducer(m.parameters()).attach(m)
     assert red.world == 2 and red.comm_stream is not None

@@ -287,6 +287,57 @@ def test_against_oracle_on_fresh_seeds(lib):
             assert torch.equal(ids, oids)
 
 
+@pytest.mark.parametrize("B", [16, 10, 100])
+def test_reference_default_sizes_take_the_plane_path_and_match_the_oracle(lib, B):
+    """The reference's own defaults - batch_size = 16, dim_hidden = dim_embed = 512 (train.py:27-28,37), eval batch 10 (eval.py:27) -
+    and a ragged batch above 64 at L = 80, F = 4096: the library pads the batch to a multiple of 64 inside its workspace
+    (s2vt_padded_batch) so that these sizes run the plane GEMMs, the persistent recurrence and the decode cache instead of the
+    launch-per-timestep fp32-MFMA driver.  Train step (logits, loss, all 13 gradients and dfeats), greedy ids and beam captions
+    against the oracle; the pad rows must not leak into anything (bias sums, embedding gradient, CE mean)."""
+    import S2VTModel, utils
+    from s2vt_video_caption_amd import beam, functional
+    L, Fd, H, E, V = 80, 4096, 512, 512, 3000
+    assert lib.s2vt_padded_batch(B) == (B + 63) // 64 * 64 and lib.s2vt_set_gemm_mode(-1) == 3
+    sd = synth.make_state_dict(V, Fd, H, E, seed=40 + B)
+    feats, caps, mask = synth.make_batch(B, L, Fd, V, seed=41 + B)
+    m = S2VTModel.S2VT(V, Fd, L, dim_hid=H, dim_embed=E)
+    m.load_state_dict(sd)
+    m.to(DEV)
+    f = feats.to(DEV).requires_grad_()
+    logits = m(f, targets=caps[:, :-1].to(DEV), mode="train")
+    loss = utils.MaskCriterion()(logits, caps.to(DEV), mask.to(DEV))
+    loss.backward()
+    om = orc.OracleModel(sd)
+    fo = feats.clone().requires_grad_()
+    ologits = om(fo, caps[:, :-1])
+    oloss = orc.mask_criterion(ologits, caps, mask)
+    oloss.backward()
+    assert (logits.detach().cpu() - ologits.detach()).abs().max().item() < 2e-5
+    assert abs(float(loss) - float(oloss)) < 1e-5
+    for (n, p), (k, q) in zip(m.named_parameters(), om.as_dict().items()):
+        assert n == k
+        assert (p.grad.cpu() - q.grad).abs().max().item() <= 1e-6 + 1e-4 * q.grad.abs().max().item(), (n, B)
+    assert (f.grad.cpu() - fo.grad).abs().max().item() <= 1e-6 + 1e-4 * fo.grad.abs().max().item()
+    m.eval()
+    with torch.no_grad():
+        ids = m(feats.to(DEV), mode="test").cpu()
+        assert m in functional._DECODE_CACHES and functional._DECODE_CACHES[m][2]      # the decode cache serves ragged batches too
+        again = m(feats.to(DEV), mode="test").cpu()
+    assert torch.equal(ids, again)
+    oids, marg = orc.greedy_decode(sd, feats, return_margins=True)
+    rows = (marg.reshape(B, -1).min(dim=1).values >= 1e-4).nonzero().flatten()       # (random-init weights: many rows rest on near-ties)
+    assert len(rows) >= B // 4
+    assert torch.equal(ids[rows], oids[rows])
+    if B <= 16:
+        with torch.no_grad():
+            caps_dev = [[int(t) for t in s] for s in m(feats.to(DEV), mode="beam_search", beam_width=3, max_beam_depth=8)]
+        assert "precomputed" in beam.LAST_PATH, beam.LAST_PATH           # the library's encode phase + plane-path depth step
+        nb = min(B, 6)            # (the oracle's search is a Python loop per sample)
+        ocaps, gaps = orc.beam_search(sd, feats[:nb], beam_width=3, max_depth=8, return_gap="per_sample")
+        for b in range(nb):
+            assert gaps[b] < 1e-5 or caps_dev[b] == [int(t) for t in ocaps[b]], b
+
+
 def test_full_size_properties_c2_shape(lib):
     """Size-independent properties at BASELINE full size (no oracle needed):
     batch independence (a sample's logits/ids do not depend on its batch mates, bitwise), determinism,
@@ -717,12 +768,13 @@ def test_out_of_range_loss_target_raises_index_error(lib):
     assert torch.isfinite(loss)
 
 
-@pytest.mark.parametrize("B,gemm_mode", [(5, 3), (64, 3), (64, 1)])
+@pytest.mark.parametrize("B,gemm_mode", [(5, 0), (5, 3), (64, 3), (64, 1)])
 def test_out_dropout_train_mode_matches_oracle_with_the_same_mask(lib, B, gemm_mode):
     """out_dropout > 0 (S2VTModel.py:25,79): the decode-step hidden states are masked between word_rnn and out_linear.  With
-    the SAME keep mask the oracle must give the same logits and the same 13 gradients (fp32 paths: B=5 takes the fp32-MFMA
-    driver, B=64 the split-precision plane driver; gemm mode 1 = bf16 operands at bf16 bounds); at model level the mask
-    is drawn like the reference draws it, eval mode ignores it."""
+    the SAME keep mask the oracle must give the same logits and the same 13 gradients (fp32 paths: gemm mode 0 = the fp32-MFMA
+    driver, mode 3 the split-precision plane driver - B=5 padded to 64 inside the workspace, its mask staged time-major at the
+    padded stride; gemm mode 1 = bf16 operands at bf16 bounds); at model level the mask is drawn like the reference draws it,
+    eval mode ignores it."""
     import S2VTModel, utils
     from s2vt_video_caption_amd import functional as F
     L, Fd, H, E, V = 6, 48, 64, 40, 90
