@@ -626,6 +626,77 @@ def main():
             finally:
                 lib.s2vt_set_gemm_mode(prev_mode)
             log("config3: %s" % config3)
+        # ---- the reference's OWN defaults (train.py:27-28,37: batch_size = 16, dim_hidden = dim_embed = 512; eval.py:27: batch 10):
+        # batches that are not multiples of 64 are padded to 64 inside the library's workspace (s2vt_padded_batch) so that they run
+        # the plane GEMMs, the persistent recurrence and the decode cache; the same step with gemm mode 0 (exact-fp32 MFMA, launches
+        # per timestep - where these sizes ran before round 5) and the reference's CPU path stand beside it
+        ref_defaults = None
+        if world == 1 and not bf and not args.headline_only:
+            Hd, Bt, Be = 512, 16, 10
+            sd_d = synth.make_state_dict(V, F, Hd, Hd, seed=5)
+            md = S2VTModel.S2VT(V, F, L, dim_hid=Hd, dim_embed=Hd)
+            md.load_state_dict(sd_d)
+            md.to(dev)
+            optd = torch.optim.Adam(md.parameters(), lr=1e-4, fused=True)
+            bd_ = tuple(t.to(dev) for t in synth.make_batch(Bt, L, F, V, seed=778))
+            fe = synth.make_batch(Be, L, F, V, seed=779)[0].to(dev)
+
+            def timed(fn, n):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize(dev)
+                t_ = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize(dev)
+                capi.check_async_error()
+                return (time.perf_counter() - t_) / n
+            step_d = lambda: dp.train_step(md, crit, optd, bd_[0], bd_[1], bd_[2], None)
+
+            def dec_d():
+                with torch.no_grad():
+                    md(fe, mode="test")
+            t_plane = timed(step_d, 30)
+            md.eval(); d_plane = timed(dec_d, 10); md.train()
+            prev_mode = lib.s2vt_set_gemm_mode(0)
+            try:
+                t_f32 = timed(step_d, 10)
+                md.eval(); d_f32 = timed(dec_d, 5); md.train()
+            finally:
+                lib.s2vt_set_gemm_mode(prev_mode)
+            cpu_d = None
+            if not args.no_cpu_baseline:
+                from oracle import s2vt_oracle as orc
+                torch.set_num_threads(usable_cores())
+                cmd_ = orc.ReferenceShapedCPUModel(sd_d)
+                coptd = torch.optim.Adam(cmd_.parameters(), lr=1e-4)
+                cfd, ccd, ckd = (t.cpu() for t in bd_)
+
+                def cpu_step_d():
+                    coptd.zero_grad()
+                    orc.mask_criterion(cmd_(cfd, ccd[:, :-1]), ccd, ckd).backward()
+                    coptd.step()
+                cpu_step_d()
+                t_ = time.perf_counter()
+                for _ in range(3):
+                    cpu_step_d()
+                cdt_d = (time.perf_counter() - t_) / 3
+                t_ = time.perf_counter()
+                cmd_.greedy(fe.cpu())
+                gdt_d = time.perf_counter() - t_
+                cpu_d = {"value": round(Bt * L / cdt_d, 1), "unit": "frames/s", "cores": usable_cores(), "kind": "port",
+                         "ms_per_step": round(cdt_d * 1e3, 1), "greedy_captions_per_s": round(Be / gdt_d, 2),
+                         "sample": "B=16 train steps (1 warm-up + 3 timed) and one B=10 greedy decode with torch-CPU nn.LSTM / nn.Linear"}
+            ref_defaults = {"workload": "the reference's defaults: train B=16, hidden=embed=512 (train.py:27-28,37), greedy decode B=10 "
+                                        "(eval.py:27); 80x4096 feats, vocab=12000, fp32-equivalent, Adam",
+                            "runs_at_batch": int(lib.s2vt_padded_batch(Bt)),
+                            "train": {"value": round(Bt * L / t_plane, 1), "unit": "frames/s", "ms_per_step": round(t_plane * 1e3, 3),
+                                      "ms_per_step_gemm_mode_0_unpadded": round(t_f32 * 1e3, 3)},
+                            "decode": {"value": round(Be / d_plane, 1), "unit": "captions/s", "ms_per_call": round(d_plane * 1e3, 3),
+                                       "ms_per_call_gemm_mode_0_unpadded": round(d_f32 * 1e3, 3)},
+                            "cpu_baseline": cpu_d}
+            del md, optd, bd_, fe
+            log("ref_defaults: %s" % ref_defaults)
         log("decode: %s" % decode)
         cpu = None
         if world == 1 and not args.no_cpu_baseline and not args.headline_only:
@@ -699,6 +770,7 @@ def main():
             "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if use_pg else None,
             "dp_b128": shard128,
             "config3": config3,
+            "ref_defaults": ref_defaults,
         }
         print(json.dumps(out), flush=True)
     if use_pg:

@@ -73,10 +73,12 @@ const char* s2vt_last_error(void);
 /* ---------------------------------------------------------------- whole-path entry points */
 
 /* The batch size the whole-path drivers RUN at for a caller's batch B in the current arithmetic mode: in the plane modes (gemm mode
- * 3 / 1) a batch that is not a multiple of 64 - the reference's defaults are 16 (train.py:27) and 10 (eval.py:27) - is padded
- * to the next multiple inside the workspace (zero features, token 0; the pad rows' logits / ids are never handed out and their
- * gradient contributions are exact zeros), so that every batch takes the plane GEMMs, the persistent recurrence kernels and the
- * decode cache; gemm mode 0 (exact-fp32 MFMA, launches per timestep) runs any batch as it is. */
+ * 3 / 1) a batch that is not a multiple of 64 and has at least `pad_min_batch` rows (option, default 33) is padded to the next
+ * multiple inside the workspace (zero features, token 0; the pad rows' logits / ids are never handed out and their gradient
+ * contributions are exact zeros), so that it takes the plane GEMMs, the persistent recurrence kernels and the decode cache.
+ * Smaller batches - the reference's own defaults are 16 (train.py:27) and 10 (eval.py:27) - and gemm mode 0 run as they are on
+ * the launch-per-timestep path (exact-fp32 MFMA tiles, gate GEMVs up to B = 4), which is FASTER at those sizes than 64 padded
+ * rows (measured: profiles/round5_ragged_batches.txt). */
 int32_t s2vt_padded_batch(int32_t B);
 
 /* Bytes of workspace s2vt_train_forward/backward need (saved activations + scratch). */
@@ -174,6 +176,10 @@ int s2vt_greedy_decode(const s2vt_dims* d, const s2vt_params* p, const float* fe
  * B = 128.  Calls that share a cache must be ordered by the stream.  The per-call workspace is s2vt_decode_workspace_bytes as
  * for s2vt_greedy_decode (whose weight images live behind the per-call part of that workspace and are rebuilt every call). */
 size_t s2vt_decode_cache_bytes(const s2vt_dims* d);
+/* 1 if s2vt_greedy_decode_cached reads (and, with cache_valid == 0, fills) the cache for this batch size in the current mode;
+ * 0 for the batches that decode on the launch-per-timestep path (gemm mode 0, or fewer than 24 clips: measured faster there than
+ * 64 padded rows on the plane path) - the caller must then not mark its cache as filled. */
+int32_t s2vt_decode_uses_cache(const s2vt_dims* d);
 int s2vt_greedy_decode_cached(const s2vt_dims* d, const s2vt_params* p, const float* feats, int32_t sos_ix, int64_t* ids,
                               void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, int32_t cache_valid,
                               void* stream);
@@ -382,6 +388,13 @@ int s2vt_decode_step_argmax_x3(int32_t B, int32_t H, int32_t V, const float* h, 
  *   cu_reserve      0..128      the persistent GEMMs plan their grids for this many compute units fewer (data-parallel runs
  *                               whose communication kernels hold compute units beside the backward's GEMMs)
  *   bptt_units      0 | 16 | 32 hidden units per workgroup of the persistent bf16 BPTT (0: 32 where two layers fit the device)
+ *   pad_min_batch   33 (1..64)  ragged batches (B % 64 != 0) of at least this many rows - a greedy decode: three quarters of it - are
+ *                               padded to a multiple of 64 inside the workspace (s2vt_padded_batch); smaller ones run as they
+ *                               are, launches per timestep (faster there: profiles/round5_ragged_batches.txt)
+ *   gemv            1 | 2 | 0   the launch-per-timestep forward step (s2vt_lstm_step_fwd and the drivers built on it) as gate
+ *                               GEMVs - h staged in LDS, weight rows streamed to registers, wavefront shuffle reductions
+ *                               (csrc/lstm_gemv.hip) - instead of the 16-row fp32-MFMA tile kernel: 1 = at B <= 4 (where it
+ *                               measured faster), 2 = at every B <= 8, 0 = never
  * Do not change gemm_mode / persist / pipe_block between a forward and its backward (the backward refuses). */
 int32_t s2vt_set_option(const char* name, int32_t value);
 int32_t s2vt_option_count(void);

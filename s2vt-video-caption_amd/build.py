@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libs2vt_hip.so")
-SOURCES = ["api_runtime.hip", "api_shared.hip", "api_train.hip", "api_decode.hip", "api_beam.hip", "api_ops.hip", "options.hip", "gemm.hip", "gemm_bf16.hip", "gemm_x3.hip", "gemm_b1.hip", "split.hip", "lstm.hip", "lstm_bf16.hip", "lstm_persist.hip", "lstm_persist_x3.hip", "argmax_x3.hip", "ce.hip", "misc.hip", "beam_queue.hip"]
+SOURCES = ["api_runtime.hip", "api_shared.hip", "api_train.hip", "api_decode.hip", "api_beam.hip", "api_ops.hip", "options.hip", "gemm.hip", "gemm_bf16.hip", "gemm_x3.hip", "gemm_b1.hip", "split.hip", "lstm.hip", "lstm_gemv.hip", "lstm_bf16.hip", "lstm_persist.hip", "lstm_persist_x3.hip", "argmax_x3.hip", "ce.hip", "misc.hip", "beam_queue.hip"]
 HEADERS = ["common.h", "kernels.h", "experiment.h", "api_internal.h", os.path.join("..", "..", "include", "s2vt_hip.h")]
 
 

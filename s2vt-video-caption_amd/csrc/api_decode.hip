@@ -100,9 +100,13 @@ DecodeConst carve_decode_const(const s2vt_dims& d, void* base) {
 }  // namespace s2vt
 extern "C" {
 
-// Batches that are not multiples of 64 (eval.py:27 decodes 10 clips at a time) are padded inside the workspace, like the train
-// drivers' (api_train.hip): zero features for the pad samples, whose ids / states are never handed out.
-static inline bool batch_padded(const s2vt_dims& d) { return gemm_mode() != 0 && d.B % 64 != 0; }
+// Batches that are not multiples of 64 are padded inside the workspace, like the train drivers' (api_train.hip): zero features for
+// the pad samples, whose ids / states are never handed out.  A plain greedy decode of fewer than 24 clips (eval.py:27 decodes 10 at
+// a time) is the exception (batch_pads): there the launch-per-timestep path - 16-row fp32-MFMA tiles, gate GEMVs up to B = 4 - is
+// faster than 64 padded rows on the plane path; the encode phase for the beam search always takes the plane path.
+static inline bool batch_padded(const s2vt_dims& d, bool encode_only = false) {
+    return encode_only ? (gemm_mode() != 0 && d.B % 64 != 0) : batch_pads(d.B, true);
+}
 static inline s2vt_dims padded_dims(const s2vt_dims& d) { s2vt_dims q = d; q.B = (d.B + 63) / 64 * 64; return q; }
 struct DecodePad { float* feats; int64_t* ids; float* states; float* gx_dec; size_t bytes; };
 static DecodePad carve_decode_pad(const s2vt_dims& d, const s2vt_dims& dp, void* base) {
@@ -119,7 +123,7 @@ static DecodePad carve_decode_pad(const s2vt_dims& d, const s2vt_dims& dp, void*
 static size_t decode_core_bytes(const s2vt_dims& d) { return align_up(carve_decode(d, nullptr).bytes + carve_decode_const(d, nullptr).bytes, 256); }
 size_t s2vt_decode_workspace_bytes(const s2vt_dims* d) {
     if (!dims_ok(d)) return 0;
-    if (batch_padded(*d)) {
+    if (batch_padded(*d, true)) {       // (sized for either use of the workspace: s2vt_decode_encode_cached pads every ragged batch)
         const s2vt_dims dp = padded_dims(*d);
         return decode_core_bytes(dp) + carve_decode_pad(*d, dp, nullptr).bytes;
     }
@@ -128,6 +132,10 @@ size_t s2vt_decode_workspace_bytes(const s2vt_dims* d) {
 size_t s2vt_decode_cache_bytes(const s2vt_dims* d) {
     if (!dims_ok(d)) return 0;
     return carve_decode_const(*d, nullptr).bytes;
+}
+int32_t s2vt_decode_uses_cache(const s2vt_dims* d) {
+    if (!dims_ok(d) || gemm_mode() == 0) return 0;
+    return (d->B % 64 == 0 || batch_padded(*d)) ? 1 : 0;
 }
 
 struct EncodeOut { float *vid_h, *vid_c, *word_h, *word_c; float* gx_dec; int depth; };      // states [B, H] after the L encode steps;
@@ -168,7 +176,7 @@ static int greedy_decode_impl(const s2vt_dims* d, const s2vt_params* p, const fl
                               void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, bool cache_valid,
                               void* stream, const EncodeOut* enc) {
     S2VT_REQUIRE(dims_ok(d) && p && feats && (ids || enc) && workspace, "s2vt_greedy_decode: null/invalid argument");
-    if (!batch_padded(*d))
+    if (!batch_padded(*d, enc != nullptr))
         return greedy_decode_core(d, p, feats, sos_ix, ids, workspace, workspace_bytes, cache, cache_bytes, cache_valid, stream, enc);
     const s2vt_dims dp = padded_dims(*d);
     const size_t core = decode_core_bytes(dp);

@@ -76,6 +76,14 @@ struct Carver {
         return p;
     }
 };
+// Batches that are not multiples of 64 in a plane mode: from option pad_min_batch rows on (default 33; a greedy decode: three
+// quarters of it, 24) the whole-path drivers pad them to the next multiple of 64 inside their workspace; smaller batches run as
+// they are on the launch-per-timestep fp32-MFMA path, which is faster there (train step at B = 16, H = 512: 4.4 vs 5.8 ms, at
+// B = 48: 6.8 vs 6.1; decode at B = 16, H = 1000: 4.2 vs 4.5 ms, at B = 32: 5.5 vs 4.6; profiles/round5_ragged_batches.txt)
+static inline bool batch_pads(int B, bool decode = false) {
+    const int from = decode ? option(O_PAD_MIN_BATCH) * 3 / 4 : option(O_PAD_MIN_BATCH);
+    return option(O_GEMM_MODE) != 0 && B % 64 != 0 && B >= (from > 0 ? from : 1);
+}
 static inline bool dims_ok(const s2vt_dims* d) { return d && d->B > 0 && d->L > 1 && d->F > 0 && d->H > 0 && d->E > 0 && d->V > 0; }
 
 // ---- options as the drivers read them (csrc/options.hip)

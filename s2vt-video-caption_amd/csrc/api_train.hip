@@ -522,7 +522,7 @@ extern "C" {
 // never handed out, and their dlogits rows are zero, so every gradient they contribute is an exact zero (dG = 0 for a row
 // whose dh and dc are 0) - the sums the real rows form are unchanged up to the order of fp32 additions.  Staging copies:
 // features, targets, logits / dlogits, the dropout mask (a few tens of MB at these batch sizes).
-static inline bool batch_padded(const s2vt_dims& d) { return gemm_mode() != 0 && d.B % 64 != 0; }
+static inline bool batch_padded(const s2vt_dims& d) { return batch_pads(d.B); }
 static inline s2vt_dims padded_dims(const s2vt_dims& d) { s2vt_dims q = d; q.B = (d.B + 63) / 64 * 64; return q; }
 struct PadWS { float* feats; int64_t* targets; float* logits; float* mask; float* dfeats; size_t bytes; };
 static PadWS carve_pad(const s2vt_dims& d, const s2vt_dims& dp, void* base) {

@@ -98,6 +98,10 @@ int lstm_step_fwd(hipStream_t stream, const StepFwdArgs& a);
 // source + guard), gx, c_prev and every output of `a` are used; h_prev / w_hh are not read, a.z_out is the INPUT
 int lstm_cell_pointwise(hipStream_t stream, const StepFwdArgs& a);
 int lstm_step_fwd2(hipStream_t stream, const StepFwdArgs& a, const StepFwdArgs* b);   // two independent steps, one launch
+// lstm_gemv.hip: the same step for B <= 8 as gate GEMVs (h staged in LDS, weight rows streamed to registers, wavefront shuffle
+// reductions); lstm_step_fwd routes there when option "gemv" is on and lstm_step_fwd_gemv_ok(a)
+bool lstm_step_fwd_gemv_ok(const StepFwdArgs& a);
+int lstm_step_fwd_gemv(hipStream_t stream, const StepFwdArgs& a);
 
 struct StepBwdArgs {
     int B, H;

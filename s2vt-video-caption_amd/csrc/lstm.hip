@@ -386,6 +386,9 @@ int lstm_step_fwd2(hipStream_t stream, const StepFwdArgs& a, const StepFwdArgs* 
     S2VT_REQUIRE(!(a.x2 || a.gx_tab) || a.tok_limit > 0, "lstm_step_fwd: a token segment needs tok_limit (rows of the table)");
     S2VT_REQUIRE(!b || (b->B == a.B && b->H == a.H && b->h_out && b->c_out && (b->gx || b->bias)),
                  "lstm_step_fwd: paired steps must have the same batch and hidden size");
+    // B <= 4: gate GEMVs (lstm_gemv.hip) - measured faster than the 16-row tile up to there (a B = 1 greedy decode 3.07 vs 3.67 ms,
+    // B = 4 3.47 vs 3.73, B = 6 4.01 vs 3.81: profiles/round5_gemv_small_batch.txt); option gemv = 2 sends every B <= 8 there
+    if (!b && lstm_step_fwd_gemv_ok(a) && (option(O_GEMV) == 2 || (option(O_GEMV) == 1 && a.B <= 4))) return lstm_step_fwd_gemv(stream, a);
     const bool vec = step_fwd_vec(a) && (!b || step_fwd_vec(*b));
     const StepFwdArgs& bb = b ? *b : a;
     if (a.B <= 16) {

@@ -23,6 +23,8 @@ static const OptionDef kOptions[O_COUNT] = {
     /* O_DECODE_FUSED   */ {"decode_fused", 1, 0, 1},       // greedy decode: recurrent GEMM inside the argmax launch
     /* O_CU_RESERVE     */ {"cu_reserve", 0, 0, 128},       // persistent GEMMs plan for this many compute units fewer
     /* O_BPTT_UNITS     */ {"bptt_units", 0, 0, 32},        // persistent bf16 BPTT: 32 | 16 hidden units per workgroup (0: 32 where it fits)
+    /* O_GEMV           */ {"gemv", 1, 0, 2},               // launch-per-timestep forward step as gate GEMVs (lstm_gemv.hip): 1 at B <= 4, 2 at B <= 8, 0 never
+    /* O_PAD_MIN_BATCH  */ {"pad_min_batch", 33, 1, 64},    // ragged batches of at least this size are padded to a multiple of 64 (plane path)
 };
 static int g_value[O_COUNT];
 static bool g_read[O_COUNT];

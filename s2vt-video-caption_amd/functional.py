@@ -228,8 +228,9 @@ def greedy_decode(feats, params, sos_ix, owner=None):
                                                      _ptr(ws), nbytes, _ptr(cache), cache.numel(), 1 if valid else 0,
                                                      _stream(dev)), "s2vt_greedy_decode_cached")
             entry = _DECODE_CACHES.get(owner)
-            if entry is not None and entry[1] is cache:
-                entry[2] = True                     # (stream-ordered: later calls on this stream see the filled images)
+            if entry is not None and entry[1] is cache and lib.s2vt_decode_uses_cache(ctypes.byref(d)):
+                entry[2] = True                     # (stream-ordered: later calls on this stream see the filled images; a batch of
+                                                    #  at most 16 clips decodes on the launch-per-timestep path and fills nothing)
         else:
             capi.check(lib.s2vt_greedy_decode(ctypes.byref(d), ctypes.byref(ps), _ptr(feats), int(sos_ix), _ptr(ids),
                                               _ptr(ws), nbytes, _stream(dev)), "s2vt_greedy_decode")

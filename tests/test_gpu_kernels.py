@@ -318,6 +318,58 @@ def test_lstm_step_fwd_matches_cell(lib, B, H):
 
 
 
+@pytest.mark.parametrize("B,H,E,V", [(1, 1000, 1000, 300), (2, 64, 40, 50), (3, 520, 500, 90), (5, 1000, 1000, 300), (8, 1000, 1000, 300),
+                                     (8, 512, 512, 200), (7, 8, 4, 30)])
+def test_small_batch_gemv_step_against_fp64_and_the_tile_kernel(lib, B, H, E, V):
+    """lstm_step_fwd_gemv_kernel (option gemv, B <= 8: h staged in LDS, weight rows streamed to registers, wavefront shuffle
+    reductions) through s2vt_lstm_step_fwd and s2vt_lstm_step_fwd_token: against the fp64 cell (fp32 rounding only: 2e-6) and
+    against the 16-row MFMA tile kernel it replaces (option gemv = 0), with the gate stash, the zero-state first step (h_prev
+    null), the embedded-word segment with int32 tokens / one constant token, and an id beyond the table (IndexError, token 0
+    read)."""
+    from s2vt_video_caption_amd import capi, ops
+    w_hh, w_ih, emb = _r(4 * H, H, seed=2, scale=H ** -0.5), _r(4 * H, E + H, seed=3, scale=(E + H) ** -0.5), _r(V, E, seed=4)
+    gx, hp, cp = _r(B, 4 * H, seed=1), _r(B, H, seed=5, scale=0.5), _r(B, H, seed=6, scale=0.5)
+    tok = torch.randint(0, V, (B,), generator=torch.Generator().manual_seed(7), dtype=torch.int32)
+
+    def ref(pre, cprev):
+        i, f, g, o = pre.chunk(4, dim=1)
+        c = torch.sigmoid(f) * cprev + torch.sigmoid(i) * torch.tanh(g)
+        return torch.sigmoid(o) * torch.tanh(c), c, torch.cat([torch.sigmoid(i), torch.sigmoid(f), torch.tanh(g), torch.sigmoid(o)], 1)
+    dev = [t.to(DEV) for t in (gx, w_hh, hp, cp, emb, w_ih)]
+    outs = {}
+    prev = lib.s2vt_set_option(b"gemv", -1)
+    try:
+        for on in (1, 0):
+            lib.s2vt_set_option(b"gemv", 2 if on else 0)        # (2: every B <= 8 takes the GEMV kernel; the default, 1, stops at B = 4)
+            a = ops.lstm_step_fwd(dev[0], None, dev[1], dev[2], dev[3], want_stash=True)
+            b0 = ops.lstm_step_fwd(dev[0], None, dev[1], None, None)                       # zero state: no recurrent segment
+            t1 = ops.lstm_step_fwd_token(*dev, tok=tok.to(DEV))
+            t2 = ops.lstm_step_fwd_token(*dev, tok_const=V - 1)
+            capi.check_async_error()
+            outs[on] = (a, b0, t1, t2)
+            bad = ops.lstm_step_fwd_token(*dev, tok=tok.clone().index_fill_(0, torch.tensor([B - 1]), V).to(DEV))
+            with pytest.raises(IndexError):
+                torch.cuda.synchronize()
+                capi.check_async_error()
+            ok_rows = slice(0, B - 1)
+            assert torch.equal(bad[0][ok_rows], t1[0][ok_rows])
+    finally:
+        lib.s2vt_set_option(b"gemv", prev)
+    d = lambda x: x.double()
+    hr, cr, sr = ref(d(gx) + d(hp) @ d(w_hh).t(), d(cp))
+    h0r, c0r, _ = ref(d(gx), torch.zeros(B, H, dtype=torch.float64))
+    e1 = d(emb)[tok.long()] @ d(w_ih)[:, :E].t()
+    h1r, c1r, _ = ref(d(gx) + d(hp) @ d(w_hh).t() + e1, d(cp))
+    e2 = d(emb)[V - 1:V].expand(B, E) @ d(w_ih)[:, :E].t()
+    h2r, c2r, _ = ref(d(gx) + d(hp) @ d(w_hh).t() + e2, d(cp))
+    for on in (1, 0):
+        (h, c, st), (hb, cb), (ht, ct), (hk, ck) = outs[on]
+        for got, want in ((h, hr), (c, cr), (st, sr), (hb, h0r), (cb, c0r), (ht, h1r), (ct, c1r), (hk, h2r), (ck, c2r)):
+            assert (got.cpu().double() - want).abs().max().item() < 4e-6, on
+    for x, y in zip(outs[1][0] + outs[1][2], outs[0][0] + outs[0][2]):
+        assert (x - y).abs().max().item() < 2e-6                 # the two kernels differ by the order of fp32 additions only
+
+
 def test_decode_step_token_segment_and_poisoned_token_word(lib):
     """The decode step's token path (S2VTModel.py:100-103: Emb[prev word] in front of vid_out) through s2vt_lstm_step_fwd_token:
     (a) int32 tokens and packed argmax words against the fp64 cell; (b) a packed word that no producer wrote (0 -> token

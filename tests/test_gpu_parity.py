@@ -287,17 +287,31 @@ def test_against_oracle_on_fresh_seeds(lib):
             assert torch.equal(ids, oids)
 
 
-@pytest.mark.parametrize("B", [16, 10, 100])
-def test_reference_default_sizes_take_the_plane_path_and_match_the_oracle(lib, B):
+@pytest.mark.parametrize("B,pad_min", [(16, 1), (10, 1), (16, 33), (10, 33), (100, 33), (40, 33)])
+def test_reference_default_sizes_and_ragged_batches_match_the_oracle(lib, B, pad_min):
     """The reference's own defaults - batch_size = 16, dim_hidden = dim_embed = 512 (train.py:27-28,37), eval batch 10 (eval.py:27) -
-    and a ragged batch above 64 at L = 80, F = 4096: the library pads the batch to a multiple of 64 inside its workspace
-    (s2vt_padded_batch) so that these sizes run the plane GEMMs, the persistent recurrence and the decode cache instead of the
-    launch-per-timestep fp32-MFMA driver.  Train step (logits, loss, all 13 gradients and dfeats), greedy ids and beam captions
-    against the oracle; the pad rows must not leak into anything (bias sums, embedding gradient, CE mean)."""
+    and ragged batches below / above 64 at L = 80, F = 4096.  From option pad_min_batch rows on (default 33; greedy decode: 24) the library pads the
+    batch to a multiple of 64 inside its workspace (s2vt_padded_batch) so that it runs the plane GEMMs, the persistent
+    recurrence and the decode cache; smaller batches run as they are on the launch-per-timestep driver (measured faster there:
+    profiles/round5_ragged_batches.txt) - pad_min_batch = 1 forces the padded path at the reference's sizes too.  Train step
+    (logits, loss, all 13 gradients and dfeats), greedy ids and beam captions against the oracle; the pad rows must not leak
+    into anything (bias sums, embedding gradient, CE mean)."""
     import S2VTModel, utils
     from s2vt_video_caption_amd import beam, functional
     L, Fd, H, E, V = 80, 4096, 512, 512, 3000
-    assert lib.s2vt_padded_batch(B) == (B + 63) // 64 * 64 and lib.s2vt_set_gemm_mode(-1) == 3
+    prev_pad = lib.s2vt_set_option(b"pad_min_batch", pad_min)
+    try:
+        _ragged_body(lib, B, pad_min, L, Fd, H, E, V)
+    finally:
+        lib.s2vt_set_option(b"pad_min_batch", prev_pad)
+        functional.clear_decode_cache()
+
+
+def _ragged_body(lib, B, pad_min, L, Fd, H, E, V):
+    import S2VTModel, utils
+    from s2vt_video_caption_amd import beam, functional
+    padded = B >= pad_min
+    assert lib.s2vt_padded_batch(B) == ((B + 63) // 64 * 64 if padded else B) and lib.s2vt_set_gemm_mode(-1) == 3
     sd = synth.make_state_dict(V, Fd, H, E, seed=40 + B)
     feats, caps, mask = synth.make_batch(B, L, Fd, V, seed=41 + B)
     m = S2VTModel.S2VT(V, Fd, L, dim_hid=H, dim_embed=E)
@@ -321,7 +335,8 @@ def test_reference_default_sizes_take_the_plane_path_and_match_the_oracle(lib, B
     m.eval()
     with torch.no_grad():
         ids = m(feats.to(DEV), mode="test").cpu()
-        assert m in functional._DECODE_CACHES and functional._DECODE_CACHES[m][2]      # the decode cache serves ragged batches too
+        # the decode cache serves padded batches too; an unpadded small batch decodes launch per timestep and fills nothing
+        assert m in functional._DECODE_CACHES and functional._DECODE_CACHES[m][2] == (B >= pad_min * 3 // 4)
         again = m(feats.to(DEV), mode="test").cpu()
     assert torch.equal(ids, again)
     oids, marg = orc.greedy_decode(sd, feats, return_margins=True)
@@ -770,6 +785,14 @@ def test_out_of_range_loss_target_raises_index_error(lib):
 
 @pytest.mark.parametrize("B,gemm_mode", [(5, 0), (5, 3), (64, 3), (64, 1)])
 def test_out_dropout_train_mode_matches_oracle_with_the_same_mask(lib, B, gemm_mode):
+    prev_pad = lib.s2vt_set_option(b"pad_min_batch", 1)       # (B = 5 in a plane mode: the padded path and its staged mask)
+    try:
+        _dropout_body(lib, B, gemm_mode)
+    finally:
+        lib.s2vt_set_option(b"pad_min_batch", prev_pad)
+
+
+def _dropout_body(lib, B, gemm_mode):
     """out_dropout > 0 (S2VTModel.py:25,79): the decode-step hidden states are masked between word_rnn and out_linear.  With
     the SAME keep mask the oracle must give the same logits and the same 13 gradients (fp32 paths: gemm mode 0 = the fp32-MFMA
     driver, mode 3 the split-precision plane driver - B=5 padded to 64 inside the workspace, its mask staged time-major at the
