@@ -127,8 +127,19 @@ def launcher_selftest(args):
     dist.all_reduce(t)
     if int(t.item()) != world:
         raise SystemExit("all-reduce saw %d of %d ranks" % (int(t.item()), world))
+    # the fixed-global-batch record's sharding (global 1024 -> 1024 / N rows per GPU): every rank reports its rows, rank 0 checks that
+    # the shards tile the batch exactly once
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import s2vt_video_caption_amd  # noqa: F401
+    from s2vt_video_caption_amd import dp as _dp
+    per, lo, hi = _dp.fixed_global_shard(1024, dist.get_rank(), world)
+    rows = [None] * world
+    dist.all_gather_object(rows, (lo, hi))
+    if sorted(rows) != [(r * per, (r + 1) * per) for r in range(world)] or per * world != 1024:
+        raise SystemExit("fixed-global-batch shards do not tile the batch: %s" % rows)
     if dist.get_rank() == 0:
-        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks": world, "backend": "gloo"}), flush=True)
+        print(json.dumps({"selftest": "launcher", "n_gpus": world, "ranks": world, "backend": "gloo",
+                          "fixed_global": {"global_batch": 1024, "per_gpu_batch": per, "rows_by_rank": rows}}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -171,8 +182,13 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_pg = world > 1 or ("RANK" in os.environ and os.environ.get("S2VT_BENCH_PG", "0") == "1")
+    cu_reserved = 0
     if use_pg:      # one process per GPU over RCCL ("nccl" backend); a 1-rank group exercises the same code path
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        import s2vt_video_caption_amd  # noqa: F401
+        from s2vt_video_caption_amd import dp as _dp0
+        cu_reserved = _dp0.plan_for_collectives(world)          # (before the communicator exists: NCCL_MAX_NCHANNELS + cu_reserve)
         dist.init_process_group(backend="nccl", device_id=dev)
         if dist.get_world_size() != args.gpus:
             raise SystemExit("--gpus %d but the RCCL group has %d ranks" % (args.gpus, dist.get_world_size()))
@@ -310,6 +326,32 @@ def main():
                     "steps": n128, "global_batch": 128 * world}
         del f2, c2, m2
         log("B=128 shard: %s" % shard128)
+
+    # ---- fixed GLOBAL batch (strong scaling; SURVEY.md 8(e) asks for it beside the weak-scaling headline): BASELINE configs[3]'s
+    # global 1024 cut into 1024 / N rows per GPU - 128 per GPU at N = 8 - the same arithmetic, every rank taking part
+    fixed_global = None
+    if mode != 1 and not args.headline_only and 1024 % world == 0:
+        perb, lo_, hi_ = dp.fixed_global_shard(1024, rank, world)
+        fb = tuple(t[lo_:hi_].to(dev) for t in synth.make_batch(1024, L, F, V, seed=4321))
+        nfg = 4 if perb >= 512 else 10
+        for _ in range(2):
+            dp.train_step(model, crit, opt, fb[0], fb[1], fb[2], reducer)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(nfg):
+            dp.train_step(model, crit, opt, fb[0], fb[1], fb[2], reducer)
+        sync_all()
+        dfg = time.perf_counter() - t0
+        capi.check_async_error()
+        if use_pg:
+            t = torch.tensor([dfg], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dfg = float(t.item())
+        fixed_global = {"workload": "BASELINE configs[3] as strong scaling: global B = 1024 over %d GPU = %d per GPU" % (world, perb),
+                        "scaling": "strong", "global_batch": 1024, "per_gpu_batch": perb, "value": round(1024 * L * nfg / dfg, 1),
+                        "unit": "frames/s", "ms_per_step": round(dfg / nfg * 1e3, 3), "steps": nfg}
+        del fb
+        log("fixed global batch: %s" % fixed_global)
 
     out = None
     if rank == 0:
@@ -771,6 +813,8 @@ def main():
             "rccl_ranks": dist.get_world_size() if use_pg else 1,
             "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if use_pg else None,
             "dp_b128": shard128,
+            "fixed_global_1024": fixed_global,
+            "cu_reserved_for_collectives": cu_reserved,
             "config3": config3,
             "ref_defaults": ref_defaults,
         }

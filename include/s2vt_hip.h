@@ -152,6 +152,11 @@ int s2vt_beam_queue_result(int32_t B, int32_t beam_width, int32_t max_depth, voi
  *   group 1 = word_rnn (4 tensors) + embedding: final before the vid_rnn / feat_linear weight-gradient GEMMs.
  * The remaining gradients (vid_rnn, feat_linear) are final when the backward's own stream is. */
 int s2vt_backward_wait_grads(int32_t group, void* stream);
+/* Order check of that overlap for the last s2vt_train_backward of the plane drivers: how many persistent BPTT launches it
+ * enqueued, and how many of them were already enqueued when gradient group 0's event was recorded for the last time.  The two
+ * must be equal: a persistent launch needs all of its workgroups resident, so no collective may be released beside one (the
+ * out_linear all-reduce then overlaps the weight-gradient GEMMs behind the recurrence instead). */
+int s2vt_backward_order(int32_t* persistent_bptt_launches, int32_t* group0_recorded_after);
 
 /* Autograd of the above (loss.backward(), train.py:124) given dlogits [B, L-1, V] (contiguous).
  * dfeats [B, L, F] may be NULL (nothing reads it in the reference: SURVEY.md §3.1 note). */

@@ -51,6 +51,7 @@ SIGNATURES = {
     "s2vt_train_backward": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_void_p, POINTER(Grads), c_void_p,
                                       c_void_p, c_size_t, c_void_p]),
     "s2vt_backward_wait_grads": (c_int32, [c_int32, c_void_p]),
+    "s2vt_backward_order": (c_int32, [POINTER(c_int32), POINTER(c_int32)]),
     "s2vt_beam_workspace_bytes": (c_size_t, [POINTER(Dims), c_int32]),
     "s2vt_beam_step": (c_int32, [POINTER(Dims), POINTER(Params), c_int32] + [c_void_p] * 14 + [c_size_t, c_void_p]),
     "s2vt_beam_step_cached": (c_int32, [POINTER(Dims), POINTER(Params), c_int32] + [c_void_p] * 14 + [c_size_t, c_void_p, c_size_t,

@@ -89,7 +89,12 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
 // group 0 = out_linear (weight, bias), group 1 = word_rnn (4 tensors) + embedding; the rest is final with the call's stream.
 static hipEvent_t g_grad_ev[2] = {nullptr, nullptr};
 static bool g_grad_ev_set[2] = {false, false};
+// Order check of the data-parallel overlap (s2vt_backward_order): a persistent BPTT launch needs every one of its workgroups
+// resident, so the event that releases the out_linear all-reduce (group 0) must have been recorded LAST behind the last such
+// launch of the backward - g_bwd_group0_after = persistent BPTT launches enqueued when group 0's event was last recorded
+static int g_bwd_persist_launches = 0, g_bwd_group0_after = 0;
 static int grads_ready(int group, hipStream_t s) {
+    if (group == 0) g_bwd_group0_after = g_bwd_persist_launches;
     if (!g_grad_ev[group]) S2VT_HIP(hipEventCreateWithFlags(&g_grad_ev[group], hipEventDisableTiming));
     // inside a capture nothing is recorded (an event recorded on a capturing stream cannot be waited for from outside, and
     // external event-record nodes are refused by this runtime): the backward driver records both groups behind the graph
@@ -331,6 +336,8 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
                              const float* out_mask, bool dlog_ready) {
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1, R = (L - 1) * B;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
+    g_bwd_persist_launches = 0;
+    g_bwd_group0_after = 0;
     const int blk = pipe_block();
     hipStream_t sx = st;
     int rc;
@@ -395,6 +402,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
                                                  w.xpart1, w.xpslot, w.xnslots, w.psync_b, w.err + 1);
                 if (hw && hv) rc = lstm_seq_bwd_x3_persist2(st, aw, &av);
                 else rc = lstm_seq_bwd_x3_persist2(st, hw ? aw : av, nullptr);
+                ++g_bwd_persist_launches;
                 if (rc) return rc;
             }
             if (hw) {
@@ -429,6 +437,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
                 ProfScope ps(st, K_STEP_BWD, (hw ? bd[k + 1] - bd[k] : 0) + (hv ? bd[k + 2] - bd[k + 1] : 0));
                 if (hw && hv) rc = lstm_seq_bwd_bf16_persist2(st, aw, &av);
                 else rc = lstm_seq_bwd_bf16_persist2(st, hw ? aw : av, nullptr);
+                ++g_bwd_persist_launches;
                 if (rc) return rc;
             }
             if (hw) {
@@ -834,6 +843,12 @@ int s2vt_train_backward_dropout(const s2vt_dims* d, const s2vt_params* p, const 
                                 const float* out_mask, const s2vt_grads* g, float* dfeats, void* workspace,
                                 size_t workspace_bytes, void* stream) {
     return train_backward_impl(d, p, feats, dlogits, g, dfeats, workspace, workspace_bytes, stream, out_mask);
+}
+
+int s2vt_backward_order(int32_t* persistent_bptt_launches, int32_t* group0_recorded_after) {
+    if (persistent_bptt_launches) *persistent_bptt_launches = g_bwd_persist_launches;
+    if (group0_recorded_after) *group0_recorded_after = g_bwd_group0_after;
+    return 0;
 }
 
 int s2vt_backward_wait_grads(int32_t group, void* stream) {

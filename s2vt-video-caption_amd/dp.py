@@ -15,6 +15,31 @@ import torch
 import torch.distributed as dist
 
 
+def plan_for_collectives(world, channels=16):
+    """Call BEFORE the RCCL process group is created when world > 1.  The persistent GEMMs of the backward plan one workgroup per
+    compute unit with a static share of the tiles; RCCL's all-reduce kernels (one workgroup per channel) run beside the
+    weight-gradient GEMMs and would make the workgroups that find no unit wait for a whole share.  So the pair is made
+    deterministic: RCCL is held to `channels` channels (NCCL_MAX_NCHANNELS, unless the user set it) and the GEMMs plan their grids
+    for that many compute units fewer (library option cu_reserve, unless the user set it: S2VT_CU_RESERVE or s2vt_set_option).
+    Returns the number of compute units reserved (0 at world 1)."""
+    import os
+    from . import capi
+    if world <= 1:
+        return 0
+    n = int(os.environ.setdefault("NCCL_MAX_NCHANNELS", str(int(channels))))
+    lib = capi.load()
+    if "S2VT_CU_RESERVE" not in os.environ and lib.s2vt_set_option(b"cu_reserve", -1) == 0:
+        lib.s2vt_set_option(b"cu_reserve", max(0, min(n, 128)))
+    return int(lib.s2vt_set_option(b"cu_reserve", -1))
+
+
+def fixed_global_shard(global_batch, rank, world):
+    """Strong-scaling companion of the weak-scaling headline (keep per-GPU B fixed AND report fixed global B):
+    rank r of `world` trains rows [r * G / W, (r + 1) * G / W) of a global batch of G; returns (per_gpu_batch, lo, hi)."""
+    lo, hi = shard_rows(global_batch, rank, world)
+    return hi - lo, lo, hi
+
+
 def shard_rows(n_rows, rank, world):
     """Row range of the global batch owned by `rank` (equal shards; n_rows must divide)."""
     if n_rows % world:

@@ -24,6 +24,9 @@ def test_gpus_2_spawns_two_ranks():
     assert len(lines) == 1, lines                       # ONE JSON line, from rank 0
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["ranks"] == 2
+    # the fixed-global-batch record (global 1024, strong scaling) shards 512 rows to each of the two ranks, tiling the batch
+    fg = out["fixed_global"]
+    assert fg["global_batch"] == 1024 and fg["per_gpu_batch"] == 512 and sorted(map(tuple, fg["rows_by_rank"])) == [(0, 512), (512, 1024)]
 
 
 def test_world_size_mismatch_aborts():

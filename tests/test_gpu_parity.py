@@ -907,7 +907,7 @@ def test_bf16_mode_config3_arithmetic(lib):
         assert torch.equal(ids_bf16_mode, oids)
 
 
-@pytest.mark.parametrize("cfg,B,gemm_mode", [("tiny", 3, None), ("c2", 64, None), ("c3", 256, 1)])
+@pytest.mark.parametrize("cfg,B,gemm_mode", [("tiny", 3, None), ("c2", 64, None), ("c2", 64, "persist_x3_bwd"), ("c3", 256, 1)])
 def test_dp_overlapped_allreduce_single_rank_rccl(lib, cfg, B, gemm_mode):
     """dp.FlatGradAllReducer.attach(): the backward writes its gradients straight into the flat buffer and the
     all-reduce of each gradient group is issued on a side stream behind s2vt_backward_wait_grads.  With one rank
@@ -920,6 +920,10 @@ def test_dp_overlapped_allreduce_single_rank_rccl(lib, cfg, B, gemm_mode):
     import torch.distributed as dist
     import utils
     from s2vt_video_caption_amd import capi, dp
+    x3b = gemm_mode == "persist_x3_bwd"          # the split-precision configuration with its persistent BPTT (option persist_x3_bwd)
+    if x3b:
+        gemm_mode = None
+        prev_x3b = lib.s2vt_set_option(b"persist_x3_bwd", 1)
     if gemm_mode is not None:
         prev_mode = lib.s2vt_set_gemm_mode(gemm_mode)
     try:
@@ -928,6 +932,13 @@ def test_dp_overlapped_allreduce_single_rank_rccl(lib, cfg, B, gemm_mode):
     finally:
         if gemm_mode is not None:
             lib.s2vt_set_gemm_mode(prev_mode)
+        if x3b:
+            lib.s2vt_set_option(b"persist_x3_bwd", prev_x3b)
+
+
+def capi_plan(B, H):
+    from s2vt_video_caption_amd import capi
+    return capi.recurrence_plan(B, H) if B % 64 == 0 else (0, 0)
 
 
 def _dp_overlapped_body(lib, cfg, B):
@@ -954,6 +965,12 @@ def _dp_overlapped_body(lib, cfg, B):
                             device_id=torch.device(DEV))
     try:
         losses, got = run(True)
+        # no collective may be released beside a persistent BPTT launch: gradient group 0's event was recorded, for the last time,
+        # behind every such launch of the backward (bf16 configuration: 7 launches; launch-per-timestep BPTT: none)
+        import ctypes
+        n_p, after = ctypes.c_int32(-1), ctypes.c_int32(-1)
+        assert lib.s2vt_backward_order(ctypes.byref(n_p), ctypes.byref(after)) == 0
+        assert after.value == n_p.value and (n_p.value > 0) == (capi_plan(d["B"], d["H"])[1] != 0), (n_p.value, after.value)
     finally:
         dist.destroy_process_group()
     # every reduction on the path has a fixed order (no atomics): the two loops must agree bitwise

@@ -62,6 +62,9 @@ def run(opt):
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import s2vt_video_caption_amd  # noqa: F401
+        from s2vt_video_caption_amd import dp as _dp
+        _dp.plan_for_collectives(world)      # RCCL's channel count and the GEMMs' compute-unit reserve, before the communicator exists
         dist.init_process_group(backend="nccl", device_id=dev)
 
     import numpy as np
