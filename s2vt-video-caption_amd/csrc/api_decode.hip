@@ -341,9 +341,13 @@ static int greedy_decode_core(const s2vt_dims* d, const s2vt_params* p, const fl
     };
     if (use_px) {
         if ((rc = handoff(sx, st, ev++))) return rc;            // lane B's weight images before their first use on this stream
+        // (vid_rnn's h_t rows arrive in the GEMM's row image w.ph1 from the persistent kernel itself - SeqFwdX3Args::hblk; the k16
+        // records past the last column slice are zeroed here)
+        {
+            const size_t kc0 = (size_t)cdiv(H, 16), kc1 = (size_t)(w.ph1.kpad / 16);
+            if (kc1 > kc0) S2VT_HIP(hipMemset2DAsync(w.ph1.p + kc0 * 3072, (size_t)64 * w.ph1.ld * 2, 0, (kc1 - kc0) * 6144, (size_t)(T * B / 64), st));
+        }
         auto gx2_block = [&](int t0, int t1) -> int {           // vid_out half of word_rnn's gate input for steps [t0, t1) (+ biases)
-            int r;
-            if ((r = psplit(la, w.ph1, t0 * B, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H))) return r;
             return pgemm(la, (t1 - t0) * B, 4 * H, H, w.ph1, t0 * B, 0, kc.wv, 0, 0, w.gx2 + t0 * B4H, 4 * H, ID, w.bsum2, false);
         };
         const std::vector<int> be = pipe_bounds(L, L, balanced_block(L, blk));     // blocks over the L encode steps
@@ -360,6 +364,7 @@ static int greedy_decode_core(const s2vt_dims* d, const s2vt_params* p, const fl
             if (hv) {
                 av = persist_fwd_x3_args(bv[k], bv[k + 1], B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
                 av.no_stash = 1;
+                av.hblk = w.ph1.p; av.ldhblk = w.ph1.ld;
             }
             if (hw) {
                 aw = persist_fwd_x3_args(be[k - 1], be[k], B, H, L, w.xkp, w.gx2, L, w.bsum2, kc.xw2, w.xh2, w.h2_all, w.c2_all, w.psync_b, w.err + 1);
@@ -387,6 +392,7 @@ static int greedy_decode_core(const s2vt_dims* d, const s2vt_params* p, const fl
                 if (tv < Td) {
                     SeqFwdX3Args av = persist_fwd_x3_args(tv, Td, B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
                     av.no_stash = 1;
+                    av.hblk = w.ph1.p; av.ldhblk = w.ph1.ld;
                     {
                         ProfScope ps(st, K_STEP_FWD, Td - tv);
                         if ((rc = lstm_seq_fwd_x3_persist2(st, av, nullptr))) return rc;
@@ -400,6 +406,7 @@ static int greedy_decode_core(const s2vt_dims* d, const s2vt_params* p, const fl
         if (tv < T) {   // the rest of vid_rnn's decode steps (no input: bias only): one launch that may use the whole device
             SeqFwdX3Args av = persist_fwd_x3_args(tv, T, B, H, T, w.xkp, w.gx1, L, w.bsum1, kc.xw1, w.xh1, w.h1, w.c1_all, w.psync_a, w.err + 1);
             av.no_stash = 1;
+            av.hblk = w.ph1.p; av.ldhblk = w.ph1.ld;
             {
                 ProfScope ps(st, K_STEP_FWD, T - tv);
                 if ((rc = lstm_seq_fwd_x3_persist2(st, av, nullptr))) return rc;

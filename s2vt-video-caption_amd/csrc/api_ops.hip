@@ -398,7 +398,7 @@ int s2vt_recurrence_plan(int32_t B, int32_t H, int32_t* fwd, int32_t* bwd) {
         return 0;
     }
     if (H <= 1024 && persist_x3_fwd_on() && lstm_seq_fwd_x3_persist_supported(B, H)) *fwd = 3;
-    if (H <= 1024 && persist_x3_bwd_on() && lstm_seq_bwd_x3_persist_supported(B, H)) *bwd = 3;
+    if (H <= 1024 && persist_x3_bwd_on(B, H) && lstm_seq_bwd_x3_persist_supported(B, H)) *bwd = 3;
     return 0;
 }
 

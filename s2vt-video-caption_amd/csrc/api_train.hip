@@ -51,7 +51,9 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     w.xh1 = c.take<unsigned short>(w.xfwd ? 3 * T * B * w.xkp : 0);
     w.xh2 = c.take<unsigned short>(w.xfwd ? 3 * T * B * w.xkp : 0);
     {   // ring slots: one more than the longest block of the backward's pipeline (a slot is written once per launch)
-        const bool can = w.xkp > 0 && B % 32 == 0 && pipe_block() > 0 && persist_x3_bwd_on();    // (opt-in kernel: no rings otherwise)
+        // (no device query in a workspace-size function: the rings are provided wherever the option allows the kernel at all)
+        const bool can = w.xkp > 0 && B % 32 == 0 && pipe_block() > 0 && option(O_PERSIST_X3_BWD) != 0 && persist_on() &&
+                         (option(O_PERSIST_X3_BWD) == 1 || B * cdiv((int)H, 16) / 32 * 2 <= 256);
         const size_t maxblk = (size_t)pipe_block() < T ? (size_t)pipe_block() : T;
         w.xnslots = can ? (int)maxblk + 1 : 0;
         w.xhp = (int64_t)((H + 15) / 16 * 16);
@@ -71,7 +73,7 @@ static TrainWS carve_train(const s2vt_dims& d, void* base) {
     w.dc1 = c.take<float>(B * H);
     w.dc2 = c.take<float>(B * H);
     w.ce_alpha = c.take<float>(64);
-    size_t cs = colsum_partial_floats((int64_t)T * B, (int)(4 * H));
+    size_t cs = 2 * colsum_partial_floats((int64_t)T * B, (int)(4 * H));      // (chunks of 32 rows when the persistent BPTT writes them)
     size_t cs2 = colsum_partial_floats((int64_t)(L - 1) * B, (int)V);
     size_t cs3 = colsum_partial_floats((int64_t)L * B, (int)H);
     const size_t csm = cs > cs2 ? (cs > cs3 ? cs : cs3) : (cs2 > cs3 ? cs2 : cs3);
@@ -241,6 +243,12 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
         // stage k = vid_rnn block k next to word_rnn block k-1
         if ((rc = handoff(sx, st, ev++))) return rc;
         const int nb = (int)bd.size() - 1;
+        // the kernel writes h_t into the GEMMs' row images itself (the hand-off payload's own 16-byte pieces); the k16 records past
+        // the last column slice are zeroed here (H = 1000: units 1008..1023)
+        for (const PB* img : {&q.h1, &q.h2r}) {
+            const size_t kc0 = (size_t)cdiv(H, 16), kc1 = (size_t)(img->kpad / 16);
+            if (kc1 > kc0) S2VT_HIP(hipMemset2DAsync(img->p + kc0 * 3072, (size_t)64 * img->ld * 2, 0, (kc1 - kc0) * 6144, (size_t)(T * B / 64), st));
+        }
         for (int k = 0; k <= nb; ++k) {
             const bool hv = k < nb, hw = k >= 1;
             {
@@ -248,21 +256,15 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
             SeqFwdX3Args av, aw;
             if (hv) av = persist_fwd_x3_args(bd[k], bd[k + 1], B, H, T, w.xkp, w.s1, L, w.bsum1, w.xw1, w.xh1, w.h1, w.c1, w.psync_a, w.err + 1);
             if (hw) aw = persist_fwd_x3_args(bd[k - 1], bd[k], B, H, T, w.xkp, w.s2, T, w.bsum2, w.xw2, w.xh2, w.h2, w.c2, w.psync_b, w.err + 1);
+            av.hblk = q.h1.p; av.ldhblk = q.h1.ld;
+            aw.hblk = q.h2r.p; aw.ldhblk = q.h2r.ld;
             if (hv && hw) rc = lstm_seq_fwd_x3_persist2(st, av, &aw);
             else rc = lstm_seq_fwd_x3_persist2(st, hv ? av : aw, nullptr);
             }
             if (rc) return rc;
-            if (hw) {
-                const int t0 = bd[k - 1], t1 = bd[k];
-                const bool cap = t0 >= L;
-                if ((rc = pdual(la, w.h2 + t0 * BH, H, ID, (t1 - t0) * B, H, &q.h2r, t0 * B, nullptr,
-                                t0 * B, nullptr)))
-                    return rc;
-            }
             if (hv) {
                 const int t0 = bd[k], t1 = bd[k + 1];
                 const bool cap = t0 >= L;
-                if ((rc = pdual(la, w.h1 + t0 * BH, H, ID, (t1 - t0) * B, H, &q.h1, t0 * B, nullptr, t0 * B, nullptr))) return rc;
                 if ((rc = pgemm(la, (t1 - t0) * B, 4 * H, H, q.h1, t0 * B, 0, q.wv, 0, 0, w.s2 + t0 * B4H, 4 * H, ID,
                                 cap ? nullptr : w.bsum2, cap)))
                     return rc;
@@ -336,8 +338,6 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
                              const float* out_mask, bool dlog_ready) {
     const int B = d->B, L = d->L, F = d->F, H = d->H, E = d->E, V = d->V, T = 2 * L - 1, R = (L - 1) * B;
     const int64_t BH = (int64_t)B * H, B4H = 4 * BH;
-    g_bwd_persist_launches = 0;
-    g_bwd_group0_after = 0;
     const int blk = pipe_block();
     hipStream_t sx = st;
     int rc;
@@ -379,9 +379,10 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = grads_ready(0, sx))) return rc;
     if (!bf && (rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     const bool pbf_bwd = bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad;
-    const bool px3_bwd = !bf && XP == 3 && blk > 0 && w.xnslots > 0 && persist_x3_bwd_on() && lstm_seq_bwd_x3_persist_supported(B, H) &&
+    const bool px3_bwd = !bf && XP == 3 && blk > 0 && w.xnslots > 0 && persist_x3_bwd_on(B, H) && lstm_seq_bwd_x3_persist_supported(B, H) &&
                          w.xnslots > (blk < T ? blk : T);
     const std::vector<int> bd = pipe_bounds(T, L, (pbf_bwd || px3_bwd) ? balanced_block(L, blk) : blk);
+    int bias_chunk = 64;      // rows per partial column sum of dG (32: written by the persistent split-precision BPTT itself)
     if (px3_bwd) {   // W_hh^T of both layers as planes (each on the lane that transposed it)
         if ((rc = split3_wt(st, w.wt2, H, (int)w.xkp, (int)w.xhp, w.xwt2, w.xkp * 4 * w.xhp))) return rc;
         if ((rc = split3_wt(sx, w.wt1, H, (int)w.xkp, (int)w.xhp, w.xwt1, w.xkp * 4 * w.xhp))) return rc;
@@ -391,6 +392,21 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
         // block k next to vid_rnn BPTT of block k+1
         if ((rc = handoff(sx, st, ev++))) return rc;               // W_hh1^T and the out_linear gradients of lane B
         const int nb = (int)bd.size() - 1;
+        // The kernel hands dG over as the GEMMs' row-plane image itself (+ its 32-row column sums for the bias gradients): its dG tile
+        // is in LDS as planes anyway - no split pass reads dG back, the fp32 dG is never stored.  (H % 8: a 16-byte slot of the image
+        // holds 8 consecutive units of one gate.)  The k padding [4H, pad64(4H)) of both images is zeroed here once per backward.
+        const bool emit = H % 8 == 0;
+        if (emit && q.dg2.kpad > 4 * H) {
+            const size_t kc0 = (size_t)(4 * H / 16), kc1 = (size_t)(q.dg2.kpad / 16);       // k16 records [kc0, kc1) of every 64-row block
+            const size_t first = (4 * H % 16) ? kc0 + 1 : kc0;                              // (4H % 16 == 8: the straddling record's upper half
+            for (const PB* img : {&q.dg2, &q.dg1}) {                                        //  is zeroed piece by piece below)
+                if (kc1 > first)
+                    S2VT_HIP(hipMemset2DAsync(img->p + first * 3072, (size_t)64 * img->ld * 2, 0, (kc1 - first) * 6144, (size_t)(T * B / 64), st));
+                if (4 * H % 16)
+                    for (int pl = 0; pl < 3; ++pl)
+                        S2VT_HIP(hipMemset2DAsync(img->p + kc0 * 3072 + (pl * 2 + 1) * 512, (size_t)64 * img->ld * 2, 0, 1024, (size_t)(T * B / 64), st));
+            }
+        }
         for (int k = nb - 1; k >= -1; --k) {
             const bool hw = k >= 0, hv = k + 1 <= nb - 1;
             {
@@ -400,6 +416,10 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
                                                  w.xpart2, w.xpslot, w.xnslots, w.psync_a, w.err + 1);
                 if (hv) av = persist_bwd_x3_args(T, bd[k + 1], bd[k + 2], B, H, w.xkp, w.xhp, w.xwt1, w.dh1, 0, w.c1, w.s1, w.dc1,
                                                  w.xpart1, w.xpslot, w.xnslots, w.psync_b, w.err + 1);
+                if (emit) {
+                    aw.dgp = q.dg2.p; aw.lddgp = q.dg2.ld; aw.colpart = w.colsum_a; aw.skip_dg = 1;
+                    av.dgp = q.dg1.p; av.lddgp = q.dg1.ld; av.colpart = w.colsum_b; av.skip_dg = 1;
+                }
                 if (hw && hv) rc = lstm_seq_bwd_x3_persist2(st, aw, &av);
                 else rc = lstm_seq_bwd_x3_persist2(st, hw ? aw : av, nullptr);
                 ++g_bwd_persist_launches;
@@ -407,19 +427,20 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
             }
             if (hw) {
                 const int t0 = bd[k], t1 = bd[k + 1];
-                if ((rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, &q.dg2, t0 * B, nullptr, t0 * B,
-                                w.colsum_a + (int64_t)(t0 * B / 64) * 4 * H)))
+                if (!emit && (rc = pdual(la, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, &q.dg2, t0 * B, nullptr, t0 * B,
+                                         w.colsum_a + (int64_t)(t0 * B / 64) * 4 * H)))
                     return rc;
                 if ((rc = pgemm(la, (t1 - t0) * B, H, 4 * H, q.dg2, t0 * B, 0, q.wvT, 0, 0, w.dh1 + t0 * BH, H, ID, nullptr, false)))
                     return rc;
             }
-            if (hv) {
+            if (hv && !emit) {
                 const int t0 = bd[k + 1], t1 = bd[k + 2];
                 if ((rc = pdual(la, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, &q.dg1, t0 * B,
                                 nullptr, t0 * B, w.colsum_b + (int64_t)(t0 * B / 64) * 4 * H)))
                     return rc;
             }
         }
+        bias_chunk = emit ? 32 : 64;
         if ((rc = grads_ready(0, st))) return rc;                  // (see the bf16 branch below)
         if ((rc = handoff(st, sx, ev++))) return rc;
     } else if (pbf_bwd) {
@@ -493,7 +514,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if ((rc = pgemm_tt(la, 4 * H, H, (T - 1) * B, q.dg2, B, q.h2r, 0, g->word_w_hh, H, ID, nullptr, false))) return rc;
     if ((rc = pgemm_tt(la, 4 * H, H, T * B, q.dg2, 0, q.h1, 0, g->word_w_ih + E, E + H, ID, nullptr, false))) return rc;
     if ((rc = pgemm_tt(la, 4 * H, E, R, q.dg2, L * B, q.emb, 0, g->word_w_ih, E + H, ID, nullptr, false))) return rc;
-    if ((rc = colsum_finish(st, w.colsum_a, T * B / 64, 4 * H, g->word_b_ih, false))) return rc;
+    if ((rc = colsum_finish(st, w.colsum_a, T * B / bias_chunk, 4 * H, g->word_b_ih, false))) return rc;
     S2VT_HIP(hipMemcpyAsync(g->word_b_hh, g->word_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
     if ((rc = pgemm(la, R, E, 4 * H, q.dg2, L * B, 0, q.weT, 0, 0, w.de, E, ID, nullptr, false))) return rc;
     if ((rc = embedding_grad(st, w.de, R, E, w.tok, V, g->emb_w, w.embws))) return rc;
@@ -502,7 +523,7 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     const Lane lt = lb;
     if ((rc = pgemm_tt(lt, 4 * H, H, (T - 1) * B, q.dg1, B, q.h1, 0, g->vid_w_hh, H, ID, nullptr, false))) return rc;
     if ((rc = pgemm_tt(lt, 4 * H, H, L * B, q.dg1, 0, q.x1, 0, g->vid_w_ih, H, ID, nullptr, false))) return rc;
-    if ((rc = colsum_finish(lt.s, w.colsum_b, T * B / 64, 4 * H, g->vid_b_ih, false))) return rc;
+    if ((rc = colsum_finish(lt.s, w.colsum_b, T * B / bias_chunk, 4 * H, g->vid_b_ih, false))) return rc;
     S2VT_HIP(hipMemcpyAsync(g->vid_b_hh, g->vid_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, lt.s));
     // dx1 comes out in BATCH-major row order (the order of feats' rows, whose row planes the forward wrote): dW_f = dx1^T feats
     // reads both transposed - no time-major transposed copy of the features, no transposed dx1 (q.x1 is free: dW_ih1 is done)
@@ -721,6 +742,8 @@ static int train_backward_impl(const s2vt_dims* d, const s2vt_params* p, const f
 static int train_backward_core(const s2vt_dims* d, const s2vt_params* p, const float* feats, const float* dlogits,
                                const s2vt_grads* g, float* dfeats, void* workspace, size_t workspace_bytes, void* stream,
                                const float* out_mask) {
+    g_bwd_persist_launches = 0;          // (s2vt_backward_order describes THIS backward, whichever driver it takes)
+    g_bwd_group0_after = 0;
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;

@@ -196,6 +196,10 @@ struct SeqFwdX3Args {
     float* gx_stash; const float* bias; float* c_all;
     int no_stash;                                   // 1: the activated gates are not written back (inference: greedy decode)
     unsigned int* sync; int* err;
+    // optional (whole-path drivers, B % 64 == 0): h_t ALSO as the blocked 3-plane row image the batched GEMMs read (gemm_x3.hip
+    // layout: rows = t * B + b, k = unit, ld = 3 * pad64(H) elements) - the 16-byte slots of that image are the hand-off payload's
+    // own (plane, row, 8 units) pieces, so no split pass reads h back; the caller keeps the k16 records past 16 * ceil(H / 16) at zero
+    unsigned short* hblk; int64_t ldhblk;
     int RB, NS;                                     // set by the launcher
     unsigned long long* stamps; int stamp_block;    // timing experiments only (experiment.h); null in the product
 };
@@ -212,6 +216,13 @@ struct SeqBwdX3Args {
     float* dc;                                      // [B][H] dL/dc carried between launches (ignored when t1 == T)
     float* part; int64_t part_slot; int nslots;     // partial-sum ring [nslots][chains][nC][nC][32][16] fp32; nslots > t1 - t0
     unsigned int* sync; int* err;
+    // optional (whole-path driver; needs H % 8 == 0): dG_t ALSO leaves as the blocked 3-plane ROW image the batched GEMMs read
+    // (gemm_x3.hip layout: rows = t * B + b, k = g * H + u, ld = 3 * pad64(4H) elements; the caller keeps the k padding at
+    // zero) together with its column sums over each 32-row chain (the bias gradient's partial sums, colsum_finish over T * B / 32
+    // chunks): the tile is in LDS as planes anyway, so no split pass reads dG back.  skip_dg: the fp32 dG is then not stored.
+    unsigned short* dgp; int64_t lddgp;
+    float* colpart;                                 // [T * B / 32][4H]
+    int skip_dg;
     int RB, NS;                                     // set by the launcher
     unsigned long long* stamps; int stamp_block;    // timing experiments only (experiment.h); null in the product
 };

@@ -317,6 +317,16 @@ __device__ __forceinline__ void seq_fwd_x3_body(const SeqFwdX3Args& p, const int
                     }
                 }
             }
+            if (kq == 1 && p.hblk) {     // the same pieces into the batched GEMMs' row image (plain stores, beside wave 0's hand-off)
+                const int rl = lane >> 1, part = lane & 1;
+                const int64_t r = (int64_t)t * B + rbase + rl;
+                if (rbase + rl < B) {
+                    unsigned short* dst = p.hblk + (r >> 6) * (64 * p.ldhblk) + (int64_t)(u0 >> 4) * 3072 + part * 512 + (r & 63) * 8;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        *reinterpret_cast<u32x4*>(dst + pl * 1024) = *reinterpret_cast<const u32x4*>(hsm + pl * (X_SR * X_UN) + rl * X_UN + part * 8);
+                }
+            }
             XSTAMP(p.stamps, xrec, 7);
             if (kq == 0) {   // the ONE wave that stored the hand-off payload drains (those three stores only: its other stores
                              // of the step come after the signal) and signals for the workgroup
@@ -413,6 +423,8 @@ static int prep_x(SeqFwdX3Args& a, bool single = false) {
     S2VT_REQUIRE(ns > 0, "lstm_seq_fwd_x3_persist: unsupported shape (B %% 32, H <= 1024) or it does not fit the device's resident capacity");
     S2VT_REQUIRE(a.t1 > a.t0 && a.t0 >= 0 && a.wp && a.hp && a.h_all && a.gx_stash && a.c_all && a.sync && a.err && (a.bias || a.n_gx >= a.t1),
                  "lstm_seq_fwd_x3_persist: bad arguments");
+    S2VT_REQUIRE(!a.hblk || (a.B % 64 == 0 && a.ldhblk >= 3 * (int64_t)a.Kp && a.ldhblk % 8 == 0 && (reinterpret_cast<uintptr_t>(a.hblk) & 15) == 0),
+                 "lstm_seq_fwd_x3_persist: the h row image needs B %% 64 == 0 and rows of 3 * pad64(H) elements");
     S2VT_REQUIRE(a.Kp == (a.H + 63) / 64 * 64 && a.ldw >= a.Kp && a.ldh >= a.Kp && a.ldw % 8 == 0 && a.ldh % 8 == 0 &&
                      a.wplane % 8 == 0 && a.hplane % 8 == 0 && (reinterpret_cast<uintptr_t>(a.wp) & 15) == 0 &&
                      (reinterpret_cast<uintptr_t>(a.hp) & 15) == 0,
@@ -492,7 +504,8 @@ int split3_rows(hipStream_t stream, const float* src, int64_t ld, int R, int C, 
 constexpr int Y_GBUF = 64 * 2048;                 // gather buffer: up to 64 producer blocks of [32][16] fp32
 constexpr int Y_TILE = Y_GBUF;                    // own dG_t tile as planes [3][32 rows][64 k] bf16 (swizzled like a forward chunk)
 constexpr int Y_DCST = Y_TILE + 3 * X_PLANE;      // dL/dc carry of the workgroup's cells, per chain [32][16]
-constexpr int Y_LDS = Y_DCST + X_MAXNS * X_SR * X_UN * 4;     // 151552 B
+constexpr int Y_CSUM = Y_DCST + X_MAXNS * X_SR * X_UN * 4;    // per-wave column sums of the dG tile [4 waves][64 gate columns]
+constexpr int Y_LDS = Y_CSUM + 4 * 64 * 4;                    // 152576 B
 
 __device__ __forceinline__ void seq_bwd_x3_body(const SeqBwdX3Args& p, const int bid, unsigned char* smem, int& s_flag) {
     const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -663,23 +676,59 @@ __device__ __forceinline__ void seq_bwd_x3_body(const SeqBwdX3Args& p, const int
                         *reinterpret_cast<unsigned int*>(tile + pl * X_PLANE + tw[g]) = (unsigned int)pb[g][0][pl] | ((unsigned int)pb[g][1][pl] << 16);
                 if (rok) {
                     float* st = p.stash_dg + rowi * H4 + eunit;
+                    const bool keep = p.skip_dg == 0;
                     if (e_vec) {
+                        if (keep) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x2*>(st + (int64_t)g * H) = dg[g];
+                            for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x2*>(st + (int64_t)g * H) = dg[g];
+                        }
                         if (t == p.t0) *reinterpret_cast<f32x2*>(p.dc + (int64_t)eb * H + eunit) = dcn;
                     } else {
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
                             if (j ? e_ok1 : e_ok0) {
+                                if (keep) {
 #pragma unroll
-                                for (int g = 0; g < 4; ++g) st[(int64_t)g * H + j] = dg[g][j];
+                                    for (int g = 0; g < 4; ++g) st[(int64_t)g * H + j] = dg[g][j];
+                                }
                                 if (t == p.t0) p.dc[(int64_t)eb * H + eunit + j] = dcn[j];
                             }
+                    }
+                }
+                if (p.colpart) {    // column sums of the tile over its 32 rows: 8 rows per wave by shuffles, the 4 waves through LDS
+                    float* cs_w = reinterpret_cast<float*>(smem + Y_CSUM) + kw * 64;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x2 v = dg[g];
+#pragma unroll
+                        for (int off = 8; off < 64; off <<= 1) { v[0] += __shfl_xor(v[0], off); v[1] += __shfl_xor(v[1], off); }
+                        if (lane < 8) *reinterpret_cast<f32x2*>(cs_w + g * 16 + eul) = v;
                     }
                 }
             }
             XSTAMP(p.stamps, xrec, 5);
             X_BARRIER();           // the dG_t tile is complete (and everyone is done with the gather buffer)
+            // dG_t as the batched GEMMs' row image + its 32-row column sums: issued BEHIND the hand-off (t > 0: after the signal)
+            auto emit_planes = [&]() {
+                if (p.colpart && kw == 0) {
+                    const int g = lane >> 4, u = lane & 15;
+                    const float* cs0 = reinterpret_cast<const float*>(smem + Y_CSUM) + lane;
+                    const float sum = ((cs0[0] + cs0[64]) + cs0[128]) + cs0[192];
+                    if (u0 + u < H) p.colpart[((int64_t)t * (B / X_SR) + chain) * H4 + (int64_t)g * H + u0 + u] = sum;
+                }
+                if (p.dgp) {
+                    const int row = tid >> 3, p8 = tid & 7;                 // piece p8 = gate 2 bits, unit octet 1 bit
+                    const int gq = p8 >> 1, k0 = gq * H + u0 + (p8 & 1) * 8;
+                    const int64_t r = (int64_t)t * B + rbase + row;
+                    if (rbase + row < B && u0 + (p8 & 1) * 8 < H) {
+                        unsigned short* dst = p.dgp + (r >> 6) * (64 * p.lddgp) + (int64_t)(k0 >> 4) * 3072 + ((k0 >> 3) & 1) * 512 + (r & 63) * 8;
+                        const unsigned char* src = tile + row * 128 + ((p8 ^ ((row >> 1) & 7)) * 16);
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            *reinterpret_cast<u32x4*>(dst + pl * 1024) = *reinterpret_cast<const u32x4*>(src + pl * X_PLANE);
+                    }
+                }
+            };
 
             if (t > 0) {           // partial products of dG_t for step t - 1 (nobody consumes those of step 0)
                 float* pslot = p.part + (int64_t)((t - 1) % p.nslots) * p.part_slot + ((int64_t)chain * nC * nC + cs) * (X_SR * X_UN)
@@ -739,7 +788,10 @@ __device__ __forceinline__ void seq_bwd_x3_body(const SeqBwdX3Args& p, const int
                 X_BARRIER();
                 if (tid == 0) __hip_atomic_fetch_add((gu32*)cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 XSTAMP(p.stamps, xrec, 8);
+                emit_planes();
+                if (p.dgp || p.colpart) X_BARRIER();       // (the tile and the column sums are rewritten by the next sub-step's cells)
             } else {
+                emit_planes();
                 X_BARRIER();
             }
         }
@@ -796,6 +848,10 @@ static int prep_y(SeqBwdX3Args& a) {
                  "lstm_seq_bwd_x3_persist: W_hh^T planes must be [3][Kp][4 Hp], 16-byte aligned");
     S2VT_REQUIRE(a.nslots > a.t1 - a.t0 && (size_t)a.part_slot >= lstm_seq_bwd_x3_part_slot_floats(a.B, a.H) && a.part_slot % 4 == 0,
                  "lstm_seq_bwd_x3_persist: the partial-sum ring needs more slots than the launch has timesteps");
+    S2VT_REQUIRE(!a.dgp || (a.H % 8 == 0 && a.B % 64 == 0 && a.lddgp >= 3 * (int64_t)((4 * a.H + 63) / 64 * 64) && a.lddgp % 8 == 0 &&
+                            (reinterpret_cast<uintptr_t>(a.dgp) & 15) == 0),
+                 "lstm_seq_bwd_x3_persist: the dG row image needs H %% 8 == 0, B %% 64 == 0 and rows of 3 * pad64(4H) elements");
+    S2VT_REQUIRE(!a.skip_dg || a.dgp, "lstm_seq_bwd_x3_persist: skip_dg without a plane image");
     a.NS = ns;
     a.RB = ns * X_SR;
     return 0;

@@ -17,7 +17,7 @@ static const OptionDef kOptions[O_COUNT] = {
     /* O_GEMM_MODE      */ {"gemm_mode", 3, 0, 3},          // 3 split precision (fp32-equivalent), 1 bf16 operands, 0 exact-fp32 MFMA
     /* O_PERSIST        */ {"persist", 1, 0, 1},            // persistent recurrence kernels (0: launches per timestep everywhere)
     /* O_PERSIST_X3_FWD */ {"persist_x3_fwd", 1, 0, 1},     // split-precision persistent forward (gemm mode 3)
-    /* O_PERSIST_X3_BWD */ {"persist_x3_bwd", 0, 0, 1},     // split-precision persistent BPTT, both layers per launch, one stream
+    /* O_PERSIST_X3_BWD */ {"persist_x3_bwd", 2, 0, 2},     // split-precision persistent BPTT: 0 off, 1 on, 2 where one chain per workgroup fits (B = 64)
     /* O_PIPE_BLOCK     */ {"pipe_block", 32, 0, 4096},     // timesteps per pipeline block (0: one stream, no layer pipeline)
     /* O_GRAPH          */ {"graph", 0, 0, 1},              // hipGraph replay of the train forward / backward launch sequences
     /* O_DECODE_FUSED   */ {"decode_fused", 1, 0, 1},       // greedy decode: recurrent GEMM inside the argmax launch
