@@ -151,6 +151,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="batch per GPU (BASELINE configs[1]: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--optimizer", default="flat", choices=["flat", "torch"],
+                    help="flat: s2vt_adam_step over flat buffers (optim.FlatAdam, what train.py uses); torch: torch.optim.Adam(fused=True)")
     ap.add_argument("--decode-batch", type=int, default=None, help="greedy-decode batch (default 128 = BASELINE configs[4])")
     ap.add_argument("--gemm-mode", type=int, default=None, choices=[0, 1, 3],
                     help="0 fp32-input MFMA, 3 split-precision bf16x3 (default, fp32-equivalent), 1 bf16 operands "
@@ -210,11 +212,12 @@ def main():
     model.load_state_dict(sd)
     model.to(dev)
     crit = utils.MaskCriterion()
-    try:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
-    except Exception:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     reducer = dp.FlatGradAllReducer(model.parameters()).attach(model) if use_pg else None
+    if args.optimizer == "flat":        # train.py:89-93's Adam as one launch over flat buffers (optim.py), what train.py of this repo uses
+        from s2vt_video_caption_amd.optim import FlatAdam
+        opt = FlatAdam(model, lr=1e-4, reducer=reducer)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
 
     # this rank's shard of the synthetic global batch (seeded recipe); resident in HBM
     feats, caps, mask = synth.make_batch(B, L, F, V, seed=1234 + rank)
@@ -679,7 +682,10 @@ def main():
             md = S2VTModel.S2VT(V, F, L, dim_hid=Hd, dim_embed=Hd)
             md.load_state_dict(sd_d)
             md.to(dev)
-            optd = torch.optim.Adam(md.parameters(), lr=1e-4, fused=True)
+            if args.optimizer == "flat":
+                optd = FlatAdam(md, lr=1e-4)
+            else:
+                optd = torch.optim.Adam(md.parameters(), lr=1e-4, fused=True)
             bd_ = tuple(t.to(dev) for t in synth.make_batch(Bt, L, F, V, seed=778))
             fe = synth.make_batch(Be, L, F, V, seed=779)[0].to(dev)
 
@@ -804,6 +810,8 @@ def main():
                                         "step_bwd": round(live["step_bwd"][2], 3), "ce": round(live["ce"][2], 3)},
             "kernel_ms_per_step_isolated": {k: round(v, 3) for k, v in fam_alone.items()} if fam_alone else None,
             "recurrence_plan": {"forward": plan[0], "bptt": plan[1], "kinds": "0 launch per timestep, 1 persistent bf16, 3 persistent split precision"},
+            "optimizer": "optim.FlatAdam (s2vt_adam_step: torch.optim.Adam's arithmetic, one launch over flat buffers)" if args.optimizer == "flat"
+                         else "torch.optim.Adam(fused=True)",
             "options": {lib.s2vt_option_name(i).decode(): int(lib.s2vt_set_option(lib.s2vt_option_name(i), -1)) for i in range(lib.s2vt_option_count())},
             "decode": decode,
             "beam": beam,

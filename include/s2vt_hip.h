@@ -189,6 +189,15 @@ int s2vt_greedy_decode_cached(const s2vt_dims* d, const s2vt_params* p, const fl
                               void* workspace, size_t workspace_bytes, void* cache, size_t cache_bytes, int32_t cache_valid,
                               void* stream);
 
+/* optimizer.step() of the reference's loop (train.py:89-93,126: torch.optim.Adam, default betas / eps, no weight decay, no
+ * amsgrad) as ONE launch over flat fp32 buffers of n elements - every parameter, its gradient and its two moments at the same
+ * offsets (s2vt-video-caption_amd/optim.py lays a model's parameters out that way).  torch's arithmetic operation for operation:
+ * m += (g - m)(1 - beta1); v = beta2 v + (1 - beta2) g g; p -= lr / (1 - beta1^step) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps).
+ * step counts from 1; the hyper-parameters are doubles because torch forms 1 - beta and the bias corrections from the Python doubles
+ * before rounding to fp32 once. */
+int s2vt_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
+                   double eps, int64_t step, void* stream);
+
 /* MaskCriterion's inner nn.CrossEntropyLoss() (utils.py:11,22): mean CE of logits [B, L-1, V] against
  * target[:, 1:] (target int64 [B, L], row stride target_ld).  lse [B*(L-1)] and rowloss [B*(L-1)] are
  * caller-provided scratch (lse is consumed by the backward); loss_out is one device float.

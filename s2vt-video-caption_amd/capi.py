@@ -63,6 +63,7 @@ SIGNATURES = {
     "s2vt_decode_uses_cache": (c_int32, [POINTER(Dims)]),
     "s2vt_greedy_decode_cached": (c_int32, [POINTER(Dims), POINTER(Params), c_void_p, c_int32, c_void_p, c_void_p, c_size_t,
                                             c_void_p, c_size_t, c_int32, c_void_p]),
+    "s2vt_adam_step": (c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_double, c_double, c_double, c_double, c_int64, c_void_p]),
     "s2vt_mean_ce_forward": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
     "s2vt_mean_ce_backward": (c_int32, [c_int32, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p,

@@ -7,6 +7,12 @@ using namespace s2vt;
 extern "C" {
 
 // ------------------------------------------------------------------ loss
+// torch.optim.Adam.step() of train.py:126 over flat buffers (see adam_flat in misc.hip)
+int s2vt_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1, double beta2,
+                   double eps, int64_t step, void* stream) {
+    return adam_flat((hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step);
+}
+
 int s2vt_mean_ce_forward(int32_t B, int32_t Lm1, int32_t V, const float* logits, const int64_t* target,
                          int64_t target_ld, float* lse, float* rowloss, float* loss_out, void* stream) {
     S2VT_REQUIRE(B > 0 && Lm1 > 0 && V > 0, "s2vt_mean_ce_forward: bad dims");

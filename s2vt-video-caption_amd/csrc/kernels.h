@@ -262,6 +262,8 @@ int logits_argmax_x3(hipStream_t stream, const ArgmaxX3Args& a);
 
 // ---- misc.hip
 int add_vectors(hipStream_t s, const float* a, const float* b, float* out, int n);
+int adam_flat(hipStream_t s, float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+              int64_t step);
 int mul_vectors(hipStream_t s, const float* a, const float* b, float* out, int64_t n);
 int transpose_f32(hipStream_t s, const float* in, int rows, int cols, float* out);   // out[cols][rows]
 int colsum_f32(hipStream_t s, const float* x, int64_t rows, int cols, int64_t ld, float* partial, float* out,

@@ -1,6 +1,7 @@
 // Small memory-bound helpers around the S2VT contractions: bias sums, the W_hh transpose used by
 // BPTT, deterministic column sums (bias gradients), caption index conversion, the embedding
 // scatter-add (autograd of S2VTModel.py:71) and unpacking of the decode argmax words.
+#include <math.h>
 #include "common.h"
 #include "kernels.h"
 
@@ -69,6 +70,55 @@ int scale_by_device_scalar(hipStream_t s, float* x, int64_t n, const float* alph
     const int64_t n4 = n / 4;
     hipLaunchKernelGGL(scale_by_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, s, x, n4, n, alpha);
     S2VT_LAUNCH_CHECK("scale_by_kernel");
+    return 0;
+}
+
+// Adam step (train.py:89-93 -> torch.optim.Adam defaults; train.py:126 optimizer.step()) over ONE flat fp32 buffer holding all
+// parameters, with flat gradient / first / second moment buffers of the same length: one memory-bound launch (28 bytes per
+// parameter) instead of the framework's multi-tensor launches.  torch.optim.Adam's arithmetic, operation for operation:
+//   m = m + (g - m) (1 - b1)              (Tensor.lerp_)
+//   v = b2 v + (1 - b2) g g
+//   p = p - (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// (weight_decay 0, amsgrad off, maximize off: the reference's configuration).  The bias corrections arrive as host doubles
+// rounded to fp32 once, and so do 1 - b1 and 1 - b2 (torch forms them from the Python doubles), which is why the hyper-parameters
+// cross the C ABI as doubles.
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int64_t n4, int64_t n, float w1, float beta2, float w2,
+                                                        float step_size, float bc2_sqrt, float eps) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    auto upd = [&](float& pp, float gg, float& mm, float& vv) {
+        mm = mm + (gg - mm) * w1;
+        vv = beta2 * vv + w2 * gg * gg;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        pp = pp - step_size * (mm / denom);
+    };
+    if (i < n4) {
+        f32x4 pv = reinterpret_cast<f32x4*>(p)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float pp = pv[j], mm = mv[j], v2 = vv[j];
+            upd(pp, gv[j], mm, v2);
+            pv[j] = pp, mv[j] = mm, vv[j] = v2;
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pv;
+        reinterpret_cast<f32x4*>(m)[i] = mv;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    } else if (i == n4) {
+        for (int64_t j = 4 * n4; j < n; ++j) upd(p[j], g[j], m[j], v[j]);
+    }
+}
+int adam_flat(hipStream_t s, float* p, const float* g, float* m, float* v, int64_t n, double lr, double beta1, double beta2, double eps,
+              int64_t step) {
+    if (n <= 0) return 0;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    S2VT_REQUIRE(p && g && m && v && al(p) && al(g) && al(m) && al(v) && step >= 1, "adam_flat: null / unaligned buffers or step < 1");
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
+    const int64_t n4 = n / 4;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n4 + 1 + 255) / 256)), dim3(256), 0, s, p, g, m, v, n4, n, (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), step_size, bc2_sqrt, (float)eps);
+    S2VT_LAUNCH_CHECK("adam_flat_kernel");
     return 0;
 }
 

@@ -527,6 +527,64 @@ def test_mask_criterion_is_the_reference_arithmetic(lib, B, Lm1, V, kind):
         assert float(loss3) == float(loss)
 
 
+@pytest.mark.parametrize("n", [1, 5, 4096, 1000003])
+def test_flat_adam_step_is_torch_adam(lib, n):
+    """s2vt_adam_step against torch.optim.Adam (the reference's optimizer, train.py:89-93) on the CPU, five steps with fresh
+    gradients each: the same arithmetic operation for operation, so within a couple of fp32 roundings of the update."""
+    import ctypes
+    g = torch.Generator().manual_seed(n)
+    p0 = torch.randn(n, generator=g)
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = p0.to(DEV)
+    m = torch.zeros(n, device=DEV)
+    v = torch.zeros(n, device=DEV)
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * (10.0 ** float(torch.randint(-4, 2, (1,), generator=g)))
+        ref.grad = grad.clone()
+        opt.step()
+        gd = grad.to(DEV)
+        rc = lib.s2vt_adam_step(ptr(p), ptr(gd), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, step, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        st = opt.state[ref]
+        assert (m.cpu() - st["exp_avg"]).abs().max().item() <= 4e-7 * st["exp_avg"].abs().max().item()
+        assert (v.cpu() - st["exp_avg_sq"]).abs().max().item() <= 4e-7 * st["exp_avg_sq"].abs().max().item()
+        assert (p.cpu() - ref.detach()).abs().max().item() <= 4e-7 * step       # updates of ~1e-3 each, parameters of O(1)
+    assert lib.s2vt_adam_step(ptr(p), ptr(gd), ptr(m), ptr(v), n, 1e-3, 0.9, 0.999, 1e-8, 0, None) != 0     # steps count from 1
+
+
+def test_flat_adam_trains_the_model_as_torch_adam_does(lib):
+    """optim.FlatAdam (parameters / gradients / moments in flat buffers, one launch per step) against torch.optim.Adam over four
+    train steps of one small model: same losses, same parameters; state_dict keys and shapes unchanged by the flattening."""
+    import S2VTModel, utils
+    from s2vt_video_caption_amd import dp, optim, synth
+    L, Fd, H, E, V, B = 12, 64, 96, 80, 200, 16
+    sd = synth.make_state_dict(V, Fd, H, E, seed=5)
+    feats, caps, mask = (t.to(DEV) for t in synth.make_batch(B, L, Fd, V, seed=6))
+    crit = utils.MaskCriterion()
+    runs = []
+    for kind in ("torch", "flat"):
+        m = S2VTModel.S2VT(V, Fd, L, dim_hid=H, dim_embed=E)
+        m.load_state_dict(sd)
+        m.to(DEV)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3) if kind == "torch" else optim.FlatAdam(m, lr=1e-3)
+        losses = [float(dp.train_step(m, crit, opt, feats, caps, mask, None)) for _ in range(4)]
+        runs.append((losses, {k: t.detach().cpu().clone() for k, t in m.state_dict().items()}))
+        if kind == "flat":
+            assert all(p.grad is not None and p.grad.data_ptr() >= opt.flat_g.data_ptr() for p in m.parameters())
+            ids = m(feats, mode="test")                      # the decode sees the updated weights (version counters were bumped)
+            m2 = S2VTModel.S2VT(V, Fd, L, dim_hid=H, dim_embed=E)
+            m2.load_state_dict(m.state_dict())
+            assert torch.equal(ids, m2.to(DEV)(feats, mode="test"))
+    (l0, s0), (l1, s1) = runs
+    assert l0[0] > l0[-1] and max(abs(a - b) for a, b in zip(l0, l1)) < 2e-5
+    assert list(s0) == list(s1)
+    for k in s0:
+        assert s0[k].shape == s1[k].shape and (s0[k] - s1[k]).abs().max().item() < 2e-5, k
+
+
 @pytest.mark.parametrize("planes", [False, True])
 def test_decode_argmax_first_max_wins(lib, planes):
     from s2vt_video_caption_amd import ops as _ops

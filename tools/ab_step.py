@@ -71,8 +71,11 @@ def main():
         crit = OldCriterion() if st["crit"] == "old" else utils.MaskCriterion()
         if st["opt"] == "hip":
             from s2vt_video_caption_amd import optim
-            opt = optim.FlatAdam(model.parameters(), lr=1e-4)
+            opt = optim.FlatAdam(model, lr=1e-4)
         else:
+            F_.set_grad_sink(model, None)
+            for p in model.parameters():
+                p.grad = None
             opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
         return crit, opt
 

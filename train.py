@@ -109,16 +109,20 @@ def run(opt):
     if opt.init_state:
         model.load_state_dict(torch.load(opt.init_state))
     model.to(dev)
-    optimizer = optim.Adam(model.parameters(), lr=opt.lr)                                           # train.py:89-93
-    lr_scheduler = optim.lr_scheduler.ReduceLROnPlateau(optimizer, patience=opt.learning_rate_patience)   # :95-97
-    early_stopping = EarlyStopping(patience=opt.early_stopping_patience, verbose=rank == 0,
-                                   path=os.path.join(opt.save_path, start_time + 'stop.pth'))        # :98-100
-    criterion = MaskCriterion()
     reducer = None
     if world > 1:       # S2VT: gradients written straight into the flat buffer, all-reduce overlapped with the backward;
         reducer = dp.FlatGradAllReducer(model.parameters())            # Att_Baseline: plain bucketed all-reduce after it
         if opt.model == "s2vt":
             reducer.attach(model)
+    if opt.model == "s2vt":     # train.py:89-93's Adam, same arithmetic, as one launch over flat parameter / gradient / moment buffers
+        from s2vt_video_caption_amd.optim import FlatAdam
+        optimizer = FlatAdam(model, lr=opt.lr, reducer=reducer)
+    else:
+        optimizer = optim.Adam(model.parameters(), lr=opt.lr)                                       # train.py:89-93
+    lr_scheduler = optim.lr_scheduler.ReduceLROnPlateau(optimizer, patience=opt.learning_rate_patience)   # :95-97
+    early_stopping = EarlyStopping(patience=opt.early_stopping_patience, verbose=rank == 0,
+                                   path=os.path.join(opt.save_path, start_time + 'stop.pth'))        # :98-100
+    criterion = MaskCriterion()
     hist = {"train_loss": [], "valid_loss": [], "lr": [], "stopped_at": None, "checkpoints": []}
 
     def save(name):
