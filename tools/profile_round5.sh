@@ -1,10 +1,10 @@
-# Round-4 profiles (run on the GPU box through gpurun; S2VT_COMMIT = the commit the tree was built from).
-#   usage (gpurun command): S2VT_COMMIT=<sha> bash tools/profile_round4.sh [stats] [pmc] [traffic]
+# Round-5 profiles (run on the GPU box through gpurun; S2VT_COMMIT = the commit the tree was built from).
+#   usage (gpurun command): S2VT_COMMIT=<sha> bash tools/profile_round5.sh [stats] [pmc] [traffic]
 # stats:   rocprofv3 --kernel-trace --stats of the bench command for config 2 / config 3 and of one greedy decode
 # pmc:     SQ / GRBM counter passes (matrix-pipe busy, wait / issue-stall shares, LDS conflicts, instruction mix) over
 #          tools/prof_path.py c2 (+ decode at B = 64), c3, c5 --decode (B = 128) and tools/prof_beam_device.py: counters only, program directly after --
 # traffic: FETCH_SIZE / WRITE_SIZE / L2 passes (tools/pmc_traffic.py)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && export OUT=${OUT:-prof_r4} && mkdir -p gpurun_out/$OUT && . tools/gpu/run_steps.sh
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && export OUT=${OUT:-prof_r5} && mkdir -p gpurun_out/$OUT && . tools/gpu/run_steps.sh
 WHAT="${*:-stats pmc traffic}"
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
 SQ2="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU"
