@@ -391,27 +391,41 @@ def main():
 
         # HBM traffic per launch from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_traffic.sh), committed
         # under profiles/ — counters cannot be collected from inside this process.  Only valid for the default workload.
-        def load_pmc(tag):
-            """(kernels, provenance) of the committed PMC traffic file of this workload; STATIC data: the file names the
-            commit it was measured at, and a kernel changed since then carries a stale figure until the passes are re-run
-            (tools/profile_round3.sh)."""
-            for rnd in ("round4", "round3", "round2"):
-                path = os.path.join(ROOT, "profiles", "%s_traffic_pmc_%s.json" % (rnd, tag))
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import source_digest
+
+        def load_static(pattern, tag):
+            """(kernels, provenance, all-kernel totals) of the newest committed counter file of this workload.  STATIC data (counters
+            cannot be collected from inside this process): the file names the commit it was measured at and carries the sha1 of every
+            kernel source of that tree; a kernel whose source changed since then is DROPPED (tools/source_digest.py), and a file
+            without digests (collected before round 5) is quoted with `unverified: true`."""
+            for rnd in ("round5", "round4"):
+                path = os.path.join(ROOT, "profiles", pattern % (rnd, tag))
                 try:
                     j = json.load(open(path))
-                    return j["kernels"], {"static": "profiles/%s@%s" % (os.path.basename(path), j.get("commit", "unrecorded"))}
                 except Exception:
                     continue
-            return {}, None
+                src = {"static": "profiles/%s@%s" % (os.path.basename(path), j.get("commit", "unrecorded"))}
+                dig = j.get("source_digests")
+                if not dig:
+                    src["unverified"] = True
+                    return j["kernels"], src, j.get("all_kernels")
+                stale = {k: source_digest.stale_sources(dig, k) for k in j["kernels"]}
+                dropped = sorted(k for k, v in stale.items() if v)
+                if dropped:
+                    src["dropped_as_stale"] = {k: stale[k] for k in dropped}
+                tot = j.get("all_kernels") if not any(source_digest.digests().get(f) != h for f, h in dig.items()) else None
+                return {k: v for k, v in j["kernels"].items() if not stale[k]}, src, tot
+            return {}, None, None
+
+        def load_pmc(tag):
+            k, src, _ = load_static("%s_traffic_pmc_%s.json", tag)
+            return k, src
+
         def load_busy(tag):
-            """Matrix-pipe busy share and wave-state shares per kernel from the committed SQ counter passes (profiles/round4_pmc_<tag>.json,
-            tools/profile_round4.sh pmc): STATIC data like `traffic`, tagged with the commit it was measured at."""
-            path = os.path.join(ROOT, "profiles", "round4_pmc_%s.json" % tag)
-            try:
-                j = json.load(open(path))
-                return j["kernels"], {"static": "profiles/%s@%s" % (os.path.basename(path), j.get("commit", "unrecorded"))}
-            except Exception:
-                return {}, None
+            """Matrix-pipe busy share and wave-state shares per kernel from the SQ counter passes (tools/profile_round5.sh pmc)"""
+            k, src, _ = load_static("%s_pmc_%s.json", tag)
+            return k, src
 
         def busy_of(table, src, kernel):
             """{mfma_busy (dispatch-weighted over the template instantiations), per-instantiation figures, provenance} for `kernel`."""
@@ -780,6 +794,21 @@ def main():
                              "Adam(lr=1e-4); greedy: one call" % (Bc, ncpu),
                    "ms_per_step": round(cdt * 1e3, 1), "greedy_captions_per_s": round(Bc / gdt, 2)}
 
+        # HBM-side bytes of a whole optimisation step (every dispatch, PMC passes of tools/profile_round5.sh traffic) beside what the step
+        # has to move whatever the kernels do: inputs, logits out and back in, parameters in, gradients out, Adam (28 B / parameter)
+        hbm_step = None
+        if world == 1 and ((B == 64 and x3) or (B == 256 and bf)):
+            _, tsrc, tot = load_static("%s_traffic_pmc_%s.json", "c2" if x3 else "c3")
+            n_par = sum(p_.numel() for p_ in model.parameters())
+            compulsory = 4 * (B * L * F + 2 * B * (L - 1) * V + 2 * n_par) + 28 * n_par
+            hbm_step = {"pmc_bytes": int(tot["hbm_bytes_per_pass"]) if tot else None,
+                        "pmc_gbs_over_the_step": round(tot["hbm_bytes_per_pass"] / (dt / args.steps) / 1e9, 1) if tot else None,
+                        "source": tsrc if tot else ({"dropped": "a kernel source changed since the counters were collected", **(tsrc or {})}),
+                        "compulsory_bytes": int(compulsory),
+                        "algorithmic_bytes_8d_recurrence": int(2 * T * pair_bytes / 2),
+                        "note": "pmc_bytes: FETCH_SIZE x 2 + WRITE_SIZE of every dispatch of one step; compulsory_bytes: feats read, logits "
+                                "written and read, parameters read, gradients written, Adam's 28 B per parameter; algorithmic_bytes_8d_recurrence: "
+                                "SURVEY 8(d)'s streaming model of the 318 layer timesteps, which the persistent kernels do not move (W_hh stays in registers)"}
         out = {
             "metric": "training frames/sec (whole node)", "value": round(frames_per_s, 1), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -809,6 +838,7 @@ def main():
             "kernel_busy_ms_per_step": {"gemm": round(live["gemm"][2], 3), "step_fwd": round(live["step_fwd"][2], 3),
                                         "step_bwd": round(live["step_bwd"][2], 3), "ce": round(live["ce"][2], 3)},
             "kernel_ms_per_step_isolated": {k: round(v, 3) for k, v in fam_alone.items()} if fam_alone else None,
+            "hbm_bytes_per_step": hbm_step,
             "recurrence_plan": {"forward": plan[0], "bptt": plan[1], "kinds": "0 launch per timestep, 1 persistent bf16, 3 persistent split precision"},
             "optimizer": "optim.FlatAdam (s2vt_adam_step: torch.optim.Adam's arithmetic, one launch over flat buffers)" if args.optimizer == "flat"
                          else "torch.optim.Adam(fused=True)",

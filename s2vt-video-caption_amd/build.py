@@ -29,7 +29,7 @@ def needs_build():
 
 def build(force=False, verbose=False, defines=(), out_path=None):
     """Compile every HIP source for gfx950 and link the shared library. Returns its path.
-    `defines`/`out` build an experimental variant (tools/bench_step.py) next to the product library."""
+    `defines`/`out` build an experimental variant (the in-kernel stamp tools, tools/bench_*_stamps.py) next to the product library."""
     if out_path is None and not force and not needs_build():
         return LIB
     objdir = os.path.join(HERE, "build" if out_path is None else "build_" + os.path.basename(out_path))

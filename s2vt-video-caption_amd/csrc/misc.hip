@@ -238,24 +238,20 @@ __device__ __forceinline__ int eg_compact(bool hit, int r, int* list, int n_list
     __syncthreads();
     return n_list + total;
 }
-// (<pad> / <eos> fill most caption rows: counted straight into global memory their thousands of same-address atomics
-// serialise - 0.2 ms at B = 256 - so every workgroup first counts its slice of the rows in an LDS histogram and adds each
-// bin it touched once)
-constexpr int EC_LDS_BINS = 16000;          // 62.5 KB of dynamic LDS: vocabularies up to this size take the histogram path
-__global__ __launch_bounds__(256) void emb_count_kernel(const int32_t* tok, int rows, int V, int per_wg, int* count) {
-    extern __shared__ int hist[];
-    const int r0 = blockIdx.x * per_wg, r1 = (r0 + per_wg < rows) ? r0 + per_wg : rows;
-    if (V > EC_LDS_BINS) {
-        for (int r = r0 + threadIdx.x; r < r1; r += 256) atomicAdd(&count[tok[r]], 1);
-        return;
-    }
-    for (int v = threadIdx.x; v < V; v += 256) hist[v] = 0;
-    __syncthreads();
-    for (int r = r0 + threadIdx.x; r < r1; r += 256) atomicAdd(&hist[tok[r]], 1);
-    __syncthreads();
-    for (int v = threadIdx.x; v < V; v += 256) {
-        const int c = hist[v];
-        if (c) atomicAdd(&count[v], c);
+// (<pad> / <eos> fill most caption rows: counted one atomic per row their thousands of same-address atomics serialise - 0.2 ms
+// at B = 256 - and an LDS histogram per workgroup pays for zeroing and flushing V bins: 91 us at B = 64.  Every wave aggregates its 64
+// rows first: the lowest lane still uncounted names its token, the lanes holding the same token are counted by one ballot and
+// retire - one global atomic per DISTINCT token of a wave, a handful of rounds for caption data)
+__global__ __launch_bounds__(256) void emb_count_kernel(const int32_t* tok, int rows, int* count) {
+    const int r = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    const int mine = (r < rows) ? tok[r] : -1;
+    unsigned long long todo = __ballot(mine >= 0);
+    while (todo) {                                            // (wave-uniform)
+        const int leader = __ffsll((long long)todo) - 1;
+        const int t = __shfl(mine, leader);
+        const unsigned long long same = __ballot(mine == t);
+        if (lane == leader) atomicAdd(&count[t], __popcll(same));
+        todo &= ~same;
     }
 }
 __global__ __launch_bounds__(256) void emb_grad_kernel(const float* d_rows, int rows, int E, const int32_t* tok, float* d_emb,
@@ -348,9 +344,7 @@ int embedding_grad(hipStream_t s, const float* d_rows, int64_t rows, int E, cons
     int* count = n_heavy + 1;
     S2VT_HIP(hipMemsetAsync(n_heavy, 0, sizeof(int) * (size_t)(1 + V), s));
     if (rows > 0) {
-        const int per_wg = 512;             // 40 workgroups at B = 256: zeroing and flushing the V bins is the fixed cost of each
-        const size_t lds = (V <= EC_LDS_BINS) ? sizeof(int) * (size_t)V : 0;
-        hipLaunchKernelGGL(emb_count_kernel, dim3(cdiv((int)rows, per_wg)), dim3(256), lds, s, tok, (int)rows, V, per_wg, count);
+        hipLaunchKernelGGL(emb_count_kernel, dim3(cdiv((int)rows, 256)), dim3(256), 0, s, tok, (int)rows, count);
     }
     S2VT_LAUNCH_CHECK("emb_count_kernel");
     hipLaunchKernelGGL(emb_grad_kernel, dim3((unsigned)V), dim3(256), 0, s, d_rows, (int)rows, E, tok, d_emb, ws, n_heavy, count);

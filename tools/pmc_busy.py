@@ -56,7 +56,9 @@ for n, c in sorted(acc.items()):
         if ctr in m:
             e[key] = round(m[ctr], 1)
     out[n] = e
-print(json.dumps({"commit": os.environ.get("S2VT_COMMIT", "unrecorded"),
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import source_digest  # noqa: E402
+print(json.dumps({"commit": os.environ.get("S2VT_COMMIT", "unrecorded"), "source_digests": source_digest.digests(),
                   "source": "rocprofv3 --pmc (SQ / GRBM passes, counters only, program directly after --): %s" % what,
                   "kernels": out}, indent=1))
 for n, e in out.items():

@@ -10,10 +10,18 @@ import sys
 
 d = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
+total = collections.defaultdict(float)          # every kernel of the passes, whatever its family: HBM-side bytes of a whole pass
+nrows = collections.defaultdict(int)
 for tag in ("fetch", "write", "l2"):
     for f in glob.glob(os.path.join(d, tag + "*_counter_collection.csv")):
-        for r in csv.DictReader(open(f)):
+        rows = list(csv.DictReader(open(f)))
+        # the passes start at the library's first dispatch: what comes before (moving the model, the optimizer's flat buffers) is set-up
+        first = min((int(r["Dispatch_Id"]) for r in rows if "s2vt::" in r["Kernel_Name"]), default=0)
+        for r in rows:
             n = r["Kernel_Name"]
+            if int(r["Dispatch_Id"]) >= first:
+                total[r["Counter_Name"]] += float(r["Counter_Value"])
+                nrows[r["Counter_Name"]] += 1
             fam = None
             for key in ("gemm_x3_kernel", "gemm_f32_kernel", "gemm_b1_kernel", "lstm_step_fwd_kernel", "lstm_step_bwd_kernel",
                         "lstm_step_fwd_bf16_kernel", "lstm_step_bwd_bf16_kernel", "lstm_seq_fwd_bf16_persist_kernel",
@@ -47,6 +55,17 @@ for fam, c in acc.items():
     out[fam] = e
 what = sys.argv[2] if len(sys.argv) > 2 else "c2"
 commit = os.environ.get("S2VT_COMMIT", "unrecorded")
-print(json.dumps({"commit": commit, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum (separate passes), tools/prof_path.py %s "
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import source_digest  # noqa: E402
+iters_ = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+step_total = None
+if total.get("FETCH_SIZE") and total.get("WRITE_SIZE"):
+    # every dispatch of the profiled program (library kernels, torch's, runtime fills and copies), FETCH_SIZE doubled throughout
+    # (the guide's correction for wide streaming reads: an upper bound where a kernel reads narrow), per pass of the driver
+    step_total = {"passes": iters_, "dispatches_per_pass": nrows["FETCH_SIZE"] / iters_,
+                  "fetch_bytes_corrected_per_pass": 2 * total["FETCH_SIZE"] * 1024 / iters_,
+                  "write_bytes_per_pass": total["WRITE_SIZE"] * 1024 / iters_,
+                  "hbm_bytes_per_pass": (2 * total["FETCH_SIZE"] + total["WRITE_SIZE"]) * 1024 / iters_}
+print(json.dumps({"commit": commit, "source_digests": source_digest.digests(), "all_kernels": step_total, "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum (separate passes), tools/prof_path.py %s "
                             "(train forward+backward passes), FETCH_SIZE doubled per MI355X_MICROARCH.md" % what,
                   "kernels": out}, indent=1))

@@ -2,7 +2,7 @@
 #   usage (gpurun command): S2VT_COMMIT=<sha> bash tools/profile_round5.sh [stats] [pmc] [traffic]
 # stats:   rocprofv3 --kernel-trace --stats of the bench command for config 2 / config 3 and of one greedy decode
 # pmc:     SQ / GRBM counter passes (matrix-pipe busy, wait / issue-stall shares, LDS conflicts, instruction mix) over
-#          tools/prof_path.py c2 (+ decode at B = 64), c3, c5 --decode (B = 128) and tools/prof_beam_device.py: counters only, program directly after --
+#          tools/prof_path.py c2, c3, c5 --decode (B = 128) and tools/prof_beam_device.py: counters only, program directly after --
 # traffic: FETCH_SIZE / WRITE_SIZE / L2 passes (tools/pmc_traffic.py)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && export OUT=${OUT:-prof_r5} && mkdir -p gpurun_out/$OUT && . tools/gpu/run_steps.sh
 WHAT="${*:-stats pmc traffic}"
@@ -19,7 +19,7 @@ case " $WHAT " in *" pmc "*)
   for cfg in c2 c3 dec beam; do
     mkdir -p gpurun_out/$OUT/sq_$cfg
     case $cfg in
-      c2) unset S2VT_GEMM_MODE; P="python3 tools/prof_path.py c2 2 --decode";;
+      c2) unset S2VT_GEMM_MODE; P="python3 tools/prof_path.py c2 2";;
       c3) export S2VT_GEMM_MODE=1; P="python3 tools/prof_path.py c3 2";;
       dec) unset S2VT_GEMM_MODE; P="python3 tools/prof_path.py c5 0 --decode";;
       beam) unset S2VT_GEMM_MODE; P="python3 tools/prof_beam_device.py";;
@@ -31,20 +31,21 @@ case " $WHAT " in *" pmc "*)
   unset S2VT_GEMM_MODE
 ;; esac
 case " $WHAT " in *" traffic "*)
-  export S2VT_GEMM_MODE=1
-  for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "l2 TCC_HIT_sum TCC_MISS_sum"; do
-    set -- $pass; tag=$1; shift
-    mkdir -p gpurun_out/$OUT/pmc_c3
-    run_step pmc_c3_$tag 300 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/$OUT/pmc_c3 -o $tag -- python3 tools/prof_path.py c3 2
+  # whole optimisation steps (tools/prof_path.py: train_step with FlatAdam), three passes each; the decode's kernels in a run of their own
+  for cfg in c3 c2 dec; do
+    case $cfg in
+      c3) export S2VT_GEMM_MODE=1; P="python3 tools/prof_path.py c3 3"; N=3; W="c3 (S2VT_GEMM_MODE=1), whole train steps";;
+      c2) unset S2VT_GEMM_MODE; P="python3 tools/prof_path.py c2 3"; N=3; W="c2, whole train steps";;
+      dec) unset S2VT_GEMM_MODE; P="python3 tools/prof_path.py c5 0 --decode"; N=1; W="c5: one greedy decode at B=128 (cold)";;
+    esac
+    mkdir -p gpurun_out/$OUT/pmc_$cfg
+    for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "l2 TCC_HIT_sum TCC_MISS_sum"; do
+      set -- $pass; tag=$1; shift
+      run_step pmc_${cfg}_$tag 300 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/$OUT/pmc_$cfg -o $tag -- $P
+    done
+    python3 tools/pmc_traffic.py gpurun_out/$OUT/pmc_$cfg "$W" $N > gpurun_out/$OUT/traffic_$cfg.json
   done
-  python3 tools/pmc_traffic.py gpurun_out/$OUT/pmc_c3 "c3 (S2VT_GEMM_MODE=1)" 2 > gpurun_out/$OUT/traffic_c3.json
   unset S2VT_GEMM_MODE
-  for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "l2 TCC_HIT_sum TCC_MISS_sum"; do
-    set -- $pass; tag=$1; shift
-    mkdir -p gpurun_out/$OUT/pmc_c2
-    run_step pmc_c2_$tag 300 rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/$OUT/pmc_c2 -o $tag -- python3 tools/prof_path.py c2 2 --decode
-  done
-  python3 tools/pmc_traffic.py gpurun_out/$OUT/pmc_c2 "c2 (+ one greedy decode at B=64)" 2 > gpurun_out/$OUT/traffic_c2.json
 ;; esac
 find gpurun_out/$OUT -name "*kernel_trace.csv" -delete; find gpurun_out/$OUT -name "*counter_collection.csv" -delete
 ls gpurun_out/$OUT | head -60

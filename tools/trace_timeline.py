@@ -6,9 +6,10 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 ev = []
 for r in rows:
     n = r["Kernel_Name"]
-    fam = ("gemm" if ("gemm_f32" in n or "gemm_x3" in n or "gemm_bf16" in n) else "split" if "split_" in n else "splitk" if "splitk" in n else "step_fwd" if "lstm_step_fwd" in n else
-           "step_bwd" if "lstm_step_bwd" in n else "argmax" if "logits_argmax" in n else "ce" if "ce_" in n else
-           "adam" if "multi_tensor" in n else "other")
+    fam = ("gemm" if ("gemm_f32" in n or "gemm_x3" in n or "gemm_b1" in n) else "splitk" if "splitk" in n else "split" if ("split_" in n or "split3" in n) else
+           "rec_fwd" if ("lstm_step_fwd" in n or "lstm_seq_fwd" in n) else "rec_bwd" if ("lstm_step_bwd" in n or "lstm_seq_bwd" in n) else
+           "argmax" if "logits_argmax" in n else "ce" if ("ce_" in n or "mask_criterion" in n) else
+           "adam" if ("multi_tensor" in n or "adam" in n) else "emb" if "emb_" in n else "other")
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), fam))
 ev.sort()
 t0, t1 = ev[0][0], max(e[1] for e in ev)
