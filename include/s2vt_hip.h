@@ -403,6 +403,9 @@ int s2vt_decode_step_argmax_x3(int32_t B, int32_t H, int32_t V, const float* h, 
  *   cu_reserve      0..128      the persistent GEMMs plan their grids for this many compute units fewer (data-parallel runs
  *                               whose communication kernels hold compute units beside the backward's GEMMs)
  *   bptt_units      0 | 16 | 32 hidden units per workgroup of the persistent bf16 BPTT (0: 32 where two layers fit the device)
+ *   corun           3 (0..5)    persistent split-precision schedule (B = 64): this many TENTHS of a GEMM that nothing waits for (dW_o's
+ *                               k range) run beside EACH one-layer first / last stage of the BPTT, planned for the compute units
+ *                               that stage leaves idle (0: every GEMM alone on the device)
  *   pad_min_batch   33 (1..64)  ragged batches (B % 64 != 0) of at least this many rows - a greedy decode: three quarters of it - are
  *                               padded to a multiple of 64 inside the workspace (s2vt_padded_batch); smaller ones run as they
  *                               are, launches per timestep (faster there: profiles/round5_ragged_batches.txt)

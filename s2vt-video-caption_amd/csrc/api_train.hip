@@ -228,7 +228,14 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
     if ((rc = pdual(lb, p->word_w_ih + E, E + H, ID, 4 * H, H, &q.wv, 0, &q.wvT, 0, nullptr))) return rc;
     if ((rc = pdual(lb, p->out_w, H, ID, V, H, &q.wo, 0, &q.woT, 0, nullptr))) return rc;
     if ((rc = pdual(lb, p->emb_w, E, gather(w.tok), R, E, &q.emb, 0, nullptr, 0, nullptr))) return rc;
-    if ((rc = pgemm(lb, R, 4 * H, E, q.emb, 0, 0, q.we, 0, 0, w.s2 + (int64_t)L * B4H, 4 * H, ID, w.bsum2, false))) return rc;
+    // (co-run: the last gxe_c rows of this GEMM and the first lg_c decode steps of the logits GEMM run beside the one-layer first /
+    // last stage of the persistent schedule below, on the compute units those leave idle - as dW_o does in the backward)
+    const int f_wgs = px3_fwd ? lstm_seq_fwd_x3_persist_single_workgroups(B, H) : 0;
+    const int f_cus = f_wgs > 0 ? (planned_compute_units() - f_wgs - 2) / 8 * 8 : 0;
+    const bool stages3 = px3_fwd && pipe_bounds(T, L, balanced_block(L, blk)).size() >= 3;      // at least two blocks: one-layer first / last stages
+    const int tenths = (stages3 && sx != st && f_cus >= 64 && R >= 2560 && B % 64 == 0) ? option(O_CORUN) : 0;
+    const int gxe_c = (R / 64 * (2 * tenths < 8 ? 2 * tenths : 8) / 10) * 64;
+    if ((rc = pgemm(lb, R - gxe_c, 4 * H, E, q.emb, 0, 0, q.we, 0, 0, w.s2 + (int64_t)L * B4H, 4 * H, ID, w.bsum2, false))) return rc;
     // lane A: feature projection and vid_rnn input GEMM                       S2VTModel.py:54, 64-67
     if ((rc = psplit(la, q.feats, 0, feats, F, ID, B * L, F))) return rc;
     if ((rc = psplit(la, q.wf, 0, p->feat_w, F, ID, H, F))) return rc;
@@ -249,8 +256,13 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
             const size_t kc0 = (size_t)cdiv(H, 16), kc1 = (size_t)(img->kpad / 16);
             if (kc1 > kc0) S2VT_HIP(hipMemset2DAsync(img->p + kc0 * 3072, (size_t)64 * img->ld * 2, 0, (kc1 - kc0) * 6144, (size_t)(T * B / 64), st));
         }
+        // decode steps whose logits run beside the last (word_rnn-only) stage: their h2 rows are final before it starts
+        int lg_c = (nb >= 2 && !out_mask) ? (L - 1) * ((2 * tenths + 1) / 3) / 10 : 0;
+        if (lg_c > bd[nb - 1] - L) lg_c = bd[nb - 1] - L > 0 ? bd[nb - 1] - L : 0;
         for (int k = 0; k <= nb; ++k) {
             const bool hv = k < nb, hw = k >= 1;
+            const bool co_first = k == 0 && nb >= 2 && gxe_c > 0, co_last = k == nb && lg_c > 0;
+            if ((co_first || co_last) && (rc = handoff(st, sx, ev++))) return rc;       // (the part starts with the stage, not before it)
             {
             ProfScope ps(st, K_STEP_FWD, (hv ? bd[k + 1] - bd[k] : 0) + (hw ? bd[k] - bd[k - 1] : 0));
             SeqFwdX3Args av, aw;
@@ -262,6 +274,17 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
             else rc = lstm_seq_fwd_x3_persist2(st, hv ? av : aw, nullptr);
             }
             if (rc) return rc;
+            if (co_first || co_last) {
+                {
+                    CuPlanCap cap(f_cus);
+                    if (co_first)
+                        rc = pgemm(lb, gxe_c, 4 * H, E, q.emb, R - gxe_c, 0, q.we, 0, 0, w.s2 + (int64_t)L * B4H + (int64_t)(R - gxe_c) * 4 * H, 4 * H,
+                                   ID, w.bsum2, false);
+                    else
+                        rc = pgemm(lb, lg_c * B, V, H, q.h2r, L * B, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
+                }
+                if (rc || (rc = handoff(sx, st, ev++))) return rc;
+            }
             if (hv) {
                 const int t0 = bd[k], t1 = bd[k + 1];
                 const bool cap = t0 >= L;
@@ -272,7 +295,8 @@ static int train_forward_x3(const s2vt_dims* d, const s2vt_params* p, const floa
         }
         const PB* lg; int lg0;
         if ((rc = masked_logits_planes(la, w, q, out_mask, B, L, H, &lg, &lg0))) return rc;
-        return pgemm(la, R, V, H, *lg, lg0, 0, q.wo, 0, 0, logits, V, perm(B, L - 1), p->out_b, false);
+        // (decode step t' of row (t', b) lands in logits row b (L-1) + t': a range of steps from t'0 on = the same row map, t'0 rows further)
+        return pgemm(la, R - lg_c * B, V, H, *lg, lg0 + lg_c * B, 0, q.wo, 0, 0, logits + (int64_t)lg_c * V, V, perm(B, L - 1), p->out_b, false);
     }
     if (pbf_fwd) {
         // Persistent schedule, ONE stream: the launch of pipeline stage k runs vid_rnn block k next to word_rnn block k-1
@@ -363,6 +387,15 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if (ce_pow2 && (rc = scale_by_device_scalar(st, w.dh2dec, (int64_t)R * H, w.ce_alpha))) return rc;
     if (out_mask && (rc = mul_vectors(st, w.dh2dec, out_mask, w.dh2dec, (int64_t)R * H))) return rc;      // autograd of out_drop
     if (!bf && (rc = transpose_f32(st, p->word_w_hh, 4 * H, H, w.wt2))) return rc;       // (the bf16 BPTT reads the W_hh^T planes instead)
+    const bool pbf_bwd = bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad;
+    const bool px3_bwd = !bf && XP == 3 && blk > 0 && w.xnslots > 0 && persist_x3_bwd_on(B, H) && lstm_seq_bwd_x3_persist_supported(B, H) &&
+                         w.xnslots > (blk < T ? blk : T);
+    // rows of dW_o's k range that run beside EACH of the two one-layer BPTT stages (0: no co-run): 3/10 of the rows each - a stage
+    // (option corun, tenths) - a stage lasts about as long as that part takes on the idle half of the device (profiles/round5_corun.txt)
+    const int x3_ns = px3_bwd ? lstm_seq_bwd_x3_persist_supported(B, H) : 0;                 // chains per workgroup
+    const int one_layer_wgs = x3_ns > 0 ? (B / (32 * x3_ns)) * cdiv(H, 16) : 1 << 20;
+    const int corun_cus = (planned_compute_units() - one_layer_wgs - 2) / 8 * 8;
+    const int corun_k = (px3_bwd && option(O_CORUN) && sx != st && corun_cus >= 64 && R >= 2560) ? (R / 64 * option(O_CORUN) / 10) * 64 : 0;
     // lane B meanwhile: out_linear weight/bias gradients (k = batch-major row index) and W_hh1^T
     {
         const float* h2dec = w.h2 + L * BH;
@@ -372,15 +405,14 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
         }
         // rows in dlogits' (batch-major) order, read transposed by the GEMM
         if ((rc = psplit(lb, q.h2decB, 0, h2dec, H, perm(L - 1, B), R, H))) return rc;
-        if ((rc = pgemm_tt(lb, V, H, R, q.dlog, 0, q.h2decB, 0, g->out_w, H, ID, nullptr, false))) return rc;
-        if (ce_pow2 && (rc = scale_by_device_scalar(sx, g->out_w, (int64_t)V * H, w.ce_alpha))) return rc;
+        // (co-run: dW_o is not needed before the optimizer - its GEMM is cut over k = rows into three parts, two of which run beside the
+        // one-layer stages of the persistent BPTT below, on the compute units those leave idle)
+        if (!corun_k && (rc = pgemm_tt(lb, V, H, R, q.dlog, 0, q.h2decB, 0, g->out_w, H, ID, nullptr, false))) return rc;
+        if (!corun_k && ce_pow2 && (rc = scale_by_device_scalar(sx, g->out_w, (int64_t)V * H, w.ce_alpha))) return rc;
     }
     if ((rc = colsum_finish(sx, w.colsum_c, cdiv(R, 64), V, g->out_b, false))) return rc;
-    if ((rc = grads_ready(0, sx))) return rc;
+    if (!corun_k && (rc = grads_ready(0, sx))) return rc;
     if (!bf && (rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
-    const bool pbf_bwd = bf && blk > 0 && persist_on() && lstm_seq_bwd_bf16_persist_supported(B, H, q.dg2.kpad) && q.dg2.kpad == q.whh2T.kpad;
-    const bool px3_bwd = !bf && XP == 3 && blk > 0 && w.xnslots > 0 && persist_x3_bwd_on(B, H) && lstm_seq_bwd_x3_persist_supported(B, H) &&
-                         w.xnslots > (blk < T ? blk : T);
     const std::vector<int> bd = pipe_bounds(T, L, (pbf_bwd || px3_bwd) ? balanced_block(L, blk) : blk);
     int bias_chunk = 64;      // rows per partial column sum of dG (32: written by the persistent split-precision BPTT itself)
     if (px3_bwd) {   // W_hh^T of both layers as planes (each on the lane that transposed it)
@@ -409,6 +441,8 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
         }
         for (int k = nb - 1; k >= -1; --k) {
             const bool hw = k >= 0, hv = k + 1 <= nb - 1;
+            const bool solo = corun_k && nb >= 2 && (k == nb - 1 || k == -1);      // a one-layer stage: half of the compute units idle
+            if (solo && (rc = handoff(st, sx, ev++))) return rc;                     // (the part starts with the stage, not before it)
             {
                 ProfScope ps(st, K_STEP_BWD, (hw ? bd[k + 1] - bd[k] : 0) + (hv ? bd[k + 2] - bd[k + 1] : 0));
                 SeqBwdX3Args aw, av;
@@ -424,6 +458,14 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
                 else rc = lstm_seq_bwd_x3_persist2(st, hw ? aw : av, nullptr);
                 ++g_bwd_persist_launches;
                 if (rc) return rc;
+            }
+            if (solo) {      // dW_o rows [r0, r0 + corun_k) on lane B, planned for the units the stage leaves idle; the caller's stream
+                const int r0 = (k == nb - 1) ? 0 : corun_k;              // goes on when both are done
+                {
+                    CuPlanCap cap(corun_cus);
+                    if ((rc = pgemm_tt(lb, V, H, corun_k, q.dlog, r0, q.h2decB, r0, g->out_w, H, ID, nullptr, r0 > 0))) return rc;
+                }
+                if ((rc = handoff(sx, st, ev++))) return rc;
             }
             if (hw) {
                 const int t0 = bd[k], t1 = bd[k + 1];
@@ -441,8 +483,14 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
             }
         }
         bias_chunk = emit ? 32 : 64;
-        if ((rc = grads_ready(0, st))) return rc;                  // (see the bf16 branch below)
+        if (!corun_k && (rc = grads_ready(0, st))) return rc;      // (see the bf16 branch below)
         if ((rc = handoff(st, sx, ev++))) return rc;
+        if (corun_k) {      // the rest of dW_o's rows: first thing of lane B's tail, then the out_linear gradients are final
+            const bool two = nb >= 2;
+            const int r0 = two ? 2 * corun_k : 0;
+            if ((rc = pgemm_tt(lb, V, H, R - r0, q.dlog, r0, q.h2decB, r0, g->out_w, H, ID, nullptr, two))) return rc;
+            if ((rc = grads_ready(0, sx))) return rc;
+        }
     } else if (pbf_bwd) {
         // Persistent schedule, ONE stream (mirror of the forward): the launch of stage k runs the word_rnn BPTT of block k
         // next to the vid_rnn BPTT of block k+1 (lstm_persist.hip); between two launches the dG planes / partial column sums

@@ -36,11 +36,19 @@ int check_hip(hipError_t e, const char* what);
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- run-time options (options.hip): one table; S2VT_<NAME> from the environment at first read, s2vt_set_option afterwards
-enum Option { O_GEMM_MODE, O_PERSIST, O_PERSIST_X3_FWD, O_PERSIST_X3_BWD, O_PIPE_BLOCK, O_GRAPH, O_DECODE_FUSED, O_CU_RESERVE, O_BPTT_UNITS, O_GEMV, O_PAD_MIN_BATCH, O_COUNT };
+enum Option { O_GEMM_MODE, O_PERSIST, O_PERSIST_X3_FWD, O_PERSIST_X3_BWD, O_PIPE_BLOCK, O_GRAPH, O_DECODE_FUSED, O_CU_RESERVE, O_BPTT_UNITS, O_GEMV, O_PAD_MIN_BATCH, O_CORUN, O_COUNT };
 int option(int id);
 int option_set(int id, int value);      // returns the previous value; value < 0 only queries
 // compute units the persistent GEMMs size their grids for: the device's, minus option "cu_reserve", rounded down to the 8 XCDs
 int planned_compute_units();
+// cap of the calling thread's persistent-GEMM grids (0: none): a driver that launches a GEMM BESIDE a persistent recurrence kernel
+// which holds only part of the compute units plans it for the units left over.  Returns the previous cap.
+int cu_plan_cap(int n);
+struct CuPlanCap {
+    int prev;
+    explicit CuPlanCap(int n) : prev(cu_plan_cap(n)) {}
+    ~CuPlanCap() { cu_plan_cap(prev); }
+};
 
 // Workgroups of `kernel` (block size `block`, static LDS only) that can be RESIDENT AT ONCE on the current device: compute
 // units x occupancy per compute unit, as the runtime reports them (cached per device and kernel; 0 when the query fails).

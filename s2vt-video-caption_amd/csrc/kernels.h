@@ -204,6 +204,7 @@ struct SeqFwdX3Args {
     unsigned long long* stamps; int stamp_block;    // timing experiments only (experiment.h); null in the product
 };
 int lstm_seq_fwd_x3_persist_supported(int B, int H);
+int lstm_seq_fwd_x3_persist_single_workgroups(int B, int H);      // workgroups of a launch with ONE layer (0: unsupported)
 int lstm_seq_fwd_x3_persist2(hipStream_t stream, SeqFwdX3Args a, const SeqFwdX3Args* b);
 int split3_rows(hipStream_t stream, const float* src, int64_t ld, int R, int C, int Cp, unsigned short* dst, int64_t plane);
 struct SeqBwdX3Args {

@@ -418,6 +418,10 @@ static int fwd_x3_single_ns(int B, int H) {
     while (R * nC > cap && ns < X_MAXNS && R % 2 == 0) { R /= 2; ns *= 2; }
     return (R * nC <= cap) ? ns : 0;
 }
+int lstm_seq_fwd_x3_persist_single_workgroups(int B, int H) {
+    const int ns = fwd_x3_single_ns(B, H);
+    return ns > 0 ? (B / (ns * X_SR)) * cdiv(H, X_UN) : 0;
+}
 static int prep_x(SeqFwdX3Args& a, bool single = false) {
     const int ns = single ? fwd_x3_single_ns(a.B, a.H) : lstm_seq_fwd_x3_persist_supported(a.B, a.H);
     S2VT_REQUIRE(ns > 0, "lstm_seq_fwd_x3_persist: unsupported shape (B %% 32, H <= 1024) or it does not fit the device's resident capacity");

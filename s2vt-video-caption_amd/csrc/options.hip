@@ -25,6 +25,7 @@ static const OptionDef kOptions[O_COUNT] = {
     /* O_BPTT_UNITS     */ {"bptt_units", 0, 0, 32},        // persistent bf16 BPTT: 32 | 16 hidden units per workgroup (0: 32 where it fits)
     /* O_GEMV           */ {"gemv", 1, 0, 2},               // launch-per-timestep forward step as gate GEMVs (lstm_gemv.hip): 1 at B <= 4, 2 at B <= 8, 0 never
     /* O_PAD_MIN_BATCH  */ {"pad_min_batch", 33, 1, 64},    // ragged batches of at least this size are padded to a multiple of 64 (plane path)
+    /* O_CORUN          */ {"corun", 3, 0, 5},              // tenths of a GEMM that nothing waits for beside EACH one-layer stage of the persistent split-precision schedules (0: off)
 };
 static int g_value[O_COUNT];
 static bool g_read[O_COUNT];
@@ -61,6 +62,8 @@ int option_set(int id, int value) {
     return prev;
 }
 
+static thread_local int t_cu_cap = 0;
+
 int planned_compute_units() {
     static int device_cus = 0;
     if (!device_cus) {
@@ -72,7 +75,14 @@ int planned_compute_units() {
     int n = device_cus;
     const int reserve = option(O_CU_RESERVE);
     if (reserve > 0 && reserve < n - 8) n -= reserve;
+    if (t_cu_cap >= 8 && t_cu_cap < n) n = t_cu_cap;
     return n / 8 * 8;
+}
+
+int cu_plan_cap(int n) {
+    const int prev = t_cu_cap;
+    t_cu_cap = n > 0 ? n : 0;
+    return prev;
 }
 
 int option_id(const char* name) {
