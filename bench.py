@@ -484,6 +484,11 @@ def main():
             gnote += ("; achieved = algorithmic FLOPs of all GEMM launches of a step / BUSY time (union of the launch brackets: "
                       "GEMMs of the two lanes that run side by side are counted once); `sum_of_launch_ms` counts overlapped "
                       "launches twice and is what a per-kernel profile (rocprofv3 --stats) adds up to")
+            if x3_ and B_ == 64 and (pf, pb) == (3, 3) and int(lib.s2vt_set_option(b"corun", -1)) > 0:
+                gnote += ("; option corun: four GEMM parts (dW_o's k range twice, the embedded-word gate GEMM, the first decode steps' logits) run "
+                          "on HALF the compute units beside the one-layer stages of the persistent recurrence - their brackets count in full in "
+                          "the busy time although they hold 128 of 256 units, which lowers this fraction while it shortens the step "
+                          "(profiles/round5_corun.txt)")
             rg = {"kernel": gk, "bound": "mfma", "achieved": round(gemm_tf, 2),
                   "peak": round(gpeak, 1), "unit": "TFLOP/s", "frac": round(gemm_tf / gpeak, 4),
                   "traffic": traffic_of(gk), "traffic_source": pmc_src_, "launches_per_step": gemm_n,
