@@ -616,6 +616,8 @@ def main():
                 am_gflop = 2.0 * Bd * (V + 4 * H) * H * (L - 1) / L / 1e9
                 am_bytes = int((4 * (V + 4 * H) * H + 4 * V + 4 * Bd * H + 8 * Bd + 16 * Bd * H) * (L - 1) / L)
             am_peak = (MFMA_BF16_PEAK_TF / 6.0) if planes else MFMA_F32_PEAK_TF
+            am_kernel = "logits_argmax_x3_kernel" if planes else "logits_argmax_kernel"
+            pmcd, pmcd_src = load_pmc("dec")             # one cold greedy decode at B = 128 (tools/profile_round5.sh traffic)
             decode = {"metric": "greedy-decode captions/sec", "value": round(Bd / ddt, 1), "unit": "captions/s",
                       "batch": Bd, "ms_per_call": round(ddt * 1e3, 2), "n_gpus": 1, "calls_timed": nd,
                       "regime": "fixed weights, one mode='test' call per batch (eval.py:48-52): weight-derived images cached between calls",
@@ -625,7 +627,10 @@ def main():
                           "achieved": round(am_gflop / (am_us * 1e-6) / 1e3, 1), "peak": round(am_peak, 1), "unit": "TFLOP/s",
                           "frac": round(am_gflop / (am_us * 1e-6) / 1e3 / am_peak, 4),
                           "avg_launch_us": round(am_us, 2), "launches_per_call": am_n,
-                          "gflop_per_launch": round(am_gflop, 2), "traffic": None,
+                          "gflop_per_launch": round(am_gflop, 2),
+                          "traffic": (int(pmcd[am_kernel]["hbm_bytes_per_launch"]) if Bd == 128 and am_kernel in pmcd and
+                                      "hbm_bytes_per_launch" in pmcd[am_kernel] else None),
+                          "traffic_source": pmcd_src if Bd == 128 else None,
                           "pipe_counters": busy_of(busyd, busyd_src, "logits_argmax_x3_kernel" if planes else "logits_argmax_kernel") if Bd == 128 else None,
                           "algorithmic_bytes_per_launch": am_bytes,
                           "hbm_frac_by_algorithmic_bytes": round(am_bytes / (am_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
