@@ -406,6 +406,9 @@ int s2vt_decode_step_argmax_x3(int32_t B, int32_t H, int32_t V, const float* h, 
  *   corun           3 (0..5)    persistent split-precision schedule (B = 64): this many TENTHS of a GEMM that nothing waits for (dW_o's
  *                               k range) run beside EACH one-layer first / last stage of the BPTT, planned for the compute units
  *                               that stage leaves idle (0: every GEMM alone on the device)
+ *   bptt_solo       1 | 0       (with corun > 0, B = 64) every persistent BPTT launch carries ONE layer - word_rnn's blocks, then vid_rnn's -
+ *                               on half of the compute units, with dW_o, the dh1 GEMMs and word_rnn's weight gradients on the other half;
+ *                               0: two layers per launch, GEMM parts only beside the first / last (one-layer) launch
  *   pad_min_batch   33 (1..64)  ragged batches (B % 64 != 0) of at least this many rows - a greedy decode: three quarters of it - are
  *                               padded to a multiple of 64 inside the workspace (s2vt_padded_batch); smaller ones run as they
  *                               are, launches per timestep (faster there: profiles/round5_ragged_batches.txt)

@@ -415,6 +415,10 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     if (!bf && (rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     const std::vector<int> bd = pipe_bounds(T, L, (pbf_bwd || px3_bwd) ? balanced_block(L, blk) : blk);
     int bias_chunk = 64;      // rows per partial column sum of dG (32: written by the persistent split-precision BPTT itself)
+    bool word_gemms_done = false, demb_done = false;                // (the one-layer BPTT schedule ran word_rnn's weight-gradient GEMMs and the
+    size_t word_grads_ev = 0, demb_ev = 0;                          //  embedded-word gradient GEMM already, on lane B: their events;
+    int hh1_t0 = 0;                                                 //  dW_hh1's timesteps >= hh1_t0 are done as well)
+    const bool solo_sched = corun_k > 0 && bd.size() >= 3 && option(O_BPTT_SOLO) != 0;
     if (px3_bwd) {   // W_hh^T of both layers as planes (each on the lane that transposed it)
         if ((rc = split3_wt(st, w.wt2, H, (int)w.xkp, (int)w.xhp, w.xwt2, w.xkp * 4 * w.xhp))) return rc;
         if ((rc = split3_wt(sx, w.wt1, H, (int)w.xkp, (int)w.xhp, w.xwt1, w.xkp * 4 * w.xhp))) return rc;
@@ -439,6 +443,104 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
                         S2VT_HIP(hipMemset2DAsync(img->p + kc0 * 3072 + (pl * 2 + 1) * 512, (size_t)64 * img->ld * 2, 0, 1024, (size_t)(T * B / 64), st));
             }
         }
+        if (solo_sched) {
+            // ONE layer per launch - word_rnn's blocks, then vid_rnn's (the word_rnn BPTT does not depend on vid_rnn's) - on half of the
+            // compute units, and the backward's GEMMs on the other half (lane B, planned for the idle units): beside word_rnn's stages
+            // dW_o (cut over k = rows, accumulated in a fixed order) and every finished block's dh1 GEMM; beside vid_rnn's stages
+            // word_rnn's weight gradients.  A two-layer stage does two blocks in ~440 us with nothing beside it; two one-layer stages take
+            // ~2 x 345 us and give half of the device to GEMMs for that long (profiles/round5_corun.txt).
+            auto event_at = [&](hipStream_t s_, size_t* idx) -> int {
+                hipEvent_t e;
+                *idx = ev++;
+                const int r = get_event(*idx, &e);
+                if (r) return r;
+                S2VT_HIP(hipEventRecord(e, s_));
+                return 0;
+            };
+            auto wait_for = [&](hipStream_t s_, size_t idx) -> int {
+                hipEvent_t e;
+                const int r = get_event(idx, &e);
+                if (r) return r;
+                S2VT_HIP(hipStreamWaitEvent(s_, e, 0));
+                return 0;
+            };
+            auto emit_args = [&](SeqBwdX3Args& a, bool word) {
+                if (!emit) return;
+                a.dgp = word ? q.dg2.p : q.dg1.p; a.lddgp = word ? q.dg2.ld : q.dg1.ld;
+                a.colpart = word ? w.colsum_a : w.colsum_b; a.skip_dg = 1;
+            };
+            if ((rc = handoff(st, sx, ev++))) return rc;            // the parts start with the first stage, not beside the dh2 GEMM
+            int wo_r = 0;                                           // next row of dW_o's k range
+            auto wo_part = [&]() -> int {
+                if (wo_r >= R) return 0;
+                int kk = corun_k < R - wo_r ? corun_k : R - wo_r;
+                if (R - wo_r - kk < 512) kk = R - wo_r;
+                const int r = pgemm_tt(lb, V, H, kk, q.dlog, wo_r, q.h2decB, wo_r, g->out_w, H, ID, nullptr, wo_r > 0);
+                wo_r += kk;
+                return r;
+            };
+            std::vector<size_t> dh1_done((size_t)nb);
+            size_t word_grads_done = 0;
+            {
+                CuPlanCap cap(corun_cus);
+                for (int k = nb - 1; k >= 0; --k) {
+                    const int t0 = bd[k], t1 = bd[k + 1];
+                    {
+                        ProfScope ps(st, K_STEP_BWD, t1 - t0);
+                        SeqBwdX3Args aw = persist_bwd_x3_args(T, t0, t1, B, H, w.xkp, w.xhp, w.xwt2, w.dh2dec, L, w.c2, w.s2, w.dc2, w.xpart2, w.xpslot,
+                                                              w.xnslots, w.psync_a, w.err + 1);
+                        emit_args(aw, true);
+                        if ((rc = lstm_seq_bwd_x3_persist2(st, aw, nullptr))) return rc;
+                        ++g_bwd_persist_launches;
+                    }
+                    if ((rc = wo_part())) return rc;
+                    if ((rc = handoff(st, sx, ev++))) return rc;    // dG2 rows of block k
+                    if (!emit && (rc = pdual(lb, w.s2 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, &q.dg2, t0 * B, nullptr, t0 * B,
+                                             w.colsum_a + (int64_t)(t0 * B / 64) * 4 * H)))
+                        return rc;
+                    if ((rc = pgemm(lb, (t1 - t0) * B, H, 4 * H, q.dg2, t0 * B, 0, q.wvT, 0, 0, w.dh1 + t0 * BH, H, ID, nullptr, false))) return rc;
+                    if ((rc = event_at(sx, &dh1_done[(size_t)k]))) return rc;
+                }
+                while (wo_r < R)
+                    if ((rc = wo_part())) return rc;
+                // word_rnn's weight gradients (dG2 is complete): beside vid_rnn's stages
+                if ((rc = pgemm_tt(lb, 4 * H, H, (T - 1) * B, q.dg2, B, q.h2r, 0, g->word_w_hh, H, ID, nullptr, false))) return rc;
+                if ((rc = pgemm_tt(lb, 4 * H, H, T * B, q.dg2, 0, q.h1, 0, g->word_w_ih + E, E + H, ID, nullptr, false))) return rc;
+                if ((rc = pgemm_tt(lb, 4 * H, E, R, q.dg2, L * B, q.emb, 0, g->word_w_ih, E + H, ID, nullptr, false))) return rc;
+                if ((rc = event_at(sx, &word_grads_done))) return rc;
+                // ... and the gradient into the embedded words (the embedding gradient's input)
+                if ((rc = pgemm(lb, R, E, 4 * H, q.dg2, L * B, 0, q.weT, 0, 0, w.de, E, ID, nullptr, false))) return rc;
+                if ((rc = event_at(sx, &demb_ev))) return rc;
+                demb_done = true;
+            }
+            // dW_hh1 = dG1[t]^T h1[t-1] over t >= hh1_t0 (the blocks vid_rnn's BPTT finishes first) beside its later stages
+            const int kc = nb / 2;
+            if (nb >= 4) hh1_t0 = bd[kc];
+            for (int k = nb - 1; k >= 0; --k) {
+                const int t0 = bd[k], t1 = bd[k + 1];
+                if ((rc = wait_for(st, dh1_done[(size_t)k]))) return rc;
+                ProfScope ps(st, K_STEP_BWD, t1 - t0);
+                SeqBwdX3Args av = persist_bwd_x3_args(T, t0, t1, B, H, w.xkp, w.xhp, w.xwt1, w.dh1, 0, w.c1, w.s1, w.dc1, w.xpart1, w.xpslot,
+                                                      w.xnslots, w.psync_b, w.err + 1);
+                emit_args(av, false);
+                if ((rc = lstm_seq_bwd_x3_persist2(st, av, nullptr))) return rc;
+                ++g_bwd_persist_launches;
+                if (!emit && (rc = pdual(la, w.s1 + t0 * B4H, 4 * H, ID, (t1 - t0) * B, 4 * H, &q.dg1, t0 * B, nullptr, t0 * B,
+                                         w.colsum_b + (int64_t)(t0 * B / 64) * 4 * H)))
+                    return rc;
+                if (hh1_t0 > 0 && k == kc) {
+                    if ((rc = handoff(st, sx, ev++))) return rc;   // dG1 rows of the blocks [kc, nb)
+                    CuPlanCap cap(corun_cus);
+                    if ((rc = pgemm_tt(lb, 4 * H, H, (T - hh1_t0) * B, q.dg1, hh1_t0 * B, q.h1, (hh1_t0 - 1) * B, g->vid_w_hh, H, ID, nullptr, false)))
+                        return rc;
+                }
+            }
+            bias_chunk = emit ? 32 : 64;
+            if ((rc = grads_ready(0, st))) return rc;              // (out_linear's gradients: released behind the last persistent launch)
+            if ((rc = handoff(st, sx, ev++))) return rc;           // lane B's vid_rnn gradients need dG1
+            word_gemms_done = true;
+            word_grads_ev = word_grads_done;                       // lane A's tail ends with "word_rnn + embedding gradients final": after these
+        } else
         for (int k = nb - 1; k >= -1; --k) {
             const bool hw = k >= 0, hv = k + 1 <= nb - 1;
             const bool solo = corun_k && nb >= 2 && (k == nb - 1 || k == -1);      // a one-layer stage: half of the compute units idle
@@ -482,10 +584,12 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
                     return rc;
             }
         }
+        if (!solo_sched) {
         bias_chunk = emit ? 32 : 64;
         if (!corun_k && (rc = grads_ready(0, st))) return rc;      // (see the bf16 branch below)
         if ((rc = handoff(st, sx, ev++))) return rc;
-        if (corun_k) {      // the rest of dW_o's rows: first thing of lane B's tail, then the out_linear gradients are final
+        }
+        if (corun_k && !solo_sched) {      // the rest of dW_o's rows: first thing of lane B's tail, then the out_linear gradients are final
             const bool two = nb >= 2;
             const int r0 = two ? 2 * corun_k : 0;
             if ((rc = pgemm_tt(lb, V, H, R - r0, q.dlog, r0, q.h2decB, r0, g->out_w, H, ID, nullptr, two))) return rc;
@@ -559,17 +663,29 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
     }
     // lane A: word_rnn parameter gradients + embedding gradient
     // dW = dG^T . (h | emb): row planes of both, read transposed
+    if (!word_gemms_done) {
     if ((rc = pgemm_tt(la, 4 * H, H, (T - 1) * B, q.dg2, B, q.h2r, 0, g->word_w_hh, H, ID, nullptr, false))) return rc;
     if ((rc = pgemm_tt(la, 4 * H, H, T * B, q.dg2, 0, q.h1, 0, g->word_w_ih + E, E + H, ID, nullptr, false))) return rc;
     if ((rc = pgemm_tt(la, 4 * H, E, R, q.dg2, L * B, q.emb, 0, g->word_w_ih, E + H, ID, nullptr, false))) return rc;
+    }
     if ((rc = colsum_finish(st, w.colsum_a, T * B / bias_chunk, 4 * H, g->word_b_ih, false))) return rc;
     S2VT_HIP(hipMemcpyAsync(g->word_b_hh, g->word_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
-    if ((rc = pgemm(la, R, E, 4 * H, q.dg2, L * B, 0, q.weT, 0, 0, w.de, E, ID, nullptr, false))) return rc;
+    if (demb_done) {
+        hipEvent_t e;
+        if ((rc = get_event(demb_ev, &e))) return rc;
+        S2VT_HIP(hipStreamWaitEvent(st, e, 0));
+    } else if ((rc = pgemm(la, R, E, 4 * H, q.dg2, L * B, 0, q.weT, 0, 0, w.de, E, ID, nullptr, false))) return rc;
     if ((rc = embedding_grad(st, w.de, R, E, w.tok, V, g->emb_w, w.embws))) return rc;
+    if (word_gemms_done) {
+        hipEvent_t e;
+        if ((rc = get_event(word_grads_ev, &e))) return rc;
+        S2VT_HIP(hipStreamWaitEvent(st, e, 0));
+    }
     if ((rc = grads_ready(1, st))) return rc;
     // lane B: vid_rnn and feat_linear parameter gradients
     const Lane lt = lb;
-    if ((rc = pgemm_tt(lt, 4 * H, H, (T - 1) * B, q.dg1, B, q.h1, 0, g->vid_w_hh, H, ID, nullptr, false))) return rc;
+    // (one-layer BPTT schedule: the timesteps >= hh1_t0 of this sum ran beside vid_rnn's later stages - the rest is accumulated)
+    if ((rc = pgemm_tt(lt, 4 * H, H, ((hh1_t0 > 0 ? hh1_t0 : T) - 1) * B, q.dg1, B, q.h1, 0, g->vid_w_hh, H, ID, nullptr, hh1_t0 > 0))) return rc;
     if ((rc = pgemm_tt(lt, 4 * H, H, L * B, q.dg1, 0, q.x1, 0, g->vid_w_ih, H, ID, nullptr, false))) return rc;
     if ((rc = colsum_finish(lt.s, w.colsum_b, T * B / bias_chunk, 4 * H, g->vid_b_ih, false))) return rc;
     S2VT_HIP(hipMemcpyAsync(g->vid_b_hh, g->vid_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, lt.s));

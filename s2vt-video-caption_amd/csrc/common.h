@@ -36,7 +36,7 @@ int check_hip(hipError_t e, const char* what);
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- run-time options (options.hip): one table; S2VT_<NAME> from the environment at first read, s2vt_set_option afterwards
-enum Option { O_GEMM_MODE, O_PERSIST, O_PERSIST_X3_FWD, O_PERSIST_X3_BWD, O_PIPE_BLOCK, O_GRAPH, O_DECODE_FUSED, O_CU_RESERVE, O_BPTT_UNITS, O_GEMV, O_PAD_MIN_BATCH, O_CORUN, O_COUNT };
+enum Option { O_GEMM_MODE, O_PERSIST, O_PERSIST_X3_FWD, O_PERSIST_X3_BWD, O_PIPE_BLOCK, O_GRAPH, O_DECODE_FUSED, O_CU_RESERVE, O_BPTT_UNITS, O_GEMV, O_PAD_MIN_BATCH, O_CORUN, O_BPTT_SOLO, O_COUNT };
 int option(int id);
 int option_set(int id, int value);      // returns the previous value; value < 0 only queries
 // compute units the persistent GEMMs size their grids for: the device's, minus option "cu_reserve", rounded down to the 8 XCDs

@@ -26,6 +26,7 @@ static const OptionDef kOptions[O_COUNT] = {
     /* O_GEMV           */ {"gemv", 1, 0, 2},               // launch-per-timestep forward step as gate GEMVs (lstm_gemv.hip): 1 at B <= 4, 2 at B <= 8, 0 never
     /* O_PAD_MIN_BATCH  */ {"pad_min_batch", 33, 1, 64},    // ragged batches of at least this size are padded to a multiple of 64 (plane path)
     /* O_CORUN          */ {"corun", 3, 0, 5},              // tenths of a GEMM that nothing waits for beside EACH one-layer stage of the persistent split-precision schedules (0: off)
+    /* O_BPTT_SOLO      */ {"bptt_solo", 1, 0, 1},          // co-run schedule of the BPTT: every persistent launch carries ONE layer, GEMMs on the other half of the device
 };
 static int g_value[O_COUNT];
 static bool g_read[O_COUNT];

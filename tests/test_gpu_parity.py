@@ -131,7 +131,7 @@ def test_c2_full_size_against_reference_golden(lib, golden, gemm_mode):
 
 @pytest.mark.parametrize("option,value,plan", [("persist", 0, (0, 0)), ("persist_x3_fwd", 0, (0, None)), ("persist_x3_bwd", 0, (3, 0)),
                                                ("persist_x3_bwd", 1, (3, 3)), ("persist_x3_bwd", 2, (3, 3)), ("pipe_block", 0, None), ("pipe_block", 20, None),
-                                               ("graph", 1, None), ("cu_reserve", 24, None), ("decode_fused", 0, None), ("corun", 0, None)])
+                                               ("graph", 1, None), ("cu_reserve", 24, None), ("decode_fused", 0, None), ("corun", 0, None), ("bptt_solo", 0, None)])
 def test_c2_train_and_decode_under_every_option(lib, golden, option, value, plan):
     """The config-2 fixture (greedy ids bit-exact, two Adam steps within 1e-4, every gradient) with ONE run-time option of the
     library moved off / onto its default through s2vt_set_option - the whole switch table of csrc/options.hip except the
