@@ -378,7 +378,7 @@ def main():
             # kind overlap where the two lanes run the same kind of kernel side by side (the weight-gradient GEMMs of the
             # two layers, the two layers' timesteps), and each overlapped launch lasts about twice as long as alone - the
             # sum counts that time twice, throughput is priced with the busy time
-            r = {k: capi.prof_read(i) + (capi.prof_read_busy(i),) for i, k in enumerate(("gemm", "step_fwd", "step_bwd", "ce"))}
+            r = {k: capi.prof_read(i) + (capi.prof_read_busy(i),) for i, k in ((0, "gemm"), (1, "step_fwd"), (2, "step_bwd"), (3, "ce"), (5, "gemm_corun"))}
             capi.check(lib.s2vt_prof_reset(), "prof_reset")
             return {k: (ms / nprof, n // nprof, busy / nprof) for k, (ms, n, busy) in r.items()}
 
@@ -467,8 +467,19 @@ def main():
             gflop_ = gemm_flops_train(B_, L, F, H, E, V) / 1e9
             pair_ = step_bytes_fwd(B_, H, H, s=esz_) + step_bytes_fwd(B_, H, E + H, s=esz_)
             gemm_ms, gemm_n, gemm_busy = pr["gemm"]
+            co_ms, co_n, co_busy = pr.get("gemm_corun", (0.0, 0, 0.0))
+            # GEMMs of option corun run on PART of the compute units beside a one-layer persistent launch (which holds the rest): their
+            # busy time is priced with the share of the device they were planned for; they never overlap a full-device GEMM
+            co_share = 0.0
+            if co_n:
+                ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+                cap = (ncu - int(lib.s2vt_set_option(b"cu_reserve", -1)) - 128) // 8 * 8      # 126 persistent workgroups + 2 idle ones of its grid
+                co_share = max(min(cap / float(ncu), 1.0), 0.0)
+            gemm_busy_w = gemm_busy + co_share * co_busy
+            gemm_busy_all = gemm_busy + co_busy
+            gemm_ms, gemm_n = gemm_ms + co_ms, gemm_n + co_n
             sf_ms, sb_ms = pr["step_fwd"][0], pr["step_bwd"][0]
-            gemm_tf = gflop_ / gemm_busy              # GFLOP / ms = TFLOP/s over the time at least one GEMM was running
+            gemm_tf = gflop_ / gemm_busy_w            # GFLOP / ms = TFLOP/s over the (device-share weighted) time at least one GEMM was running
             step_us = sf_ms * 1e3 / (2 * T)           # average timestep of one layer, forward (2T per step: both layers)
             bstep_us = sb_ms * 1e3 / (2 * T)
             step_gbs = (pair_ / 2) / (step_us * 1e-6) / 1e9
@@ -484,15 +495,17 @@ def main():
             gnote += ("; achieved = algorithmic FLOPs of all GEMM launches of a step / BUSY time (union of the launch brackets: "
                       "GEMMs of the two lanes that run side by side are counted once); `sum_of_launch_ms` counts overlapped "
                       "launches twice and is what a per-kernel profile (rocprofv3 --stats) adds up to")
-            if x3_ and B_ == 64 and (pf, pb) == (3, 3) and int(lib.s2vt_set_option(b"corun", -1)) > 0:
-                gnote += ("; option corun: four GEMM parts (dW_o's k range twice, the embedded-word gate GEMM, the first decode steps' logits) run "
-                          "on HALF the compute units beside the one-layer stages of the persistent recurrence - their brackets count in full in "
-                          "the busy time although they hold 128 of 256 units, which lowers this fraction while it shortens the step "
-                          "(profiles/round5_corun.txt)")
+            if co_n:
+                gnote += ("; option corun: %d of the %d launches run on %.0f %% of the compute units beside the one-layer launches of the "
+                          "persistent recurrence (which hold the rest) - their busy time (%.3f ms per step) is priced with that share of the "
+                          "device in `achieved` / `frac`; `frac_unweighted` prices it in full (profiles/round5_corun.txt)"
+                          % (co_n, gemm_n, 100 * co_share, co_busy))
             rg = {"kernel": gk, "bound": "mfma", "achieved": round(gemm_tf, 2),
                   "peak": round(gpeak, 1), "unit": "TFLOP/s", "frac": round(gemm_tf / gpeak, 4),
                   "traffic": traffic_of(gk), "traffic_source": pmc_src_, "launches_per_step": gemm_n,
-                  "busy_ms_per_step": round(gemm_busy, 3), "sum_of_launch_ms": round(gemm_ms, 3),
+                  "busy_ms_per_step": round(gemm_busy_all, 3), "busy_ms_full_device": round(gemm_busy, 3),
+                  "busy_ms_part_of_device": round(co_busy, 3), "device_share_of_those": round(co_share, 3),
+                  "frac_unweighted": round(gflop_ / gemm_busy_all / gpeak, 4), "sum_of_launch_ms": round(gemm_ms, 3),
                   "frac_by_sum_of_launch_ms": round(gflop_ / gemm_ms / gpeak, 4),
                   "algorithmic_bytes_or_flops_per_launch": round(gflop_ * 1e9 / max(gemm_n, 1)),
                   "algorithmic_gflop_per_step": round(gflop_, 1), "timing": how, "note": gnote,
@@ -530,7 +543,11 @@ def main():
                          "wall time per layer timestep while the family runs (union of the lanes' brackets)")
             rs = step_rec(fk, step_gbs, step_us, fnote + lane_note, pr["step_fwd"][2])
             rb = step_rec(bk, bstep_gbs, bstep_us,
-                          "BPTT timestep: dh = dG_{t+1} W_hh + gate derivatives; same §8(d) byte accounting as the forward timestep" + lane_note,
+                          "BPTT timestep: dh = dG_{t+1} W_hh + gate derivatives; same §8(d) byte accounting as the forward timestep" + lane_note +
+                          ("; option bptt_solo: every launch carries ONE layer on half of the compute units (the layers run one after the other: "
+                           "twice the launches of the two-layer schedule, 0.56 there) while the backward's GEMMs fill the other half - the step is "
+                           "0.4 ms shorter, this family's own time longer (profiles/round5_corun.txt)"
+                           if (co_n and pb == 3 and int(lib.s2vt_set_option(b"bptt_solo", -1))) else ""),
                           pr["step_bwd"][2])
             return rg, rs, rb
 
@@ -553,15 +570,16 @@ def main():
             roof_gemm_alone, roof_step_alone, roof_bstep_alone = rooflines(alone, "pipeline off: launch per timestep, every kernel alone on the GPU", False)
         log("profiled steps done (pipeline block %d)" % prev_blk)
         gname = roof_gemm["kernel"]
-        fam = {gname: live["gemm"][0], roof_step["kernel"]: live["step_fwd"][0],
+        gsum = lambda pr_: pr_["gemm"][0] + pr_.get("gemm_corun", (0.0,))[0]      # all GEMM launches, full-device and co-run ones
+        fam = {gname: gsum(live), roof_step["kernel"]: live["step_fwd"][0],
                roof_bstep["kernel"]: live["step_bwd"][0], "ce": live["ce"][0]}
-        fam_alone = None if args.headline_only else {gname: alone["gemm"][0], roof_step_alone["kernel"]: alone["step_fwd"][0],
+        fam_alone = None if args.headline_only else {gname: gsum(alone), roof_step_alone["kernel"]: alone["step_fwd"][0],
                                                      roof_bstep_alone["kernel"]: alone["step_bwd"][0], "ce": alone["ce"][0]}
         # The headline `roofline` is the kernel family with the LARGEST live time in THIS run (sum of its launch durations, what
         # a per-kernel profile ranks by); the other two families follow as roofline_gemm / roofline_lstm_step[_bwd], and
         # `roofline_min` names the weakest fraction of the three.
         cands = [roof_gemm, roof_step, roof_bstep]
-        live_ms = [live["gemm"][0], live["step_fwd"][0], live["step_bwd"][0]]
+        live_ms = [gsum(live), live["step_fwd"][0], live["step_bwd"][0]]
         roofline = dict(cands[max(range(3), key=lambda i: live_ms[i])])
         roofline["chosen_as"] = "largest sum of launch durations in this run"
         roofline["family_ms_per_step"] = {"batched_gemm": round(live_ms[0], 3), "timestep_fwd": round(live_ms[1], 3),
@@ -845,7 +863,8 @@ def main():
             "roofline_lstm_step_bwd": roof_bstep,
             "roofline_isolated": None if args.headline_only else {"gemm": roof_gemm_alone, "lstm_step": roof_step_alone, "lstm_step_bwd": roof_bstep_alone},
             "kernel_ms_per_step": {k: round(v, 3) for k, v in fam.items()},
-            "kernel_busy_ms_per_step": {"gemm": round(live["gemm"][2], 3), "step_fwd": round(live["step_fwd"][2], 3),
+            "kernel_busy_ms_per_step": {"gemm": round(live["gemm"][2], 3), "gemm_beside_one_layer_launches": round(live.get("gemm_corun", (0, 0, 0.0))[2], 3),
+                                        "step_fwd": round(live["step_fwd"][2], 3),
                                         "step_bwd": round(live["step_bwd"][2], 3), "ce": round(live["ce"][2], 3)},
             "kernel_ms_per_step_isolated": {k: round(v, 3) for k, v in fam_alone.items()} if fam_alone else None,
             "hbm_bytes_per_step": hbm_step,

@@ -478,7 +478,8 @@ int s2vt_test_occupy_cus(int32_t workgroups, int32_t lds_bytes, int64_t microsec
 /* ---------------------------------------------------------------- live kernel timing (bench.py)
  * When enabled, launch sites bracket kernels of one kind with hipEvents on the launch stream.
  * kinds: 0 gemm, 1 lstm_step_fwd (whole sequence loop), 2 lstm_step_bwd (whole sequence loop),
- *        3 ce, 4 logits_argmax. */
+ *        3 ce, 4 logits_argmax, 5 gemm launches planned for PART of the compute units (option corun: beside a one-layer
+ *        persistent launch; kind 0 counts only the GEMMs that have the device to themselves). */
 int s2vt_prof_enable(int32_t on);
 /* Synchronises the recorded events; returns summed milliseconds and launch count for `kind`. */
 int s2vt_prof_read(int32_t kind, double* total_ms, int64_t* launches);

@@ -36,7 +36,8 @@ int post_async_error(hipStream_t st, const int* dev_flags, int kind = 0);
 int device_flags(int** out);
 
 // live kernel timing: launch sites bracket kernels of one kind with hipEvents on the launch stream while s2vt_prof_enable(1)
-enum { K_GEMM = 0, K_STEP_FWD = 1, K_STEP_BWD = 2, K_CE = 3, K_ARGMAX = 4, K_NKINDS = 5 };
+enum { K_GEMM = 0, K_STEP_FWD = 1, K_STEP_BWD = 2, K_CE = 3, K_ARGMAX = 4, K_GEMM_CORUN = 5, K_NKINDS = 6 };   // (5: a GEMM planned for PART of the
+                                                                                                               //  compute units, beside a one-layer persistent launch)
 struct ProfRec { hipEvent_t a, b; int kind; int64_t launches; };
 struct ProfScope {
     hipStream_t s; bool on; ProfRec r;

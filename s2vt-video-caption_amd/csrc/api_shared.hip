@@ -92,7 +92,7 @@ int pdual(const Lane& ln, const float* in, int64_t ld, RowMap imap, int rows, in
 // C[M,N] (+)= A[rows a0.., k ka..ka+K) · B[rows b0.., k kb..kb+K)^T
 int pgemm(const Lane& ln, int M, int N, int K, const PB& A, int a0, int ka, const PB& B, int b0, int kb, float* C,
                  int64_t ldc, RowMap cm, const float* bias, bool acc) {
-    ProfScope ps(ln.s, K_GEMM, 1);
+    ProfScope ps(ln.s, cu_plan_cap_current() ? K_GEMM_CORUN : K_GEMM, 1);
     return gemm_bf16_nt(ln.s, XP, M, N, pad64(K), A.p + (int64_t)a0 * A.ld + koff(ka), A.ld,
                         B.p + (int64_t)b0 * B.ld + koff(kb), B.ld, C, ldc, cm, bias, acc, ln.gws, ln.gws_floats);
 }
@@ -103,7 +103,7 @@ int pgemm(const Lane& ln, int M, int N, int K, const PB& A, int a0, int ka, cons
 // C[M,N] = A_img[a_row0 .., :M]^T . B_img[b_row0 .., :N] over K image rows (row offsets: multiples of 64)
 int pgemm_tt(const Lane& ln, int M, int N, int K, const PB& A, int a_row0, const PB& B, int b_row0, float* C, int64_t ldc,
                     RowMap cm, const float* bias, bool acc) {
-    ProfScope ps(ln.s, K_GEMM, 1);
+    ProfScope ps(ln.s, cu_plan_cap_current() ? K_GEMM_CORUN : K_GEMM, 1);
     if (XP == 1)
         return gemm_b1_tt(ln.s, M, N, K, A.p + (int64_t)a_row0 * A.ld, A.ld, B.p + (int64_t)b_row0 * B.ld, B.ld, C, ldc, cm, bias, acc,
                           ln.gws, ln.gws_floats);

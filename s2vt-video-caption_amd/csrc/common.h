@@ -44,6 +44,7 @@ int planned_compute_units();
 // cap of the calling thread's persistent-GEMM grids (0: none): a driver that launches a GEMM BESIDE a persistent recurrence kernel
 // which holds only part of the compute units plans it for the units left over.  Returns the previous cap.
 int cu_plan_cap(int n);
+int cu_plan_cap_current();
 struct CuPlanCap {
     int prev;
     explicit CuPlanCap(int n) : prev(cu_plan_cap(n)) {}

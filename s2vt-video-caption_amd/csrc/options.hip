@@ -80,6 +80,8 @@ int planned_compute_units() {
     return n / 8 * 8;
 }
 
+int cu_plan_cap_current() { return t_cu_cap; }
+
 int cu_plan_cap(int n) {
     const int prev = t_cu_cap;
     t_cu_cap = n > 0 ? n : 0;
