@@ -479,7 +479,7 @@ def main():
             gemm_busy_all = gemm_busy + co_busy
             gemm_ms, gemm_n = gemm_ms + co_ms, gemm_n + co_n
             sf_ms, sb_ms = pr["step_fwd"][0], pr["step_bwd"][0]
-            gemm_tf = gflop_ / gemm_busy_w            # GFLOP / ms = TFLOP/s over the (device-share weighted) time at least one GEMM was running
+            gemm_tf = gflop_ / gemm_busy_all          # GFLOP / ms = TFLOP/s over the time at least one GEMM was running
             step_us = sf_ms * 1e3 / (2 * T)           # average timestep of one layer, forward (2T per step: both layers)
             bstep_us = sb_ms * 1e3 / (2 * T)
             step_gbs = (pair_ / 2) / (step_us * 1e-6) / 1e9
@@ -497,15 +497,16 @@ def main():
                       "launches twice and is what a per-kernel profile (rocprofv3 --stats) adds up to")
             if co_n:
                 gnote += ("; option corun: %d of the %d launches run on %.0f %% of the compute units beside the one-layer launches of the "
-                          "persistent recurrence (which hold the rest) - their busy time (%.3f ms per step) is priced with that share of the "
-                          "device in `achieved` / `frac`; `frac_unweighted` prices it in full (profiles/round5_corun.txt)"
+                          "persistent recurrence (which hold the rest): `achieved` / `frac` price their busy time (%.3f ms per step) in full, "
+                          "as a per-kernel profile does; `frac_by_device_share` prices it with the share of the device those launches were "
+                          "planned for - the figure that compares with earlier rounds' full-device GEMMs (profiles/round5_corun.txt)"
                           % (co_n, gemm_n, 100 * co_share, co_busy))
             rg = {"kernel": gk, "bound": "mfma", "achieved": round(gemm_tf, 2),
                   "peak": round(gpeak, 1), "unit": "TFLOP/s", "frac": round(gemm_tf / gpeak, 4),
                   "traffic": traffic_of(gk), "traffic_source": pmc_src_, "launches_per_step": gemm_n,
                   "busy_ms_per_step": round(gemm_busy_all, 3), "busy_ms_full_device": round(gemm_busy, 3),
                   "busy_ms_part_of_device": round(co_busy, 3), "device_share_of_those": round(co_share, 3),
-                  "frac_unweighted": round(gflop_ / gemm_busy_all / gpeak, 4), "sum_of_launch_ms": round(gemm_ms, 3),
+                  "frac_by_device_share": round(gflop_ / gemm_busy_w / gpeak, 4), "sum_of_launch_ms": round(gemm_ms, 3),
                   "frac_by_sum_of_launch_ms": round(gflop_ / gemm_ms / gpeak, 4),
                   "algorithmic_bytes_or_flops_per_launch": round(gflop_ * 1e9 / max(gemm_n, 1)),
                   "algorithmic_gflop_per_step": round(gflop_, 1), "timing": how, "note": gnote,

@@ -52,9 +52,15 @@ def _worker(rank, world, port, out_dir, cfg, B):
     # launches of two processes would each hold part of the compute units and wait for the rest (bounded: S2VT_ERR_TIMEOUT) -
     # the documented setting for a shared card is launches per timestep (one process per GPU is the product)
     capi.load().s2vt_set_option(b"persist", 0)
-    opt = torch.optim.Adam(m.parameters(), lr=1e-4)
     red = dp.FlatGradAllReducer(m.parameters()).attach(m)
     assert red.world == 2 and red.comm_stream is not None
+    # what train.py / bench.py build for N > 1: Adam as one launch over the all-reduce buffer (optim.FlatAdam with the reducer's flat
+    # gradient buffer); the reference form - torch.optim.Adam on the parameters - at the smallest configuration
+    if cfg == "tiny":
+        opt = torch.optim.Adam(m.parameters(), lr=1e-4)
+    else:
+        from s2vt_video_caption_amd.optim import FlatAdam
+        opt = FlatAdam(m, lr=1e-4, reducer=red)
     losses, grads1 = [], None
     for s in range(STEPS):
         losses.append(float(dp.train_step(m, crit, opt, feats, caps, mask, red)))
