@@ -44,6 +44,28 @@ def test_workspace_queries_and_argument_errors(lib):
         capi.check(rc, "s2vt_train_forward")
 
 
+def test_option_table_set_query_clamp_and_the_padding_rule(lib):
+    """s2vt_set_option / s2vt_option_name on the host alone (no device call behind them): a negative value queries, values are
+    clamped to the option's range, an unknown name is refused; s2vt_padded_batch follows pad_min_batch and the arithmetic mode."""
+    names = [lib.s2vt_option_name(i).decode() for i in range(lib.s2vt_option_count())]
+    assert {"gemm_mode", "persist", "pipe_block", "corun", "bptt_solo", "pad_min_batch", "gemv", "cu_reserve"} <= set(names)
+    assert lib.s2vt_set_option(b"nope", 1) == -(2 ** 31) and b"nope" in lib.s2vt_last_error()
+    prev = {n: lib.s2vt_set_option(n.encode(), -1) for n in names}
+    try:
+        assert lib.s2vt_set_option(b"corun", 99) == prev["corun"] and lib.s2vt_set_option(b"corun", -1) == 5        # clamped to 0..5
+        assert lib.s2vt_set_option(b"gemm_mode", 2) == prev["gemm_mode"] and lib.s2vt_set_option(b"gemm_mode", -1) == 0   # 0 | 1 | 3 only
+        assert lib.s2vt_set_gemm_mode(3) == 0 and lib.s2vt_set_option(b"gemm_mode", -1) == 3       # the typed setters are views of the table
+        lib.s2vt_set_option(b"pad_min_batch", 33)
+        assert [lib.s2vt_padded_batch(b) for b in (1, 16, 32, 33, 64, 65, 100, 128)] == [1, 16, 32, 64, 64, 128, 128, 128]
+        lib.s2vt_set_option(b"pad_min_batch", 1)
+        assert [lib.s2vt_padded_batch(b) for b in (1, 16, 64)] == [64, 64, 64]
+        lib.s2vt_set_gemm_mode(0)                                  # fp32-input MFMA: no plane path, nothing is padded
+        assert lib.s2vt_padded_batch(100) == 100
+    finally:
+        for n, v in prev.items():
+            lib.s2vt_set_option(n.encode(), v)
+
+
 def test_dropin_module_layout_and_reference_pickle():
     import S2VTModel
     from s2vt_video_caption_amd import capi, synth
