@@ -4,7 +4,7 @@ oracle (oracle/s2vt_oracle.py - the restatement of /root/reference/S2VTModel.py 
   train step : |loss - oracle| and the worst relative error of the 13 gradients (max |g - g_oracle| / max |g_oracle|)
   greedy     : ids of every row whose weakest top-2 margin in the oracle is >= 1e-4 (rows compared / rows equal)
   beam 5     : captions of the first 6 samples whose weakest decision gap in the oracle is >= 1e-5 (compared / equal)
-8 seeds by default; S2VT_SWEEP_SEEDS=64 python -m pytest tests/test_gpu_parity_sweep.py -s wrote profiles/round4_parity_sweep.txt."""
+8 seeds by default; S2VT_SWEEP_SEEDS=64 python -m pytest tests/test_gpu_parity_sweep.py -s wrote profiles/round{4,5}_parity_sweep.txt."""
 import os
 import time
 
