@@ -395,7 +395,7 @@ int s2vt_decode_step_argmax_x3(int32_t B, int32_t H, int32_t V, const float* h, 
  *   gemm_mode       3 | 1 | 0   arithmetic of the batched GEMMs (s2vt_set_gemm_mode)
  *   persist         1 | 0       persistent recurrence kernels (s2vt_set_recurrence_mode)
  *   persist_x3_fwd  1 | 0       split-precision persistent forward of gemm mode 3
- *   persist_x3_bwd  2 | 1 | 0   split-precision persistent BPTT of gemm mode 3 (both layers per launch, one stream): 1 wherever the
+ *   persist_x3_bwd  2 | 1 | 0   split-precision persistent BPTT of gemm mode 3 (layers per launch: option bptt_solo): 1 wherever the
  *                               shape is supported, 2 only where a workgroup carries one 32-row chain (B = 64 at H = 1000), 0 never
  *   pipe_block      32          timesteps per pipeline block (s2vt_set_pipeline_block)
  *   graph           0 | 1       hipGraph replay of the train launch sequences (s2vt_set_graph_mode)

@@ -102,10 +102,11 @@ static inline bool planes_ok(const s2vt_dims& d) { return gemm_mode() != 0 && d.
 static inline int persist_mode() { return option(O_PERSIST); }
 static inline bool persist_on() { return persist_mode() >= 1; }
 static inline bool persist_x3_fwd_on() { return option(O_PERSIST_X3_FWD) != 0 && persist_on(); }
-// split-precision persistent BPTT (reduce-scatter over the gate columns, lstm_persist_x3.hip), both layers per launch, one stream:
-// option persist_x3_bwd = 1 wherever the shape is supported, 2 (default) only where a workgroup carries ONE 32-row chain (B = 64
-// at H = 1000) - there it ties the launch-per-timestep BPTT on two lanes end to end (11.12 vs 11.14 ms per config-2 step) with
-// the recurrence at 0.59 of its roofline instead of 0.25; with two or more chains per workgroup (B = 128, 256) the two-lane
+// split-precision persistent BPTT (reduce-scatter over the gate columns, lstm_persist_x3.hip): option persist_x3_bwd = 1 wherever
+// the shape is supported, 2 (default) only where a workgroup carries ONE 32-row chain (B = 64 at H = 1000).  There a one-layer
+// launch holds half of the compute units and the backward's GEMMs run beside it (options corun / bptt_solo, api_train.hip:
+// 9.9-10.2 ms per config-2 step; two layers per launch with nothing beside them 10.7-11.0, the launch-per-timestep BPTT on two
+// lanes 11.1); with two or more chains per workgroup (B = 128, 256) no unit is left idle and the two-lane launch-per-timestep
 // schedule is 6-8 % faster (20.4 vs 19.2 ms, 39.4 vs 36.5)
 static inline bool persist_x3_bwd_on(int B, int H) {
     const int m = option(O_PERSIST_X3_BWD);
