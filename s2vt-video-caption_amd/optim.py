@@ -5,7 +5,7 @@ view into it: names, shapes, state_dict and pickles are unchanged), keeps the gr
 WRITES into directly (`functional.set_grad_sink`, the mechanism of `dp.FlatGradAllReducer.attach`; `param.grad` are views of it,
 so hooks / inspection still see them) and the two moments in two more; `step()` is `s2vt_adam_step` - 28 bytes per parameter
 in one launch instead of torch's multi-tensor launches.  Same arithmetic as `torch.optim.Adam` operation for operation
-(`tests/test_gpu_kernels.py::test_flat_adam_is_torch_adam`); `lr` may be changed through `param_groups[0]["lr"]`, so
+(`tests/test_gpu_kernels.py::test_flat_adam_step_is_torch_adam`, `::test_flat_adam_trains_the_model_as_torch_adam_does`); `lr` may be changed through `param_groups[0]["lr"]`, so
 `ReduceLROnPlateau` works on it unchanged.
 """
 import ctypes
@@ -66,3 +66,18 @@ class FlatAdam(torch.optim.Optimizer):
         # the kernel wrote through raw pointers: bump the version counters, as an in-place torch op would have (autograd's saved-tensor
         # check and the decode-image cache of functional.py key on them)
         torch.autograd.graph.increment_version(g["params"])
+
+    # (the reference checkpoints the module only, train.py:160-175; a resumable optimizer costs two methods)
+    def state_dict(self):
+        return {"steps": self.steps, "exp_avg": self.flat_m.detach().clone(), "exp_avg_sq": self.flat_v.detach().clone(),
+                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+
+    @torch.no_grad()
+    def load_state_dict(self, state):
+        if state["exp_avg"].numel() != self.n or state["exp_avg_sq"].numel() != self.n:
+            raise capi.S2VTHipError("FlatAdam.load_state_dict: the state belongs to a model of another size")
+        self.steps = int(state["steps"])
+        self.flat_m.copy_(state["exp_avg"])
+        self.flat_v.copy_(state["exp_avg_sq"])
+        for k, v in state["param_groups"][0].items():
+            self.param_groups[0][k] = v

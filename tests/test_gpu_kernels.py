@@ -578,6 +578,16 @@ def test_flat_adam_trains_the_model_as_torch_adam_does(lib):
             m2 = S2VTModel.S2VT(V, Fd, L, dim_hid=H, dim_embed=E)
             m2.load_state_dict(m.state_dict())
             assert torch.equal(ids, m2.to(DEV)(feats, mode="test"))
+            # resume: a second optimizer loaded from this one's state takes the same next step
+            st = opt.state_dict()
+            m3 = S2VTModel.S2VT(V, Fd, L, dim_hid=H, dim_embed=E)
+            m3.load_state_dict(m.state_dict())
+            m3.to(DEV)
+            opt3 = optim.FlatAdam(m3, lr=1e-3)
+            opt3.load_state_dict(st)
+            la = float(dp.train_step(m, crit, opt, feats, caps, mask, None))
+            lb = float(dp.train_step(m3, crit, opt3, feats, caps, mask, None))
+            assert la == lb and all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m3.state_dict().values()))
     (l0, s0), (l1, s1) = runs
     assert l0[0] > l0[-1] and max(abs(a - b) for a, b in zip(l0, l1)) < 2e-5
     assert list(s0) == list(s1)
