@@ -205,9 +205,11 @@ def prof_read(kind):
 
 
 def recurrence_plan(B, H):
-    """(forward, backward) recurrence kernels the train drivers would run for (B, H) in the current modes:
-    0 launch per timestep, 1 persistent bf16, 2 persistent exact-fp32 MFMA, 3 persistent split precision."""
+    """(forward, backward) recurrence kernels the train drivers would run for a batch of B rows (as the caller hands it over: a ragged
+    batch the library pads - s2vt_padded_batch - is planned at its padded size) and hidden size H under the current options:
+    0 launch per timestep, 1 persistent bf16, 3 persistent split precision."""
     import ctypes
     f, b = c_int32(0), c_int32(0)
-    check(load().s2vt_recurrence_plan(int(B), int(H), ctypes.byref(f), ctypes.byref(b)), "s2vt_recurrence_plan")
+    lib = load()
+    check(lib.s2vt_recurrence_plan(int(lib.s2vt_padded_batch(int(B))), int(H), ctypes.byref(f), ctypes.byref(b)), "s2vt_recurrence_plan")
     return f.value, b.value

@@ -10,6 +10,22 @@ if ROOT not in sys.path:
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+# The suite is hermetic with respect to the library's run-time options: every option has ONE default (csrc/options.hip) and a test that
+# needs another value sets it through s2vt_set_option (test_gpu_parity.py::test_c2_train_and_decode_under_every_option runs the
+# whole table).  S2VT_<OPTION> variables of the calling environment would be read at the library's first use and silently move
+# those defaults under tests that assert plans, paths or fp32-level tolerances - they are removed here, before the library loads
+# (and for the child processes some tests start), and named in the report header.
+_KEEP_ENV = {"S2VT_LIB", "S2VT_SWEEP_SEEDS", "S2VT_CPU_THREADS", "S2VT_BENCH_PG", "S2VT_COMMIT"}
+_IGNORED_ENV = {k: os.environ.pop(k) for k in sorted(os.environ) if k.startswith("S2VT_") and k not in _KEEP_ENV}
+
+
+def pytest_report_header(config):
+    if _IGNORED_ENV:
+        return "S2VT option environment ignored by the suite (options are set per test through the C ABI): %s" % (
+            ", ".join("%s=%s" % kv for kv in _IGNORED_ENV.items()))
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

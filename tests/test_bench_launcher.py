@@ -44,7 +44,7 @@ def test_one_rank_rccl_line_carries_the_comm_record():
     after the backward - the fields the first 8-GPU run will be read by."""
     r = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--headline-only"],
              {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29931",
-              "S2VT_BENCH_PG": "1"})
+              "S2VT_BENCH_PG": "1", "S2VT_PERSIST": "1", "S2VT_PIPE_BLOCK": "32"})       # (the options the asserted overlap rests on)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     out = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
     assert out["rccl_ranks"] == 1 and out["n_gpus"] == 1

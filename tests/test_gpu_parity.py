@@ -20,6 +20,25 @@ def _model(d, sd):
     return m.to(DEV)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _options(lib, **kv):
+    """library options set for the block and put back afterwards: a test that asserts a plan or a path SETS the options that plan
+    rests on - the suite must not depend on the S2VT_* environment it is run under"""
+    prev = {k: lib.s2vt_set_option(k.encode(), v) for k, v in kv.items()}
+    assert all(v != -(2 ** 31) for v in prev.values()), "unknown option"
+    try:
+        yield
+    finally:
+        for k, v in prev.items():
+            lib.s2vt_set_option(k.encode(), v)
+
+
+_PLAN_DEFAULTS = dict(persist=1, persist_x3_fwd=1, persist_x3_bwd=2, pipe_block=32)
+
+
 def _setup(g, name):
     d = synth.CONFIGS[name]
     seed = int(g["seed"])
@@ -141,17 +160,13 @@ def test_c2_train_and_decode_under_every_option(lib, golden, option, value, plan
     from s2vt_video_caption_amd import capi
     g = golden("c2")
     d, sd, feats, caps, mask = _setup(g, "c2")
-    prev = lib.s2vt_set_option(option.encode(), value)
-    assert prev != -(2 ** 31), "unknown option"
-    try:
+    with _options(lib, **{**_PLAN_DEFAULTS, option: value}):          # (the option under test on top of the plan's defaults)
         assert lib.s2vt_set_option(option.encode(), -1) == value
         if plan is not None:
             got = capi.recurrence_plan(d["B"], d["H"])
             assert got[0] == plan[0] and (plan[1] is None or got[1] == plan[1]), (got, plan)
         _c2_body(g, d, sd, feats, caps, mask)
         capi.check_async_error()
-    finally:
-        lib.s2vt_set_option(option.encode(), prev)
 
 
 def test_every_option_of_the_library_is_named_in_the_header_and_covered(lib):
@@ -346,7 +361,9 @@ def _ragged_body(lib, B, pad_min, L, Fd, H, E, V):
     if B <= 16:
         with torch.no_grad():
             caps_dev = [[int(t) for t in s] for s in m(feats.to(DEV), mode="beam_search", beam_width=3, max_beam_depth=8)]
-        assert "precomputed" in beam.LAST_PATH, beam.LAST_PATH           # the library's encode phase + plane-path depth step
+        from s2vt_video_caption_amd import capi as _capi
+        if _capi.recurrence_plan(64, H)[0] == 3:                         # (the persistent forward is available under the options of this run)
+            assert "precomputed" in beam.LAST_PATH, beam.LAST_PATH       # the library's encode phase + plane-path depth step
         nb = min(B, 6)            # (the oracle's search is a Python loop per sample)
         ocaps, gaps = orc.beam_search(sd, feats[:nb], beam_width=3, max_depth=8, return_gap="per_sample")
         for b in range(nb):
@@ -544,9 +561,7 @@ def test_library_encode_phase_is_the_beam_searchs_python_encoder(lib):
     sd = synth.make_state_dict(d["V"], d["F"], d["H"], d["E"], seed=31)
     feats = synth.make_batch(B, d["L"], d["F"], d["V"], seed=32)[0].to(DEV)
     m = _model(d, sd).eval()
-    if lib.s2vt_set_recurrence_mode(-1) == 0:
-        pytest.skip("launch-per-timestep recurrence mode (S2VT_PERSIST=0): the library's encode phase is the persistent one")
-    with torch.no_grad():
+    with _options(lib, **_PLAN_DEFAULTS), torch.no_grad():             # (the library's encode phase is the persistent one)
         caps_on = [[int(t.item()) for t in s] for s in m(feats, mode="beam_search", beam_width=5, max_beam_depth=10)]
         assert "precomputed" in beam.LAST_PATH
         keep = beam.PLANE_ENCODER
@@ -583,7 +598,8 @@ def test_library_encode_phase_is_the_beam_searchs_python_encoder(lib):
                                               "word_rnn.weight_ih_l0", "word_rnn.weight_hh_l0", "word_rnn.bias_ih_l0", "word_rnn.bias_hh_l0",
                                               "feat_linear.weight", "feat_linear.bias", "out_linear.weight", "out_linear.bias",
                                               "embedding.weight"))
-    out = functional.decode_encode(feats, plist, m, depth=depth)
+    with _options(lib, **_PLAN_DEFAULTS):
+        out = functional.decode_encode(feats, plist, m, depth=depth)
     assert out is not None
     vh, vc, wh, wc, gx = out
     for got, ref in ((vh, h1), (vc, c1), (wh, h2), (wc, c2)):
@@ -1181,13 +1197,9 @@ def test_persistent_bptt_is_the_launch_per_timestep_backward_within_fp32_roundin
     """Option persist_x3_bwd (the split-precision reduce-scatter BPTT) against the launch-per-timestep BPTT through the whole
     config-2 train step: same loss bits (the forward is unchanged), every gradient within fp32 rounding."""
     outs = []
-    prev = lib.s2vt_set_option(b"persist_x3_bwd", -1)
-    try:
-        for flag in (0, 1):
-            lib.s2vt_set_option(b"persist_x3_bwd", flag)
+    for flag in (0, 1):
+        with _options(lib, **{**_PLAN_DEFAULTS, "persist_x3_bwd": flag}):
             outs.append(_c2_step_summary(lib))
-    finally:
-        lib.s2vt_set_option(b"persist_x3_bwd", prev)
     base, opt = outs
     assert base["plan"] == [3, 0] and opt["plan"] == [3, 3]
     assert base["loss"] == opt["loss"]
