@@ -473,7 +473,7 @@ def main():
             co_share = 0.0
             if co_n:
                 ncu = torch.cuda.get_device_properties(dev).multi_processor_count
-                cap = (ncu - int(lib.s2vt_set_option(b"cu_reserve", -1)) - 128) // 8 * 8      # 126 persistent workgroups + 2 idle ones of its grid
+                cap = (ncu - 128) // 8 * 8          # 126 persistent workgroups + 2 idle ones of its grid hold the rest
                 co_share = max(min(cap / float(ncu), 1.0), 0.0)
             gemm_busy_w = gemm_busy + co_share * co_busy
             gemm_busy_all = gemm_busy + co_busy

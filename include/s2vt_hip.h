@@ -400,8 +400,10 @@ int s2vt_decode_step_argmax_x3(int32_t B, int32_t H, int32_t V, const float* h, 
  *   pipe_block      32          timesteps per pipeline block (s2vt_set_pipeline_block)
  *   graph           0 | 1       hipGraph replay of the train launch sequences (s2vt_set_graph_mode)
  *   decode_fused    1 | 0       schedule of the greedy decode's token steps (s2vt_set_decode_schedule)
- *   cu_reserve      0..128      the persistent GEMMs plan their grids for this many compute units fewer (data-parallel runs
- *                               whose communication kernels hold compute units beside the backward's GEMMs)
+ *   cu_reserve      0..128      the persistent GEMMs of s2vt_train_backward plan their grids for this many compute units fewer FROM
+ *                               THE RELEASE OF GRADIENT GROUP 0 (s2vt_backward_wait_grads) to the end of the backward - the span in
+ *                               which the communication kernels of a data-parallel run hold compute units; everything before
+ *                               it (forward, BPTT and the GEMMs beside it) plans for the whole device
  *   bptt_units      0 | 16 | 32 hidden units per workgroup of the persistent bf16 BPTT (0: 32 where two layers fit the device)
  *   corun           3 (0..5)    persistent split-precision schedule (B = 64): this many TENTHS of a GEMM that nothing waits for (dW_o's
  *                               k range) run beside EACH one-layer first / last stage of the BPTT, planned for the compute units

@@ -96,7 +96,10 @@ static bool g_grad_ev_set[2] = {false, false};
 // launch of the backward - g_bwd_group0_after = persistent BPTT launches enqueued when group 0's event was last recorded
 static int g_bwd_persist_launches = 0, g_bwd_group0_after = 0;
 static int grads_ready(int group, hipStream_t s) {
-    if (group == 0) g_bwd_group0_after = g_bwd_persist_launches;
+    if (group == 0) {
+        g_bwd_group0_after = g_bwd_persist_launches;
+        cu_reserve_window(true);         // from here on a collective's kernels may hold compute units beside this backward's GEMMs
+    }
     if (!g_grad_ev[group]) S2VT_HIP(hipEventCreateWithFlags(&g_grad_ev[group], hipEventDisableTiming));
     // inside a capture nothing is recorded (an event recorded on a capturing stream cannot be waited for from outside, and
     // external event-record nodes are refused by this runtime): the backward driver records both groups behind the graph
@@ -411,7 +414,9 @@ static int train_backward_x3(const s2vt_dims* d, const s2vt_params* p, const flo
         if (!corun_k && ce_pow2 && (rc = scale_by_device_scalar(sx, g->out_w, (int64_t)V * H, w.ce_alpha))) return rc;
     }
     if ((rc = colsum_finish(sx, w.colsum_c, cdiv(R, 64), V, g->out_b, false))) return rc;
-    if (!corun_k && (rc = grads_ready(0, sx))) return rc;
+    // (a persistent BPTT re-records "group 0 is final" behind its last launch - no collective may start beside one - so it is not
+    // recorded here for those schedules: option cu_reserve counts from the release that holds)
+    if (!corun_k && !pbf_bwd && !px3_bwd && (rc = grads_ready(0, sx))) return rc;
     if (!bf && (rc = transpose_f32(sx, p->vid_w_hh, 4 * H, H, w.wt1))) return rc;
     const std::vector<int> bd = pipe_bounds(T, L, (pbf_bwd || px3_bwd) ? balanced_block(L, blk) : blk);
     int bias_chunk = 64;      // rows per partial column sum of dG (32: written by the persistent split-precision BPTT itself)
@@ -908,6 +913,10 @@ static int train_backward_core(const s2vt_dims* d, const s2vt_params* p, const f
                                const float* out_mask) {
     g_bwd_persist_launches = 0;          // (s2vt_backward_order describes THIS backward, whichever driver it takes)
     g_bwd_group0_after = 0;
+    struct ReserveWindow {               // option cu_reserve: off until gradient group 0 is released, off again when the backward is enqueued
+        ReserveWindow() { cu_reserve_window(false); }
+        ~ReserveWindow() { cu_reserve_window(false); }
+    } reserve_window;
     const TrainWS w = carve_train(*d, workspace);
     S2VT_REQUIRE(workspace_bytes >= w.bytes, "s2vt_train_backward: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
     hipStream_t st = (hipStream_t)stream;

@@ -45,6 +45,9 @@ int planned_compute_units();
 // which holds only part of the compute units plans it for the units left over.  Returns the previous cap.
 int cu_plan_cap(int n);
 int cu_plan_cap_current();
+// option cu_reserve applies while a collective may be running beside the calling thread's launches: inside s2vt_train_backward from
+// the release of gradient group 0 (s2vt_backward_wait_grads) to the end of the backward.  Returns the previous state.
+bool cu_reserve_window(bool on);
 struct CuPlanCap {
     int prev;
     explicit CuPlanCap(int n) : prev(cu_plan_cap(n)) {}

@@ -21,7 +21,7 @@ static const OptionDef kOptions[O_COUNT] = {
     /* O_PIPE_BLOCK     */ {"pipe_block", 32, 0, 4096},     // timesteps per pipeline block (0: one stream, no layer pipeline)
     /* O_GRAPH          */ {"graph", 0, 0, 1},              // hipGraph replay of the train forward / backward launch sequences
     /* O_DECODE_FUSED   */ {"decode_fused", 1, 0, 1},       // greedy decode: recurrent GEMM inside the argmax launch
-    /* O_CU_RESERVE     */ {"cu_reserve", 0, 0, 128},       // persistent GEMMs plan for this many compute units fewer
+    /* O_CU_RESERVE     */ {"cu_reserve", 0, 0, 128},       // persistent GEMMs of the backward plan for this many compute units fewer once gradient group 0 is released
     /* O_BPTT_UNITS     */ {"bptt_units", 0, 0, 32},        // persistent bf16 BPTT: 32 | 16 hidden units per workgroup (0: 32 where it fits)
     /* O_GEMV           */ {"gemv", 1, 0, 2},               // launch-per-timestep forward step as gate GEMVs (lstm_gemv.hip): 1 at B <= 4, 2 at B <= 8, 0 never
     /* O_PAD_MIN_BATCH  */ {"pad_min_batch", 33, 1, 64},    // ragged batches of at least this size are padded to a multiple of 64 (plane path)
@@ -64,6 +64,13 @@ int option_set(int id, int value) {
 }
 
 static thread_local int t_cu_cap = 0;
+static thread_local bool t_reserve_window = false;
+
+bool cu_reserve_window(bool on) {
+    const bool prev = t_reserve_window;
+    t_reserve_window = on;
+    return prev;
+}
 
 int planned_compute_units() {
     static int device_cus = 0;
@@ -74,7 +81,7 @@ int planned_compute_units() {
         device_cus = n;
     }
     int n = device_cus;
-    const int reserve = option(O_CU_RESERVE);
+    const int reserve = t_reserve_window ? option(O_CU_RESERVE) : 0;
     if (reserve > 0 && reserve < n - 8) n -= reserve;
     if (t_cu_cap >= 8 && t_cu_cap < n) n = t_cu_cap;
     return n / 8 * 8;
